@@ -1,0 +1,87 @@
+"""ctypes binding of liblec_hip.so (the C ABI declared in include/lec_hip.h).
+
+The product path has no CPU fallback: if the HIP library is missing, loading raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblec_hip.so")
+
+LEC_ABI_VERSION = 1
+LEC_NSTAT = 32
+LEC_NLEVRAW = 40
+LEC_NSCALAR = 16
+LEC_NLEVTAB = 21
+LEC_F64, LEC_F32 = 0, 1
+
+EXPORTS = ["lec_version", "lec_last_error", "lec_max_row", "lec_rowstats", "lec_reduce"]
+
+
+class RowstatsArgs(C.Structure):
+    """struct lec_rowstats_args (include/lec_hip.h)."""
+    _fields_ = [
+        ("tair_d", C.c_void_p), ("u_d", C.c_void_p), ("v_d", C.c_void_p), ("omega_d", C.c_void_p),
+        ("geopt_d", C.c_void_p), ("dTdt_d", C.c_void_p),
+        ("dtype", C.c_int32), ("with_q", C.c_int32),
+        ("nt", C.c_int32), ("nl", C.c_int32), ("ny", C.c_int32), ("nx", C.c_int32),
+        ("t_begin", C.c_int32), ("t_count", C.c_int32),
+        ("n_box", C.c_int32), ("nxb_max", C.c_int32), ("nyb_max", C.c_int32), ("lon_uniform", C.c_int32),
+        ("box_d", C.c_void_p), ("boxtab_d", C.c_void_p), ("wlon_d", C.c_void_p), ("glon_d", C.c_void_p),
+        ("lattab_d", C.c_void_p), ("levtab_d", C.c_void_p), ("tcoef_d", C.c_void_p),
+        ("rows_d", C.c_void_p), ("stream", C.c_void_p),
+    ]
+
+
+class ReduceArgs(C.Structure):
+    """struct lec_reduce_args (include/lec_hip.h)."""
+    _fields_ = [
+        ("rows_d", C.c_void_p),
+        ("t_count", C.c_int32), ("nl", C.c_int32), ("n_box", C.c_int32), ("nyb_max", C.c_int32),
+        ("box_d", C.c_void_p), ("boxtab2_d", C.c_void_p), ("lattab2_d", C.c_void_p), ("levtab2_d", C.c_void_p),
+        ("phi_scale", C.c_double),
+        ("am_d", C.c_void_p), ("levraw_d", C.c_void_p), ("scalars_d", C.c_void_p), ("levels_d", C.c_void_p),
+        ("nanflag_d", C.c_void_p), ("stream", C.c_void_p),
+    ]
+
+
+class LecLibraryError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Loads liblec_hip.so (once).  Raises LecLibraryError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LecLibraryError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C lorenzcycletoolkit_amd/csrc` (there is no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    lib.lec_version.restype = C.c_int
+    lib.lec_last_error.restype = C.c_char_p
+    lib.lec_max_row.restype = C.c_int
+    lib.lec_max_row.argtypes = [C.c_int, C.c_int]
+    lib.lec_rowstats.restype = C.c_int
+    lib.lec_rowstats.argtypes = [C.POINTER(RowstatsArgs)]
+    lib.lec_reduce.restype = C.c_int
+    lib.lec_reduce.argtypes = [C.POINTER(ReduceArgs)]
+    if lib.lec_version() != LEC_ABI_VERSION:
+        raise LecLibraryError(f"liblec_hip.so ABI {lib.lec_version()} != expected {LEC_ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    """Maps a C-ABI return code onto the reference's error behaviour: bad arguments raise ValueError
+    (the reference raises ValueError for invalid boxes, lec_fixed_framework.py:121-154)."""
+    if rc != 0:
+        msg = load().lec_last_error().decode("utf-8", "replace")
+        if rc == 1:
+            raise ValueError(f"{what}: {msg}")
+        raise LecLibraryError(f"{what} failed (code {rc}): {msg}")

@@ -1,0 +1,18 @@
+// lec_internal.h -- constants and helpers shared by the HIP translation units (not part of the ABI).
+#ifndef LEC_INTERNAL_H
+#define LEC_INTERNAL_H
+
+// MetPy 1.6.2 constants used by the reference (thermodynamics.py:21-22, conversion_terms.py:31,
+// boundary_terms.py:31, energy_contents.py:31); SURVEY.md appendix E.
+#define LEC_G 9.80665
+#define LEC_RE 6371008.7714
+#define LEC_RD (8.314462618 / 28.96546e-3)
+#define LEC_CP_D (1.4 * LEC_RD / (1.4 - 1.0))
+
+// vectors per lane of the largest row kernel (rows up to 256 * LEC_MAX_ITERS vectors)
+#define LEC_MAX_ITERS 8
+
+// records an error message (thread-local) and returns `code`
+int lec_set_error(int code, const char* msg);
+
+#endif

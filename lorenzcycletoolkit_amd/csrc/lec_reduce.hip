@@ -1,0 +1,351 @@
+// lec_reduce.hip -- stage 2 of the MI355X Lorenz-Energy-Cycle engine (gfx950, wave64).
+//
+// Consumes the per-(time, level, lat) row records of lec_rowstats and produces, per time step, the 16
+// integrated terms and the 21 per-level tables.  Three small kernels (O(level x lat) work, <1 % of the
+// stage-1 bytes):
+//   lec_area_means_kernel   {[X]} cos-weighted meridional means of the six zonal means        (calc_averages.py:46-78)
+//   lec_level_terms_kernel  sigma, every per-level integrand and boundary piece of one level
+//                           (energy_contents.py:99-165, conversion_terms.py:103-245,
+//                            boundary_terms.py:125-418, generation_and_dissipation_terms.py:122-152)
+//   lec_vertical_kernel     _handle_nans + integrate(level) + boundary assembly               (energy_contents.py:190-208)
+// Formulas: SURVEY.md appendix A / F (factored through row statistics; exact in exact arithmetic).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/lec_hip.h"
+#include "lec_internal.h"
+
+namespace {
+
+constexpr double kG = LEC_G, kRe = LEC_RE, kRd = LEC_RD, kCp = LEC_CP_D;
+constexpr int kMaxNl = 160;
+
+enum {
+    V_AZ = 0, V_AE, V_KZ, V_KE, V_CZ2, V_CE2, V_CA1, V_CA2, V_CK1, V_CK2, V_CK3, V_CK4, V_CK5, V_GZ, V_GE,
+    V_B1 = 15,  // BAz BAe BKz BKe BPhiZ BPhiE : east-west term, integrated over phi
+    V_B2 = 21,  // north-south term
+    V_B3 = 27,  // bottom-top term (area mean)
+    V_SIG = 33,
+    V_COUNT = 34
+};
+static_assert(V_COUNT <= LEC_NLEVRAW, "levraw record too small");
+
+struct RedParams {
+    const double* rows;
+    int t_count, nl, n_box, nyb_max;
+    const int* box;
+    const double* boxtab2;
+    const double* lattab2;
+    const double* levtab2;
+    double phi_scale;
+    double* am;
+    double* levraw;
+    double* scalars;
+    double* levels;
+    int* nanflag;
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// grid (nl, t_count), block 64
+__global__ void __launch_bounds__(64) lec_area_means_kernel(const RedParams p) {
+    const int k = blockIdx.x, tl = blockIdx.y, lane = threadIdx.x;
+    const int bi = (p.n_box == 1) ? 0 : tl;
+    const int nyb = p.box[4 * bi + 3] - p.box[4 * bi + 2] + 1;
+    const double* rec = p.rows + (size_t)(tl * p.nl + k) * p.nyb_max * LEC_NSTAT;
+    const double* lt = p.lattab2 + (size_t)bi * p.nyb_max * 8;
+    double a[6] = {0, 0, 0, 0, 0, 0};
+    for (int jb = lane; jb < nyb; jb += 64) {
+        const double cw = lt[8 * jb + 0];
+        const double* r = rec + (size_t)jb * LEC_NSTAT;
+#pragma unroll
+        for (int s = 0; s < 6; ++s) a[s] += cw * r[s];
+    }
+#pragma unroll
+    for (int s = 0; s < 6; ++s) a[s] = wave_sum(a[s]);
+    if (lane == 0) {
+        double* o = p.am + (size_t)(tl * p.nl + k) * 8;
+        o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3];
+        o[4] = a[4] * p.phi_scale; o[5] = a[5]; o[6] = 0.0; o[7] = 0.0;
+    }
+}
+
+// grid (nl, t_count), block 64
+__global__ void __launch_bounds__(64) lec_level_terms_kernel(const RedParams p) {
+    const int k = blockIdx.x, tl = blockIdx.y, lane = threadIdx.x;
+    const int nl = p.nl;
+    const int bi = (p.n_box == 1) ? 0 : tl;
+    const int nyb = p.box[4 * bi + 3] - p.box[4 * bi + 2] + 1;
+    const int km = k > 0 ? k - 1 : k, kp = k < nl - 1 ? k + 1 : k;
+    const double* am = p.am + (size_t)tl * nl * 8;
+    const double aT = am[8 * k + 0], aW = am[8 * k + 3], aP = am[8 * k + 4], aQ = am[8 * k + 5];
+    const double aTm = am[8 * km + 0], aTp = am[8 * kp + 0];
+    const double pk = p.levtab2[4 * k + 0], pa = p.levtab2[4 * k + 1], pb = p.levtab2[4 * k + 2], pc = p.levtab2[4 * k + 3];
+
+    // static stability (thermodynamics.py:55-70); the zonal/area mean commutes with the linear d/dp
+    double sig = kG * aT / kCp - (pk * kG / kRd) * (pa * aTm + pb * aT + pc * aTp);
+    sig = (sig > 0.03) ? sig : 0.03;
+
+    const size_t lstride = (size_t)p.nyb_max * LEC_NSTAT;
+    const double* rec = p.rows + (size_t)(tl * nl + k) * lstride;
+    const double* recm = p.rows + (size_t)(tl * nl + km) * lstride;
+    const double* recp = p.rows + (size_t)(tl * nl + kp) * lstride;
+    const double* lt = p.lattab2 + (size_t)bi * p.nyb_max * 8;
+    const double ps = p.phi_scale;
+
+    double acc[V_COUNT];
+#pragma unroll
+    for (int i = 0; i < V_COUNT; ++i) acc[i] = 0.0;
+
+    for (int jb = lane; jb < nyb; jb += 64) {
+        const int jm = jb > 0 ? jb - 1 : jb, jp = jb < nyb - 1 ? jb + 1 : jb;
+        const double* r = rec + (size_t)jb * LEC_NSTAT;
+        const double* rjm = rec + (size_t)jm * LEC_NSTAT;
+        const double* rjp = rec + (size_t)jp * LEC_NSTAT;
+        const double* rkm = recm + (size_t)jb * LEC_NSTAT;
+        const double* rkp = recp + (size_t)jb * LEC_NSTAT;
+        const double cw = lt[8 * jb + 0], wphi = lt[8 * jb + 1], c = lt[8 * jb + 2], tn = lt[8 * jb + 3];
+        const double gra = lt[8 * jb + 4], grb = lt[8 * jb + 5], grc = lt[8 * jb + 6];
+        const double cm = lt[8 * jm + 2], cp = lt[8 * jp + 2];
+
+        const double mT = r[LEC_S_MT], mU = r[LEC_S_MU], mV = r[LEC_S_MV], mW = r[LEC_S_MW];
+        const double mP = r[LEC_S_MP] * ps, mQ = r[LEC_S_MQ];
+        const double Ts = mT - aT, Ws = mW - aW, Ps = mP - aP, Qs = mQ - aQ;      // X* = [X] - {[X]}
+        const double sTT = r[LEC_S_TT], sUU = r[LEC_S_UU], sVV = r[LEC_S_VV], sVT = r[LEC_S_VT], sWT = r[LEC_S_WT];
+        const double sUV = r[LEC_S_UV], sWU = r[LEC_S_WU], sWV = r[LEC_S_WV], sWP = r[LEC_S_WP] * ps, sQT = r[LEC_S_QT];
+
+        const double dphiTc = gra * (rjm[LEC_S_MT] - aT) * cm + grb * Ts * c + grc * (rjp[LEC_S_MT] - aT) * cp;
+        const double dphiUc = gra * (rjm[LEC_S_MU] / cm) + grb * (mU / c) + grc * (rjp[LEC_S_MU] / cp);
+        const double dphiV = gra * rjm[LEC_S_MV] + grb * mV + grc * rjp[LEC_S_MV];
+        const double dpT = pa * (rkm[LEC_S_MT] - aTm) + pb * Ts + pc * (rkp[LEC_S_MT] - aTp);
+        const double dpU = pa * rkm[LEC_S_MU] + pb * mU + pc * rkp[LEC_S_MU];
+
+        acc[V_AZ] += cw * (Ts * Ts);
+        acc[V_AE] += cw * sTT;
+        acc[V_KZ] += cw * (mU * mU + mV * mV);
+        acc[V_KE] += cw * (sUU + sVV);
+        acc[V_CZ2] += cw * (Ws * Ts);
+        acc[V_CE2] += cw * sWT;
+        acc[V_CA1] += cw * (sVT * dphiTc);
+        acc[V_CA2] += cw * (sWT * dpT);
+        acc[V_CK1] += cw * (c * sUV / kRe * dphiUc);
+        acc[V_CK2] += cw * (sVV / kRe * dphiV);
+        acc[V_CK3] += cw * (tn * sUU * mV / kRe);
+        acc[V_CK4] += cw * (sWU * dpU);
+        acc[V_CK5] += cw * (sWV * dpU);   // sic: d[u]/dp, conversion_terms.py:225-229
+        acc[V_GZ] += cw * (Qs * Ts);
+        acc[V_GE] += cw * sQT;
+
+        // east-west pieces, plain trapezoid over phi (boundary_terms.py:135-147,188-197,237-246,287-296,337-344,377-388)
+        const double TW = r[LEC_S_TW], TE = r[LEC_S_TE], uW = r[LEC_S_UW], uE = r[LEC_S_UE], vW = r[LEC_S_VW], vE = r[LEC_S_VE];
+        const double TpW = TW - mT, TpE = TE - mT;
+        const double upW = uW - mU, upE = uE - mU, vpW = vW - mV, vpE = vE - mV;
+        const double EW_ = upW * upW + vpW * vpW, EE_ = upE * upE + vpE * vpE;
+        const double KW_ = uW * uW + vW * vW - EW_, KE_ = uE * uE + vE * vE - EE_;
+        acc[V_B1 + 0] += wphi * (((2 * Ts * TpE * uE) + (Ts * Ts * uE)) - ((2 * Ts * TpW * uW) + (Ts * Ts * uW)));
+        acc[V_B1 + 1] += wphi * (uE * (TpE * TpE) - uW * (TpW * TpW));
+        acc[V_B1 + 2] += wphi * (uE * KE_ - uW * KW_);
+        acc[V_B1 + 3] += wphi * (uE * EE_ - uW * EW_);
+        acc[V_B1 + 4] += wphi * (mV * Ps);
+        acc[V_B1 + 5] += wphi * (vpE * Ps - vpW * Ps);
+
+        // north-south pieces (boundary_terms.py:150-163,200-212,249-262,299-310,347-356,390-399)
+        const double sgn = (jb == nyb - 1 ? 1.0 : 0.0) - (jb == 0 ? 1.0 : 0.0);
+        if (sgn != 0.0) {
+            acc[V_B2 + 0] += sgn * (((sVT * 2 * Ts) + (Ts * Ts * mV)) * c);
+            acc[V_B2 + 1] += sgn * (r[LEC_S_VTT] * c);
+            acc[V_B2 + 2] += sgn * (r[LEC_S_KV] * c);
+            acc[V_B2 + 3] += sgn * (r[LEC_S_EV] * c);
+            acc[V_B2 + 4] += sgn * (mV * Ps * c);
+            acc[V_B2 + 5] += sgn * (mV * Ps * c);   // BPhiE term 2 uses zonal means, boundary_terms.py:390
+        }
+
+        // bottom-top pieces, area means (boundary_terms.py:165-176,214-221,264-271,312-318,358-363,401-413)
+        acc[V_B3 + 0] += cw * ((2 * sWT) * Ts + mW * (Ts * Ts));
+        acc[V_B3 + 1] += cw * r[LEC_S_WTT];
+        acc[V_B3 + 2] += cw * r[LEC_S_KW];
+        acc[V_B3 + 3] += cw * r[LEC_S_EW];
+        acc[V_B3 + 4] += cw * (Ws * Ps);
+        acc[V_B3 + 5] += cw * sWP;
+    }
+#pragma unroll
+    for (int i = 0; i < V_SIG; ++i) acc[i] = wave_sum(acc[i]);
+
+    if (lane == 0) {
+        double* o = p.levraw + (size_t)(tl * nl + k) * LEC_NLEVRAW;
+        const double s2 = 2 * sig, g2 = 2 * kG;
+        o[V_AZ] = acc[V_AZ] / s2;
+        o[V_AE] = acc[V_AE] / s2;
+        o[V_KZ] = acc[V_KZ];
+        o[V_KE] = acc[V_KE];
+        o[V_CZ2] = acc[V_CZ2];
+        o[V_CE2] = acc[V_CE2];
+        o[V_CA1] = acc[V_CA1] / (2 * kRe * sig);
+        o[V_CA2] = acc[V_CA2] / sig;
+        o[V_CK1] = acc[V_CK1]; o[V_CK2] = acc[V_CK2]; o[V_CK3] = acc[V_CK3]; o[V_CK4] = acc[V_CK4]; o[V_CK5] = acc[V_CK5];
+        o[V_GZ] = acc[V_GZ] / (kCp * sig);
+        o[V_GE] = acc[V_GE] / (kCp * sig);
+        o[V_B1 + 0] = acc[V_B1 + 0] / s2; o[V_B1 + 1] = acc[V_B1 + 1] / s2;
+        o[V_B1 + 2] = acc[V_B1 + 2] / g2; o[V_B1 + 3] = acc[V_B1 + 3] / g2;
+        o[V_B1 + 4] = acc[V_B1 + 4] / kG; o[V_B1 + 5] = acc[V_B1 + 5] / kG;
+        o[V_B2 + 0] = acc[V_B2 + 0] / s2; o[V_B2 + 1] = acc[V_B2 + 1] / s2;
+        o[V_B2 + 2] = acc[V_B2 + 2] / g2; o[V_B2 + 3] = acc[V_B2 + 3] / g2;
+        o[V_B2 + 4] = acc[V_B2 + 4] / kG; o[V_B2 + 5] = acc[V_B2 + 5] / kG;
+        o[V_B3 + 0] = acc[V_B3 + 0] / s2; o[V_B3 + 1] = acc[V_B3 + 1] / s2;
+        o[V_B3 + 2] = acc[V_B3 + 2] / g2; o[V_B3 + 3] = acc[V_B3 + 3] / g2;
+        o[V_B3 + 4] = acc[V_B3 + 4] / kG; o[V_B3 + 5] = acc[V_B3 + 5] / kG;
+        o[V_SIG] = sig;
+        for (int i = V_COUNT; i < LEC_NLEVRAW; ++i) o[i] = 0.0;
+    }
+}
+
+// functions of level handled by lec_vertical_kernel (one lane each)
+enum {
+    F_AZ = 0, F_AE, F_KZ, F_KE, F_CZ, F_CA, F_CK, F_CE, F_GZ, F_GE,
+    F_B1 = 10, F_B2 = 16, F_B3 = 22, F_COUNT = 28
+};
+
+// grid (t_count), block 64
+__global__ void __launch_bounds__(64) lec_vertical_kernel(const RedParams p) {
+    __shared__ double fn[F_COUNT][kMaxNl];
+    __shared__ double res[F_COUNT];
+    __shared__ int nans[64];
+    const int tl = blockIdx.x, lane = threadIdx.x, nl = p.nl;
+    const int bi = (p.n_box == 1) ? 0 : tl;
+    const double* raw = p.levraw + (size_t)tl * nl * LEC_NLEVRAW;
+    const double* lv = p.levtab2;
+
+    int nnan = 0;
+    if (lane < F_COUNT) {
+        const int f = lane;
+        // build the function of level
+        for (int k = 0; k < nl; ++k) {
+            const double* o = raw + (size_t)k * LEC_NLEVRAW;
+            const double c1k = kRd / (lv[4 * k] * kG);   // Rd / (p g), conversion_terms.py:146,172
+            double x;
+            switch (f) {
+                case F_AZ: x = o[V_AZ]; break;
+                case F_AE: x = o[V_AE]; break;
+                case F_KZ: x = o[V_KZ]; break;
+                case F_KE: x = o[V_KE]; break;
+                case F_CZ: x = -(c1k * o[V_CZ2]); break;
+                case F_CA: x = -(o[V_CA1] + o[V_CA2]); break;
+                case F_CK: x = o[V_CK1] + o[V_CK2] + o[V_CK3] + o[V_CK4] + o[V_CK5]; break;
+                case F_CE: x = -(c1k * o[V_CE2]); break;
+                case F_GZ: x = o[V_GZ]; break;
+                case F_GE: x = o[V_GE]; break;
+                default: x = o[V_B1 + (f - F_B1)]; break;   // V_B1.. V_B3 are contiguous like F_B1..F_B3
+            }
+            fn[f][k] = x;
+            nnan += isnan(x) ? 1 : 0;
+        }
+        // _handle_nans: linear interpolation in p across interior gaps, remaining (leading/trailing) levels dropped
+        int k0 = 0, k1 = nl - 1;
+        if (nnan) {
+            int last_ok = -1;
+            for (int k = 0; k < nl; ++k) {
+                if (!isnan(fn[f][k])) { last_ok = k; continue; }
+                int nxt = k + 1;
+                while (nxt < nl && isnan(fn[f][nxt])) ++nxt;
+                if (last_ok >= 0 && nxt < nl) {
+                    const double xl = lv[4 * last_ok], xr = lv[4 * nxt], yl = fn[f][last_ok], yr = fn[f][nxt];
+                    const double slope = (yr - yl) / (xr - xl);
+                    for (int q = k; q < nxt; ++q) fn[f][q] = slope * (lv[4 * q] - xl) + yl;
+                }
+                k = nxt - 1;
+            }
+            while (k0 < nl && isnan(fn[f][k0])) ++k0;
+            while (k1 >= 0 && isnan(fn[f][k1])) --k1;
+        }
+        double r;
+        if (k0 > k1) {
+            r = nan("");
+        } else if (f >= F_B3) {
+            r = fn[f][k1] - fn[f][k0];                       // .isel(level=-1) - .isel(level=0)
+        } else {
+            r = 0.0;
+            for (int k = k0; k < k1; ++k) r += (lv[4 * (k + 1)] - lv[4 * k]) * 0.5 * (fn[f][k + 1] + fn[f][k]);
+        }
+        res[f] = r;
+    }
+    nans[lane] = nnan;
+    __syncthreads();
+
+    if (lane == 0) {
+        const double c1 = p.boxtab2[4 * bi + 0], c2 = p.boxtab2[4 * bi + 1];
+        double* s = p.scalars + (size_t)tl * LEC_NSCALAR;
+        s[0] = res[F_AZ];
+        s[1] = res[F_AE];
+        s[2] = res[F_KZ] / (2 * kG);
+        s[3] = res[F_KE] / (2 * kG);
+        s[4] = res[F_CZ];
+        s[5] = res[F_CA];
+        s[6] = res[F_CK] / kG;
+        s[7] = res[F_CE];
+        for (int i = 0; i < 6; ++i) s[8 + i] = res[F_B1 + i] * c1 + res[F_B2 + i] * c2 - res[F_B3 + i];
+        s[14] = res[F_GZ];
+        s[15] = res[F_GE];
+        int tot = 0;
+        for (int i = 0; i < F_COUNT; ++i) tot += nans[i];
+        p.nanflag[tl] = tot;
+    }
+
+    // per-level tables, order of lec_fixed_framework.py:172-194
+    double* L = p.levels + (size_t)tl * LEC_NLEVTAB * nl;
+    for (int k = lane; k < nl; k += 64) {
+        const double* o = raw + (size_t)k * LEC_NLEVRAW;
+        const double c1k = kRd / (lv[4 * k] * kG);
+        L[0 * nl + k] = fn[F_AZ][k];
+        L[1 * nl + k] = fn[F_AE][k];
+        L[2 * nl + k] = fn[F_KZ][k];
+        L[3 * nl + k] = fn[F_KE][k];
+        L[4 * nl + k] = fn[F_GE][k];
+        L[5 * nl + k] = fn[F_GZ][k];
+        L[6 * nl + k] = fn[F_CZ][k];
+        L[7 * nl + k] = c1k;
+        L[8 * nl + k] = o[V_CZ2];
+        L[9 * nl + k] = fn[F_CA][k];
+        L[10 * nl + k] = o[V_CA1];
+        L[11 * nl + k] = o[V_CA2];
+        L[12 * nl + k] = fn[F_CE][k];
+        L[13 * nl + k] = c1k;
+        L[14 * nl + k] = o[V_CE2];
+        L[15 * nl + k] = fn[F_CK][k];
+        L[16 * nl + k] = o[V_CK1];
+        L[17 * nl + k] = o[V_CK2];
+        L[18 * nl + k] = o[V_CK3];
+        L[19 * nl + k] = o[V_CK4];
+        L[20 * nl + k] = o[V_CK5];
+    }
+}
+
+}  // namespace
+
+extern "C" int lec_reduce(const lec_reduce_args* a) {
+    if (!a) return lec_set_error(LEC_ERR_ARG, "lec_reduce: null args");
+    if (!a->rows_d || !a->box_d || !a->boxtab2_d || !a->lattab2_d || !a->levtab2_d || !a->am_d || !a->levraw_d ||
+        !a->scalars_d || !a->levels_d || !a->nanflag_d)
+        return lec_set_error(LEC_ERR_ARG, "lec_reduce: null pointer argument");
+    if (a->t_count < 1 || a->nl < 2 || a->nyb_max < 2) return lec_set_error(LEC_ERR_ARG, "lec_reduce: needs t_count>=1, nl>=2, nyb_max>=2");
+    if (a->nl > kMaxNl) return lec_set_error(LEC_ERR_UNSUPPORTED, "lec_reduce: more than 160 levels");
+    if (a->t_count > 65535) return lec_set_error(LEC_ERR_UNSUPPORTED, "lec_reduce: more than 65535 time steps in one call");
+    if (a->n_box != 1 && a->n_box != a->t_count) return lec_set_error(LEC_ERR_ARG, "lec_reduce: n_box must be 1 or t_count");
+    RedParams p;
+    p.rows = a->rows_d; p.t_count = a->t_count; p.nl = a->nl; p.n_box = a->n_box; p.nyb_max = a->nyb_max;
+    p.box = a->box_d; p.boxtab2 = a->boxtab2_d; p.lattab2 = a->lattab2_d; p.levtab2 = a->levtab2_d;
+    p.phi_scale = a->phi_scale; p.am = a->am_d; p.levraw = a->levraw_d; p.scalars = a->scalars_d;
+    p.levels = a->levels_d; p.nanflag = a->nanflag_d;
+    hipStream_t st = (hipStream_t)a->stream;
+    const dim3 grid2(a->nl, a->t_count);
+    hipLaunchKernelGGL(lec_area_means_kernel, grid2, dim3(64), 0, st, p);
+    hipLaunchKernelGGL(lec_level_terms_kernel, grid2, dim3(64), 0, st, p);
+    hipLaunchKernelGGL(lec_vertical_kernel, dim3(a->t_count), dim3(64), 0, st, p);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return lec_set_error(LEC_ERR_LAUNCH, hipGetErrorString(e));
+    return LEC_OK;
+}

@@ -1,0 +1,397 @@
+// lec_rowstats.hip -- stage 1 of the MI355X Lorenz-Energy-Cycle engine (gfx950, wave64).
+//
+// One workgroup per (time, level, box-latitude) longitude row.  The row of every field is held in
+// registers (16-byte coalesced loads, ITERS vectors per lane); sweep 1 forms the trapezoid-weighted
+// zonal means (and the diabatic-heating residual Q point by point), sweep 2 the eddy covariances and
+// mixed moments about those means -- the same "deviation from the zonal mean, then average" order as
+// the reference (box_data.py:157-231, calc_averages.py:25-43), in fp64.  Block-wide sums go through an
+// LDS transpose (conflict-free ds_write_b64 / ds_read_b64) and a fixed-order tree, so results are
+// bitwise reproducible run to run.  HBM-bound: no MFMA (nothing here is a contraction).
+//
+// Reference formulas: SURVEY.md appendix A / F; AdiabaticHEating thermodynamics.py:95-121.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/lec_hip.h"
+#include "lec_internal.h"
+
+namespace {
+
+constexpr double kCp = LEC_CP_D;
+
+// ---------------------------------------------------------------------------------------------
+// vector loads: VEC elements of TIN -> double[VEC]
+// ---------------------------------------------------------------------------------------------
+template <typename TIN, int VEC>
+struct VecLoad;
+
+template <>
+struct VecLoad<double, 2> {
+    static __device__ __forceinline__ void load(const double* p, double (&o)[2]) {
+        const double2 v = *reinterpret_cast<const double2*>(p);
+        o[0] = v.x; o[1] = v.y;
+    }
+};
+template <>
+struct VecLoad<double, 1> {
+    static __device__ __forceinline__ void load(const double* p, double (&o)[1]) { o[0] = *p; }
+};
+template <>
+struct VecLoad<float, 4> {
+    static __device__ __forceinline__ void load(const float* p, double (&o)[4]) {
+        const float4 v = *reinterpret_cast<const float4*>(p);
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    }
+};
+template <>
+struct VecLoad<float, 1> {
+    static __device__ __forceinline__ void load(const float* p, double (&o)[1]) { o[0] = (double)*p; }
+};
+
+// elements e0 .. e0+VEC-1 of a box row of nxb points (elements outside the box read as 0)
+template <typename TIN, int VEC>
+__device__ __forceinline__ void load_row_vec(const TIN* __restrict__ row, int e0, int nxb, double (&o)[VEC]) {
+    if (e0 >= 0 && e0 + VEC <= nxb) {
+        VecLoad<TIN, VEC>::load(row + e0, o);
+    } else {
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+            const int e = e0 + q;
+            o[q] = (e >= 0 && e < nxb) ? (double)row[e] : 0.0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// block-wide sums of N per-thread values through an LDS transpose.
+// nthr in {64,128,256}; R = nthr/32 lanes cooperate on one statistic, each adds 32 partials in a
+// fixed order, then an R-lane butterfly.  On return the lanes with (tid % R) == 0 and tid / R < N
+// hold the total of statistic tid / R.  `red` needs N * kRedStride doubles.
+// ---------------------------------------------------------------------------------------------
+constexpr int kRedStride = 264;  // 256 + 8: the 8 statistics of a wave's lanes land on disjoint LDS banks
+
+template <int N>
+__device__ __forceinline__ double block_sums(const double (&v)[N], double* red, int tid, int nthr) {
+#pragma unroll
+    for (int s = 0; s < N; ++s) red[s * kRedStride + tid] = v[s];
+    __syncthreads();
+    const int rshift = (nthr == 256) ? 3 : (nthr == 128 ? 2 : 1);
+    const int R = 1 << rshift;
+    const int s = tid >> rshift, part = tid & (R - 1);
+    double acc = 0.0;
+    if (s < N) {
+        const double* src = red + s * kRedStride + part;
+#pragma unroll 8
+        for (int m = 0; m < 32; ++m) acc += src[m << rshift];
+    }
+    for (int o = R >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    return acc;
+}
+
+struct RowParams {
+    const void* T; const void* U; const void* V; const void* W; const void* P; const void* DT;
+    int nt, nl, ny, nx;
+    int t_begin, t_count;
+    int n_box, nxb_max, nyb_max;
+    const int* box;
+    const double* boxtab;
+    const double* wlon;
+    const double* glon;
+    const double* lattab;
+    const double* levtab;
+    const double* tcoef;
+    double* rows;
+};
+
+// ---------------------------------------------------------------------------------------------
+// the row kernel
+//   TIN      storage type of the cubes
+//   VEC      elements per 16-byte load (1 = unaligned fallback)
+//   ITERS    vectors per lane
+//   UNIFORM  uniformly spaced longitudes (weights / d-dlon from two scalars instead of tables)
+//   WITH_Q   compute the diabatic-heating residual statistics (needs T at t+-1, k+-1, j+-1, i+-1)
+// ---------------------------------------------------------------------------------------------
+template <typename TIN, int VEC, int ITERS, bool UNIFORM, bool WITH_Q>
+__global__ void __launch_bounds__(256) lec_rowstats_kernel(const RowParams p) {
+    __shared__ double red[16 * kRedStride];
+    __shared__ double bc[8];
+
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    int r = blockIdx.x;
+    const int jb = r % p.nyb_max; r /= p.nyb_max;
+    const int k = r % p.nl;
+    const int tl = r / p.nl;
+    const int bi = (p.n_box == 1) ? 0 : tl;
+    const int iw = p.box[4 * bi + 0], ie = p.box[4 * bi + 1], js = p.box[4 * bi + 2], jn = p.box[4 * bi + 3];
+    const int nxb = ie - iw + 1, nyb = jn - js + 1;
+    double* __restrict__ out = p.rows + ((size_t)(tl * p.nl + k) * p.nyb_max + jb) * LEC_NSTAT;
+    if (jb >= nyb) {  // padding rows of a box smaller than nyb_max
+        if (tid < LEC_NSTAT) out[tid] = 0.0;
+        return;
+    }
+    const int j = js + jb, t = p.t_begin + tl;
+    const size_t plane = (size_t)p.ny * p.nx;
+    const size_t cube = plane * p.nl;
+    const size_t rowoff = (size_t)t * cube + (size_t)k * plane + (size_t)j * p.nx + iw;
+    const int shift = (VEC > 1) ? (int)(rowoff % VEC) : 0;
+
+    const TIN* __restrict__ rT = (const TIN*)p.T + rowoff;
+    const TIN* __restrict__ rU = (const TIN*)p.U + rowoff;
+    const TIN* __restrict__ rV = (const TIN*)p.V + rowoff;
+    const TIN* __restrict__ rW = (const TIN*)p.W + rowoff;
+    const TIN* __restrict__ rP = p.P ? (const TIN*)p.P + rowoff : nullptr;
+
+    const double inv_xlen = p.boxtab[4 * bi + 0];
+    const double h_rad = p.boxtab[4 * bi + 1];
+    const double inv_hdeg = p.boxtab[4 * bi + 2];
+    const double* __restrict__ wl = UNIFORM ? nullptr : p.wlon + (size_t)bi * p.nxb_max;
+    const double* __restrict__ gl = UNIFORM ? nullptr : p.glon + (size_t)bi * p.nxb_max * 3;
+
+    // Q neighbours (clamped to an existing row; the matching coefficient is 0 there)
+    const TIN *rTjm = rT, *rTjp = rT, *rTkm = rT, *rTkp = rT, *rTtm = rT, *rTtp = rT, *rDT = nullptr;
+    double ga = 0, gb = 0, gc = 0, inv_dx = 0, al = 0, be = 0, gm = 0, ta = 0, tb = 0, tc = 0;
+    if (WITH_Q) {
+        if (jb > 0) rTjm = rT - p.nx;
+        if (jb < nyb - 1) rTjp = rT + p.nx;
+        if (k > 0) rTkm = rT - plane;
+        if (k < p.nl - 1) rTkp = rT + plane;
+        const double* lt = p.lattab + ((size_t)bi * p.nyb_max + jb) * 4;
+        ga = lt[0]; gb = lt[1]; gc = lt[2]; inv_dx = lt[3];
+        const double* lv = p.levtab + (size_t)k * 3;
+        al = lv[0]; be = lv[1]; gm = lv[2];
+        if (p.DT) {
+            rDT = (const TIN*)p.DT + rowoff;
+        } else {
+            if (t > 0) rTtm = rT - cube;
+            if (t < p.nt - 1) rTtp = rT + cube;
+            const double* tcf = p.tcoef + (size_t)t * 3;
+            ta = tcf[0]; tb = tcf[1]; tc = tcf[2];
+        }
+    }
+
+    double fT[ITERS][VEC], fU[ITERS][VEC], fV[ITERS][VEC], fW[ITERS][VEC], fP[ITERS][VEC], fQ[ITERS][VEC];
+    double wg[ITERS][VEC];
+    double a1[6] = {0, 0, 0, 0, 0, 0};
+
+    // ---------------- sweep 1: loads, Q, weighted sums ----------------
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int e0 = (it * nthr + tid) * VEC - shift;
+        if (it * nthr * VEC - shift < nxb) {  // wave-uniform: this iteration touches the row at all
+            load_row_vec<TIN, VEC>(rT, e0, nxb, fT[it]);
+            load_row_vec<TIN, VEC>(rU, e0, nxb, fU[it]);
+            load_row_vec<TIN, VEC>(rV, e0, nxb, fV[it]);
+            load_row_vec<TIN, VEC>(rW, e0, nxb, fW[it]);
+            if (rP) {
+                load_row_vec<TIN, VEC>(rP, e0, nxb, fP[it]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) fP[it][q] = 0.0;
+            }
+            double tjm[VEC], tjp[VEC], tkm[VEC], tkp[VEC], dtv[VEC];
+            double tl_edge = 0.0, tr_edge = 0.0;
+            if (WITH_Q) {
+                load_row_vec<TIN, VEC>(rTjm, e0, nxb, tjm);
+                load_row_vec<TIN, VEC>(rTjp, e0, nxb, tjp);
+                load_row_vec<TIN, VEC>(rTkm, e0, nxb, tkm);
+                load_row_vec<TIN, VEC>(rTkp, e0, nxb, tkp);
+                if (rDT) {
+                    load_row_vec<TIN, VEC>(rDT, e0, nxb, dtv);
+                } else {
+                    double tm[VEC], tp[VEC];
+                    load_row_vec<TIN, VEC>(rTtm, e0, nxb, tm);
+                    load_row_vec<TIN, VEC>(rTtp, e0, nxb, tp);
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) dtv[q] = ta * tm[q] + tb * fT[it][q] + tc * tp[q];
+                }
+                const int le = min(max(e0 - 1, 0), nxb - 1);
+                const int re = min(max(e0 + VEC, 0), nxb - 1);
+                tl_edge = (double)rT[le];
+                tr_edge = (double)rT[re];
+            }
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) {
+                const int e = e0 + q;
+                const bool inside = (e >= 0) && (e < nxb);
+                const bool first = (e == 0), last = (e == nxb - 1);
+                double w;
+                if (UNIFORM) {
+                    w = inside ? ((first || last) ? 0.5 * h_rad : h_rad) : 0.0;
+                } else {
+                    w = inside ? wl[e] : 0.0;
+                }
+                wg[it][q] = w;
+                const double T0 = fT[it][q];
+                double Q = 0.0;
+                if (WITH_Q) {
+                    const double Tl = (q == 0) ? tl_edge : fT[it][q > 0 ? q - 1 : 0];
+                    const double Tr = (q == VEC - 1) ? tr_edge : fT[it][q < VEC - 1 ? q + 1 : q];
+                    double dTl;
+                    if (UNIFORM) {
+                        dTl = first ? (Tr - T0) * inv_hdeg : (last ? (T0 - Tl) * inv_hdeg : (Tr - Tl) * (0.5 * inv_hdeg));
+                    } else {
+                        const int ec = inside ? e : 0;
+                        dTl = gl[3 * ec + 0] * Tl + gl[3 * ec + 1] * T0 + gl[3 * ec + 2] * Tr;
+                    }
+                    const double dTphi = ga * tjm[q] + gb * T0 + gc * tjp[q];
+                    const double S = al * tkm[q] + be * T0 + gm * tkp[q];
+                    Q = kCp * (dtv[q] + fU[it][q] * dTl * inv_dx + fV[it][q] * dTphi - fW[it][q] * S);
+                    Q = inside ? Q : 0.0;
+                }
+                fQ[it][q] = Q;
+                a1[0] += w * T0;
+                a1[1] += w * fU[it][q];
+                a1[2] += w * fV[it][q];
+                a1[3] += w * fW[it][q];
+                a1[4] += w * fP[it][q];
+                a1[5] += w * Q;
+                // west / east box columns (boundary_terms.py:138-140 etc.)
+                if (first) { out[LEC_S_TW] = T0; out[LEC_S_UW] = fU[it][q]; out[LEC_S_VW] = fV[it][q]; }
+                if (last)  { out[LEC_S_TE] = T0; out[LEC_S_UE] = fU[it][q]; out[LEC_S_VE] = fV[it][q]; }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) {
+                fT[it][q] = fU[it][q] = fV[it][q] = fW[it][q] = fP[it][q] = fQ[it][q] = 0.0;
+                wg[it][q] = 0.0;
+            }
+        }
+    }
+
+    {
+        const double tot = block_sums<6>(a1, red, tid, nthr);
+        const int rshift = (nthr == 256) ? 3 : (nthr == 128 ? 2 : 1);
+        if ((tid & ((1 << rshift) - 1)) == 0 && (tid >> rshift) < 6) {
+            const double m = tot * inv_xlen;
+            bc[tid >> rshift] = m;
+            out[LEC_S_MT + (tid >> rshift)] = m;
+        }
+        __syncthreads();
+    }
+    const double mT = bc[0], mU = bc[1], mV = bc[2], mW = bc[3], mP = bc[4], mQ = bc[5];
+
+    // ---------------- sweep 2: eddy covariances and mixed moments about the means ----------------
+    double a2[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) a2[s] = 0.0;
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+            const double w = wg[it][q];
+            const double u = fU[it][q], v = fV[it][q], om = fW[it][q];
+            const double Te = fT[it][q] - mT, ue = u - mU, ve = v - mV, we = om - mW;
+            const double Pe = fP[it][q] - mP, Qe = fQ[it][q] - mQ;
+            const double wTe = w * Te;
+            const double TT = Te * Te;
+            const double E = ue * ue + ve * ve;            // u'^2 + v'^2           (boundary_terms.py:287)
+            const double K = u * u + v * v - E;            // u^2+v^2-u'^2-v'^2     (boundary_terms.py:237)
+            a2[0] += wTe * Te;           // [T'T']
+            a2[1] += w * ue * ue;        // [u'u']
+            a2[2] += w * ve * ve;        // [v'v']
+            a2[3] += wTe * ve;           // [v'T']
+            a2[4] += wTe * we;           // [w'T']
+            a2[5] += w * ue * ve;        // [u'v']
+            a2[6] += w * we * ue;        // [w'u']
+            a2[7] += w * we * ve;        // [w'v']
+            a2[8] += w * we * Pe;        // [w'Phi']
+            a2[9] += wTe * Qe;           // [Q'T']
+            a2[10] += w * v * TT;        // [v T'T']
+            a2[11] += w * om * TT;       // [w T'T']
+            a2[12] += w * K * v;         // [K v]
+            a2[13] += w * K * om;        // [K w]
+            a2[14] += w * E * v;         // [E v]
+            a2[15] += w * E * om;        // [E w]
+        }
+    }
+    {
+        const double tot = block_sums<16>(a2, red, tid, nthr);
+        const int rshift = (nthr == 256) ? 3 : (nthr == 128 ? 2 : 1);
+        if ((tid & ((1 << rshift) - 1)) == 0 && (tid >> rshift) < 16) out[LEC_S_TT + (tid >> rshift)] = tot * inv_xlen;
+    }
+    if (tid < 4) out[LEC_S_SPARE + tid] = 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side dispatch
+// ---------------------------------------------------------------------------------------------
+template <typename TIN, int VEC, int ITERS>
+void launch_cfg(const RowParams& p, bool uniform, bool with_q, int nthr, int nblocks, hipStream_t st) {
+    dim3 grid(nblocks), block(nthr);
+    if (uniform) {
+        if (with_q) hipLaunchKernelGGL((lec_rowstats_kernel<TIN, VEC, ITERS, true, true>), grid, block, 0, st, p);
+        else        hipLaunchKernelGGL((lec_rowstats_kernel<TIN, VEC, ITERS, true, false>), grid, block, 0, st, p);
+    } else {
+        if (with_q) hipLaunchKernelGGL((lec_rowstats_kernel<TIN, VEC, ITERS, false, true>), grid, block, 0, st, p);
+        else        hipLaunchKernelGGL((lec_rowstats_kernel<TIN, VEC, ITERS, false, false>), grid, block, 0, st, p);
+    }
+}
+
+template <typename TIN, int VEC>
+int launch_vec(const RowParams& p, bool uniform, bool with_q, int nblocks, hipStream_t st) {
+    // vectors needed to cover the longest row, plus one for the alignment shift
+    const int nvec = (p.nxb_max + VEC - 1) / VEC + (VEC > 1 ? 1 : 0);
+    int nthr = 256;
+    if (nvec <= 64) nthr = 64;
+    else if (nvec <= 128) nthr = 128;
+    const int iters = (nvec + nthr - 1) / nthr;
+    if (iters <= 1) launch_cfg<TIN, VEC, 1>(p, uniform, with_q, nthr, nblocks, st);
+    else if (iters <= 3) launch_cfg<TIN, VEC, 3>(p, uniform, with_q, nthr, nblocks, st);
+    else if (iters <= LEC_MAX_ITERS) launch_cfg<TIN, VEC, LEC_MAX_ITERS>(p, uniform, with_q, nthr, nblocks, st);
+    else return LEC_ERR_UNSUPPORTED;
+    return LEC_OK;
+}
+
+}  // namespace
+
+extern "C" int lec_max_row(int dtype, int aligned) {
+    const int vec = aligned ? (dtype == LEC_F32 ? 4 : 2) : 1;
+    return (256 * LEC_MAX_ITERS - (vec > 1 ? 1 : 0)) * vec;
+}
+
+extern "C" int lec_rowstats(const lec_rowstats_args* a) {
+    if (!a) return lec_set_error(LEC_ERR_ARG, "lec_rowstats: null args");
+    if (!a->tair_d || !a->u_d || !a->v_d || !a->omega_d || !a->rows_d || !a->box_d || !a->boxtab_d)
+        return lec_set_error(LEC_ERR_ARG, "lec_rowstats: null field / output / box pointer");
+    if (a->dtype != LEC_F64 && a->dtype != LEC_F32) return lec_set_error(LEC_ERR_ARG, "lec_rowstats: dtype must be LEC_F64 or LEC_F32");
+    if (a->nt < 1 || a->nl < 2 || a->ny < 2 || a->nx < 2) return lec_set_error(LEC_ERR_ARG, "lec_rowstats: cube needs nt>=1, nl>=2, ny>=2, nx>=2");
+    if (a->t_begin < 0 || a->t_count < 1 || a->t_begin + a->t_count > a->nt) return lec_set_error(LEC_ERR_ARG, "lec_rowstats: [t_begin, t_begin+t_count) outside the cube");
+    if (a->n_box != 1 && a->n_box != a->t_count) return lec_set_error(LEC_ERR_ARG, "lec_rowstats: n_box must be 1 or t_count");
+    if (a->nxb_max < 2 || a->nyb_max < 2 || a->nxb_max > a->nx || a->nyb_max > a->ny) return lec_set_error(LEC_ERR_ARG, "lec_rowstats: box extents must be 2..nx by 2..ny points");
+    if (!a->lon_uniform && (!a->wlon_d || !a->glon_d)) return lec_set_error(LEC_ERR_ARG, "lec_rowstats: non-uniform longitudes need wlon_d and glon_d");
+    if (a->with_q) {
+        if (!a->lattab_d || !a->levtab_d) return lec_set_error(LEC_ERR_ARG, "lec_rowstats: with_q needs lattab_d and levtab_d");
+        if (!a->dTdt_d && !a->tcoef_d) return lec_set_error(LEC_ERR_ARG, "lec_rowstats: with_q needs dTdt_d or tcoef_d");
+        if (!a->dTdt_d && a->nt < 2) return lec_set_error(LEC_ERR_ARG, "lec_rowstats: dT/dt from the cube needs nt >= 2");
+    }
+    const size_t esz = a->dtype == LEC_F32 ? 4 : 8;
+    const int vecw = (int)(16 / esz);
+    const void* cubes[6] = {a->tair_d, a->u_d, a->v_d, a->omega_d, a->geopt_d, a->dTdt_d};
+    bool aligned = (a->nx % vecw) == 0;
+    for (const void* c : cubes) {
+        if (!c) continue;
+        if ((uintptr_t)c % esz) return lec_set_error(LEC_ERR_ARG, "lec_rowstats: cube pointer not aligned to its element size");
+        if ((uintptr_t)c % 16) aligned = false;
+    }
+    if (a->nxb_max > lec_max_row(a->dtype, aligned)) return lec_set_error(LEC_ERR_UNSUPPORTED, "lec_rowstats: box row longer than lec_max_row()");
+    const long long nrows = (long long)a->t_count * a->nl * a->nyb_max;
+    if (nrows > 0x7fffffffLL) return lec_set_error(LEC_ERR_UNSUPPORTED, "lec_rowstats: more than 2^31-1 rows in one call");
+
+    RowParams p;
+    p.T = a->tair_d; p.U = a->u_d; p.V = a->v_d; p.W = a->omega_d; p.P = a->geopt_d; p.DT = a->dTdt_d;
+    p.nt = a->nt; p.nl = a->nl; p.ny = a->ny; p.nx = a->nx;
+    p.t_begin = a->t_begin; p.t_count = a->t_count;
+    p.n_box = a->n_box; p.nxb_max = a->nxb_max; p.nyb_max = a->nyb_max;
+    p.box = a->box_d; p.boxtab = a->boxtab_d; p.wlon = a->wlon_d; p.glon = a->glon_d;
+    p.lattab = a->lattab_d; p.levtab = a->levtab_d; p.tcoef = a->tcoef_d;
+    p.rows = a->rows_d;
+    hipStream_t st = (hipStream_t)a->stream;
+    const bool uni = a->lon_uniform != 0, wq = a->with_q != 0;
+    int rc;
+    if (a->dtype == LEC_F64) rc = aligned ? launch_vec<double, 2>(p, uni, wq, (int)nrows, st) : launch_vec<double, 1>(p, uni, wq, (int)nrows, st);
+    else                     rc = aligned ? launch_vec<float, 4>(p, uni, wq, (int)nrows, st) : launch_vec<float, 1>(p, uni, wq, (int)nrows, st);
+    if (rc != LEC_OK) return lec_set_error(rc, "lec_rowstats: row too long for the compiled kernels");
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return lec_set_error(LEC_ERR_LAUNCH, hipGetErrorString(e));
+    return LEC_OK;
+}

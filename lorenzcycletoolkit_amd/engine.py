@@ -1,0 +1,164 @@
+"""LECEngine: device-resident Lorenz-Energy-Cycle computation through the C-ABI HIP library.
+
+Holds the (time, level, lat, lon) fields as PyTorch-ROCm tensors, builds the small coefficient
+tables on the host, and issues ``lec_rowstats`` + ``lec_reduce`` on the current HIP stream.
+It is the replacement for ``BoxData`` + the four analysis classes of the reference
+(box_data.py:58-105, energy_contents.py, conversion_terms.py, boundary_terms.py,
+generation_and_dissipation_terms.py).  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib, tables
+from .constants import LEVEL_TERMS, SCALAR_TERMS
+
+
+@dataclass
+class LECResult:
+    """Per-time-step outputs (device tensors) of one engine call."""
+    scalars: torch.Tensor      # [t_count, 16] fp64, columns = constants.SCALAR_TERMS
+    levels: torch.Tensor       # [t_count, 21, nl] fp64, tables = constants.LEVEL_TERMS
+    nanflag: torch.Tensor      # [t_count] int32: NaN level values repaired/dropped by _handle_nans
+    rows: Optional[torch.Tensor] = None   # [t_count, nl, nyb_max, 32] row records (kept on request)
+
+    def scalars_dict(self) -> Dict[str, np.ndarray]:
+        s = self.scalars.cpu().numpy()
+        return {name: s[:, i].copy() for i, name in enumerate(SCALAR_TERMS)}
+
+    def levels_dict(self) -> Dict[str, np.ndarray]:
+        lv = self.levels.cpu().numpy()
+        return {name: lv[:, i, :].copy() for i, name in enumerate(LEVEL_TERMS)}
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class LECEngine:
+    """One engine per (grid, device).
+
+    Parameters
+    ----------
+    lat_deg, lon_deg : 1-D arrays, degrees, ascending (lat S->N, lon W->E in (-180, 180])
+    level_pa         : 1-D array, Pa, ascending
+    device           : torch device of the field tensors (``cuda:N`` on ROCm)
+    """
+
+    def __init__(self, lat_deg, lon_deg, level_pa, device="cuda"):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.LecLibraryError("LECEngine needs a GPU device: the HIP path is the only path")
+        self.lat = np.asarray(lat_deg, dtype=np.float64)
+        self.lon = np.asarray(lon_deg, dtype=np.float64)
+        self.level = np.asarray(level_pa, dtype=np.float64)
+        if np.any(np.diff(self.lat) <= 0) or np.any(np.diff(self.lon) <= 0):
+            raise ValueError("lat and lon must be strictly ascending (preprocessing.py:358-362 sorts them)")
+        levtab, levtab2 = tables.level_tables(self.level)
+        self._levtab = self._up(levtab)
+        self._levtab2 = self._up(levtab2)
+        self._box_cache = {}
+
+    # -- helpers ---------------------------------------------------------------------------
+    def _up(self, a: np.ndarray, dtype=torch.float64) -> torch.Tensor:
+        return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(self.device)
+
+    def box_from_limits(self, west, east, south, north):
+        """Nearest-grid-point inclusive box, as BoxData._set_domain_limits (box_data.py:115-131)."""
+        return tables.box_indices(self.lat, self.lon, west, east, south, north)
+
+    def _box_tables(self, boxes):
+        key = tuple(int(v) for b in boxes for v in b)
+        hit = self._box_cache.get(key)
+        if hit is not None:
+            return hit
+        bt = tables.build_box_tables(self.lat, self.lon, boxes)
+        dev = {
+            "box": self._up(bt.box, torch.int32), "boxtab": self._up(bt.boxtab), "wlon": self._up(bt.wlon),
+            "glon": self._up(bt.glon), "lattab": self._up(bt.lattab), "boxtab2": self._up(bt.boxtab2),
+            "lattab2": self._up(bt.lattab2),
+        }
+        if len(self._box_cache) > 8:
+            self._box_cache.clear()
+        self._box_cache[key] = (bt, dev)
+        return bt, dev
+
+    # -- the hot path ----------------------------------------------------------------------
+    def compute(self, tair: torch.Tensor, u: torch.Tensor, v: torch.Tensor, omega: torch.Tensor,
+                geopt: Optional[torch.Tensor], boxes: Sequence[Sequence[int]], *,
+                time_s=None, dTdt: Optional[torch.Tensor] = None, t_begin: int = 0,
+                t_count: Optional[int] = None, with_q: bool = True, phi_scale: float = 1.0,
+                keep_rows: bool = False) -> LECResult:
+        """All LEC terms for time steps [t_begin, t_begin + t_count) of the cubes.
+
+        ``boxes``: one (iw, ie, js, jn) quadruple (fixed framework) or one per processed time step
+        (moving framework).  ``time_s`` (seconds, length nt) gives dT/dt by np.gradient over the
+        cube's time axis unless a ``dTdt`` cube is supplied (moving framework).
+        """
+        if tair.dim() != 4:
+            raise ValueError("fields must be [time, level, lat, lon]")
+        nt, nl, ny, nx = tair.shape
+        if (nl, ny, nx) != (self.level.size, self.lat.size, self.lon.size):
+            raise ValueError(f"field shape {tuple(tair.shape)} does not match the engine grid "
+                             f"({self.level.size} levels, {self.lat.size} lats, {self.lon.size} lons)")
+        if tair.dtype not in (torch.float64, torch.float32):
+            raise ValueError("fields must be float64 or float32")
+        cubes = [tair, u, v, omega] + ([geopt] if geopt is not None else []) + ([dTdt] if dTdt is not None else [])
+        for c in cubes:
+            if c.shape != tair.shape or c.dtype != tair.dtype or c.device != tair.device or not c.is_contiguous():
+                raise ValueError("all field cubes must share shape, dtype, device and be contiguous")
+        if tair.device.type != "cuda":
+            raise _lib.LecLibraryError("fields must live on the GPU: there is no CPU path")
+        if t_count is None:
+            t_count = nt - t_begin
+        boxes = [tuple(int(x) for x in b) for b in (boxes if isinstance(boxes[0], (tuple, list, np.ndarray)) else [boxes])]
+        if len(boxes) not in (1, t_count):
+            raise ValueError("boxes: give one box, or one per processed time step")
+        bt, dev = self._box_tables(boxes)
+
+        tcoef = None
+        if with_q and dTdt is None:
+            if time_s is None:
+                raise ValueError("with_q needs time_s (seconds) or a dTdt cube")
+            time_s = np.asarray(time_s, dtype=np.float64)
+            if time_s.size != nt:
+                raise ValueError("time_s must have one entry per time step of the cube")
+            if nt < 2:
+                raise ValueError("dT/dt by finite differences needs at least 2 time steps")
+            tcoef = self._up(tables.time_coefs(time_s))
+
+        f64 = dict(dtype=torch.float64, device=tair.device)
+        rows = torch.empty((t_count, nl, bt.nyb_max, _lib.LEC_NSTAT), **f64)
+        am = torch.empty((t_count, nl, 8), **f64)
+        levraw = torch.empty((t_count, nl, _lib.LEC_NLEVRAW), **f64)
+        scalars = torch.empty((t_count, _lib.LEC_NSCALAR), **f64)
+        levels = torch.empty((t_count, _lib.LEC_NLEVTAB, nl), **f64)
+        nanflag = torch.empty((t_count,), dtype=torch.int32, device=tair.device)
+        stream = C.c_void_p(torch.cuda.current_stream(tair.device).cuda_stream)
+
+        ra = _lib.RowstatsArgs(
+            tair_d=_ptr(tair), u_d=_ptr(u), v_d=_ptr(v), omega_d=_ptr(omega), geopt_d=_ptr(geopt), dTdt_d=_ptr(dTdt),
+            dtype=_lib.LEC_F64 if tair.dtype == torch.float64 else _lib.LEC_F32, with_q=int(bool(with_q)),
+            nt=nt, nl=nl, ny=ny, nx=nx, t_begin=t_begin, t_count=t_count,
+            n_box=len(boxes), nxb_max=bt.nxb_max, nyb_max=bt.nyb_max, lon_uniform=int(bt.lon_uniform),
+            box_d=_ptr(dev["box"]), boxtab_d=_ptr(dev["boxtab"]), wlon_d=_ptr(dev["wlon"]), glon_d=_ptr(dev["glon"]),
+            lattab_d=_ptr(dev["lattab"]), levtab_d=_ptr(self._levtab), tcoef_d=_ptr(tcoef),
+            rows_d=_ptr(rows), stream=stream)
+        with torch.cuda.device(tair.device):
+            _lib.check(self.lib.lec_rowstats(C.byref(ra)), "lec_rowstats")
+            rd = _lib.ReduceArgs(
+                rows_d=_ptr(rows), t_count=t_count, nl=nl, n_box=len(boxes), nyb_max=bt.nyb_max,
+                box_d=_ptr(dev["box"]), boxtab2_d=_ptr(dev["boxtab2"]), lattab2_d=_ptr(dev["lattab2"]),
+                levtab2_d=_ptr(self._levtab2), phi_scale=float(phi_scale),
+                am_d=_ptr(am), levraw_d=_ptr(levraw), scalars_d=_ptr(scalars), levels_d=_ptr(levels),
+                nanflag_d=_ptr(nanflag), stream=stream)
+            _lib.check(self.lib.lec_reduce(C.byref(rd)), "lec_reduce")
+        # tcoef / workspaces are released to torch's caching allocator only after the stream work is
+        # enqueued; the allocator is stream-ordered, so reuse on this stream is safe.
+        return LECResult(scalars=scalars, levels=levels, nanflag=nanflag, rows=rows if keep_rows else None)

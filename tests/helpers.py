@@ -1,0 +1,63 @@
+"""Shared helpers of the parity tests: synthetic domains and engine-vs-oracle comparison."""
+from __future__ import annotations
+
+import numpy as np
+
+from oracle import lec_oracle as o
+
+SCALARS = ["Az", "Ae", "Kz", "Ke", "Cz", "Ca", "Ck", "Ce", "BAz", "BAe", "BKz", "BKe", "BΦZ", "BΦE", "Gz", "Ge"]
+
+
+def synthetic_domain(nt, nl, ny, nx, seed=0, dtype=np.float64, lat0=-60.0, lat1=-10.0, lon0=-80.0, lon1=-20.0,
+                     nonuniform_lon=False, dt_s=21600.0, pmin=10000.0):
+    """Smooth + noisy fields in the spirit of SURVEY.md section 8(d), on a regional grid."""
+    rng = np.random.default_rng(seed)
+    lat = np.linspace(lat0, lat1, ny)
+    lon = np.linspace(lon0, lon1, nx)
+    if nonuniform_lon:
+        lon = lon + 0.3 * (lon1 - lon0) / nx * np.sin(np.linspace(0, 7, nx))
+        lon = np.sort(lon)
+    level = np.linspace(pmin, 100000.0, nl)
+    time_s = np.arange(nt) * dt_s
+    phi, lam = np.deg2rad(lat)[None, None, :, None], np.deg2rad(lon)[None, None, None, :]
+    p = level[None, :, None, None]
+    tt = (np.arange(nt) / max(nt, 1))[:, None, None, None]
+    shp = (nt, nl, ny, nx)
+    T = 288.0 * (p / 1e5) ** 0.19 + 10.0 * np.cos(2 * phi) * (p / 1e5) + 2.0 * np.sin(3 * lam + tt) + rng.standard_normal(shp)
+    u = 25.0 * np.cos(phi) * (1 - p / 1.2e5) + 5.0 * rng.standard_normal(shp)
+    v = 3.0 * np.sin(2 * lam) * np.cos(phi) + 3.0 * rng.standard_normal(shp)
+    w = 0.05 * np.sin(3 * lam) * np.cos(phi) + 0.1 * rng.standard_normal(shp)
+    ph = o.G * 7000.0 * np.log(1e5 / p) + 100.0 * rng.standard_normal(shp)
+    f = [np.ascontiguousarray(a.astype(dtype)) for a in (T, u, v, w, ph)]
+    return o.Domain(f[0], f[1], f[2], f[3], f[4], lat.astype(np.float64), lon.astype(np.float64), level, time_s)
+
+
+def as_f64(dom: o.Domain) -> o.Domain:
+    """The same values in float64 (what the engine computes from float32 storage)."""
+    c = lambda a: np.ascontiguousarray(a.astype(np.float64))
+    return o.Domain(c(dom.tair), c(dom.u), c(dom.v), c(dom.omega), c(dom.geopt), c(dom.lat), c(dom.lon),
+                    dom.level, dom.time_s)
+
+
+def scale_err(a, r):
+    a = np.asarray(a, dtype=np.float64)
+    r = np.asarray(r, dtype=np.float64)
+    den = np.max(np.abs(r))
+    return float(np.max(np.abs(a - r)) / den) if den > 0 else float(np.max(np.abs(a - r)))
+
+
+def compare(engine_scalars, engine_levels, ref_scalars, ref_levels, tol, what=""):
+    """Every integrated term and level table within `tol` of the oracle, relative to the term's scale."""
+    worst = {}
+    for name in SCALARS:
+        if name in ref_scalars:
+            worst[name] = scale_err(engine_scalars[name], ref_scalars[name])
+    for name, ref in ref_levels.items():
+        ref = np.asarray(ref, dtype=np.float64)
+        got = engine_levels[name]
+        if ref.ndim == 1:                         # Cz_1 / Ce_1: level-only
+            ref = np.broadcast_to(ref, got.shape)
+        worst["lv:" + name] = scale_err(got, ref)
+    bad = {k: v for k, v in worst.items() if not (v <= tol)}
+    assert not bad, f"{what}: terms beyond tol={tol:g}: {bad}"
+    return worst

@@ -1,0 +1,248 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same inputs.
+
+Tolerances: fp64 arithmetic on both sides; the engine factors every term through row statistics
+ while the oracle evaluates the reference's un-factored 4-D formulas, so they
+agree to rounding.  TOL = 1e-9 of each term's scale (north_star asks for 1e-6 relative).
+"""
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from oracle import lec_oracle as o
+from tests.helpers import SCALARS, as_f64, compare, scale_err, synthetic_domain
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-9
+
+
+def _engine(dom):
+    from lorenzcycletoolkit_amd.engine import LECEngine
+    return LECEngine(dom.lat, dom.lon, dom.level, device="cuda:0")
+
+
+def _dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).to("cuda:0")
+
+
+def run_fixed(dom, limits, **kw):
+    eng = _engine(dom)
+    box = eng.box_from_limits(*limits)
+    res = eng.compute(_dev(dom.tair), _dev(dom.u), _dev(dom.v), _dev(dom.omega), _dev(dom.geopt), [box],
+                      time_s=dom.time_s, **kw)
+    torch.cuda.synchronize()
+    return res
+
+
+def run_moving(dom, limits_per_t):
+    eng = _engine(dom)
+    boxes = [eng.box_from_limits(*lim) for lim in limits_per_t]
+    dTdt = o.moving_dTdt(dom)      # host-side here; the framework computes it on the device
+    res = eng.compute(_dev(dom.tair), _dev(dom.u), _dev(dom.v), _dev(dom.omega), _dev(dom.geopt), boxes,
+                      dTdt=_dev(dTdt.astype(dom.tair.dtype)))
+    torch.cuda.synchronize()
+    return res
+
+
+def check_fixed(dom, limits, tol=TOL, what=""):
+    res = run_fixed(dom, limits)
+    assert int(res.nanflag.sum()) == 0
+    ref_s, ref_l = o.lec_fixed(as_f64(dom), *limits)
+    return compare(res.scalars_dict(), res.levels_dict(), ref_s, ref_l, tol, what)
+
+
+# ---------------------------------------------------------------------------------------------
+# the reference's own samples
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.float64, None])
+def test_catarina_fixed(golden_dir, dtype):
+    """BASELINE config 2 stand-in (testdata_ERA5.nc is absent): Catarina sample, fixed box, fp64 and
+    fp32 storage.  Oracle = fp64 evaluation of the same values."""
+    dom = o.load_ncep_sample(os.path.join(golden_dir, "Catarina_NCEP-R2.nc"), dtype=dtype)
+    limits = (-55, -36, -35, -20)
+    worst = check_fixed(o.crop_domain(dom, *limits), limits, what="catarina")
+    print(worst)
+
+
+def test_catarina_against_committed_csv(golden_dir):
+    """Engine (fp64) vs the reference's committed float32-generated CSV: float32 noise only
+    (tolerance policy (ii) of SURVEY.md appendix D)."""
+    dom = o.load_ncep_sample(os.path.join(golden_dir, "Catarina_NCEP-R2.nc"), dtype=np.float64)
+    limits = (-55, -36, -35, -20)
+    res = run_fixed(o.crop_domain(dom, *limits), limits)
+    ref = pd.read_csv(os.path.join(golden_dir, "Catarina_NCEP-R2_fixed", "Catarina_NCEP-R2_fixed_results.csv"), index_col=0)
+    got = res.scalars_dict()
+    for name in ["Az", "Ae", "Kz", "Ke", "Cz", "Ca", "Ck", "Ce", "BAz", "BAe", "BKz", "BKe", "Gz", "Ge"]:
+        a, r = got[name], ref[name].values
+        assert np.all(np.abs(a - r) <= 2e-4 * np.abs(r) + 1e-4 * np.max(np.abs(r))), name
+
+
+def test_testdata_fixed_box_inside_domain(golden_dir):
+    """Box strictly inside a larger domain with an odd row length (nx = 41): exercises the box offsets
+    and the unaligned (scalar-load) kernel.  Q differentiates T in time over the whole cube."""
+    dom = o.load_ncep_sample(os.path.join(golden_dir, "testdata_NCEP-R2.nc"), dtype=np.float64)
+    limits = (-60, -30, -42.5, -17.5)
+    res = run_fixed(dom, limits)
+    ref_s, ref_l = o.lec_fixed(o.crop_domain(dom, *limits), *limits)
+    compare(res.scalars_dict(), res.levels_dict(), ref_s, ref_l, TOL, "testdata fixed")
+
+
+def test_testdata_moving(golden_dir):
+    """Semi-Lagrangian boxes from the reference's track file, dT/dt supplied as a cube."""
+    dom = o.load_ncep_sample(os.path.join(golden_dir, "testdata_NCEP-R2.nc"), dtype=np.float64)
+    tr = pd.read_csv(os.path.join(golden_dir, "inputs", "track_testdata_NCEP-R2"), sep=";")
+    domt = o.crop_domain_track(dom, tr.Lat.values, tr.Lon.values)
+    limits = [(lo - 7.5, lo + 7.5, la - 7.5, la + 7.5) for la, lo in zip(tr.Lat, tr.Lon)]
+    res = run_moving(domt, limits)
+    ref_s, ref_l = o.lec_moving(domt, limits)
+    compare(res.scalars_dict(), res.levels_dict(), ref_s, ref_l, TOL, "testdata moving")
+
+
+# ---------------------------------------------------------------------------------------------
+# synthetic shapes: every kernel configuration
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("nx,dtype,nonuni", [
+    (48, np.float64, False),     # 1 vector per lane, 64-thread blocks
+    (200, np.float64, False),    # 128-thread blocks
+    (300, np.float64, False),    # 256-thread blocks, 1 vector per lane
+    (1000, np.float64, False),   # 256-thread blocks, 2-3 vectors per lane
+    (1001, np.float64, False),   # odd row length -> scalar-load kernel
+    (2400, np.float64, False),   # up to 8 vectors per lane
+    (300, np.float32, False),    # float4 loads
+    (1000, np.float32, False),
+    (303, np.float32, False),    # float, unaligned
+    (300, np.float64, True),     # non-uniform longitudes: table path
+    (1000, np.float32, True),
+])
+def test_synthetic_fixed(nx, dtype, nonuni):
+    dom = synthetic_domain(4, 5, 12, nx, seed=nx, dtype=dtype, nonuniform_lon=nonuni)
+    limits = (dom.lon[3], dom.lon[-3], dom.lat[1], dom.lat[-2])     # odd box start: misaligned rows
+    check_fixed(dom, limits, what=f"synthetic nx={nx} {np.dtype(dtype).name} nonuni={nonuni}")
+
+
+def test_synthetic_full_domain_box():
+    dom = synthetic_domain(3, 6, 9, 64, seed=5)
+    limits = (dom.lon[0], dom.lon[-1], dom.lat[0], dom.lat[-1])
+    check_fixed(dom, limits, what="full-domain box")
+
+
+def test_synthetic_moving_variable_boxes():
+    """Boxes of different sizes per time step (track with width/length columns)."""
+    dom = synthetic_domain(5, 6, 40, 60, seed=11)
+    cen = [(-35.0 + 2 * t, -50.0 + 3 * t) for t in range(5)]
+    size = [(10, 12), (12, 10), (14, 14), (8, 16), (10, 10)]
+    limits = [(lo - w / 2, lo + w / 2, la - l / 2, la + l / 2) for (la, lo), (w, l) in zip(cen, size)]
+    res = run_moving(dom, limits)
+    ref_s, ref_l = o.lec_moving(dom, limits)
+    compare(res.scalars_dict(), res.levels_dict(), ref_s, ref_l, TOL, "moving variable boxes")
+
+
+def test_time_shard_invariance():
+    """Processing [t0, t1) of a cube gives bit-identical results to processing the whole cube."""
+    dom = synthetic_domain(6, 5, 10, 128, seed=3)
+    limits = (dom.lon[2], dom.lon[-2], dom.lat[1], dom.lat[-2])
+    full = run_fixed(dom, limits)
+    part = run_fixed(dom, limits, t_begin=2, t_count=3)
+    assert torch.equal(full.scalars[2:5], part.scalars)
+    assert torch.equal(full.levels[2:5], part.levels)
+
+
+def test_without_q_and_without_geopotential():
+    dom = synthetic_domain(3, 5, 10, 128, seed=4)
+    limits = (dom.lon[2], dom.lon[-2], dom.lat[1], dom.lat[-2])
+    eng = _engine(dom)
+    box = eng.box_from_limits(*limits)
+    res = eng.compute(_dev(dom.tair), _dev(dom.u), _dev(dom.v), _dev(dom.omega), None, [box], with_q=False)
+    ref_s, ref_l = o.lec_fixed(dom, *limits)
+    got = res.scalars_dict()
+    for name in ["Az", "Ae", "Kz", "Ke", "Cz", "Ca", "Ck", "Ce", "BAz", "BAe", "BKz", "BKe"]:
+        assert scale_err(got[name], ref_s[name]) <= TOL, name
+    assert np.all(got["Gz"] == 0) and np.all(got["Ge"] == 0)
+
+
+def test_geopotential_height_scale(golden_dir):
+    """phi_scale = g turns geopotential height into geopotential (box_data.py:233-241)."""
+    dom = synthetic_domain(3, 5, 10, 64, seed=6)
+    limits = (dom.lon[1], dom.lon[-2], dom.lat[1], dom.lat[-2])
+    eng = _engine(dom)
+    box = eng.box_from_limits(*limits)
+    hgt = dom.geopt / o.G
+    res = eng.compute(_dev(dom.tair), _dev(dom.u), _dev(dom.v), _dev(dom.omega), _dev(hgt), [box],
+                      time_s=dom.time_s, phi_scale=o.G)
+    ref_s, _ = o.lec_fixed(dom, *limits)
+    got = res.scalars_dict()
+    for name in ["BΦZ", "BΦE"]:
+        assert scale_err(got[name], ref_s[name]) <= TOL, name
+
+
+def test_nan_levels_are_repaired_like_handle_nans():
+    """A NaN level at one latitude row propagates to that level's tables; _handle_nans interpolates it."""
+    dom = synthetic_domain(3, 7, 10, 64, seed=8)
+    dom.u[:, 3, 4, 10] = np.nan
+    limits = (dom.lon[1], dom.lon[-2], dom.lat[1], dom.lat[-2])
+    res = run_fixed(dom, limits)
+    assert int(res.nanflag.min()) > 0
+    ref_s, _ = o.lec_fixed(dom, *limits)
+    got = res.scalars_dict()
+    for name in ["Kz", "Ke", "Ck", "BKz", "BKe", "Az", "Ae"]:
+        assert np.isfinite(got[name]).all(), name
+        assert scale_err(got[name], ref_s[name]) <= 1e-8, name
+
+
+# ---------------------------------------------------------------------------------------------
+# argument checking mirrors the reference's error behaviour
+# ---------------------------------------------------------------------------------------------
+def test_errors():
+    from lorenzcycletoolkit_amd.engine import LECEngine
+    dom = synthetic_domain(3, 5, 10, 64, seed=9)
+    eng = LECEngine(dom.lat, dom.lon, dom.level, device="cuda:0")
+    with pytest.raises(ValueError):
+        eng.box_from_limits(dom.lon[5], dom.lon[5], dom.lat[1], dom.lat[4])    # single-column box
+    T = _dev(dom.tair)
+    with pytest.raises(ValueError):
+        eng.compute(T, T, T, T, T, [(0, 10, 0, 5)])                             # with_q but no time axis
+    with pytest.raises(ValueError):
+        eng.compute(T[:, :, :, :32], T, T, T, T, [(0, 10, 0, 5)], time_s=dom.time_s)
+    with pytest.raises(ValueError):
+        eng.compute(T, T, T, T, T, [(0, 70, 0, 5)], time_s=dom.time_s)          # box outside the grid
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json size: a latitude band of the 37 x 721 x 1440 grid against the oracle, and
+# size-independent properties on the whole grid
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_full_size_band_and_properties(dtype):
+    from lorenzcycletoolkit_amd.engine import LECEngine
+    from lorenzcycletoolkit_amd.synthetic import era5_grid, era5_like_levels, synthetic_cube
+    lat, lon = era5_grid()
+    level = era5_like_levels()
+    nt = 3
+    time_s = np.arange(nt) * 3600.0
+    f = synthetic_cube(nt, level, lat, lon, device="cuda:0", dtype=dtype, seed=1234)
+    eng = LECEngine(lat, lon, level, device="cuda:0")
+    # (1) 15-degree band against the oracle
+    box = eng.box_from_limits(-180, 179.75, -40.0, -25.0)
+    res = eng.compute(f["tair"], f["u"], f["v"], f["omega"], f["geopt"], [box], time_s=time_s)
+    iw, ie, js, jn = box
+    crop = lambda a: a[:, :, js:jn + 1, iw:ie + 1].double().cpu().numpy()
+    dom = o.Domain(crop(f["tair"]), crop(f["u"]), crop(f["v"]), crop(f["omega"]), crop(f["geopt"]),
+                   lat[js:jn + 1], lon[iw:ie + 1], level, time_s)
+    ref_s, ref_l = o.lec_fixed(dom, lon[iw], lon[ie], lat[js], lat[jn])
+    compare(res.scalars_dict(), res.levels_dict(), ref_s, ref_l, 1e-8, "full-size band")
+    # (2) whole grid without the polar rows: finite, shard-invariant, and energy scaling:
+    #     doubling u and v multiplies Kz, Ke, BKz, BKe by 4 / 4 / 8 / 8 exactly (powers of two).
+    box = eng.box_from_limits(-180, 179.75, -89.75, 89.75)
+    r1 = eng.compute(f["tair"], f["u"], f["v"], f["omega"], f["geopt"], [box], time_s=time_s)
+    s1 = r1.scalars_dict()
+    assert all(np.isfinite(s1[k]).all() for k in SCALARS)
+    r2 = eng.compute(f["tair"], f["u"], f["v"], f["omega"], f["geopt"], [box], time_s=time_s, t_begin=1, t_count=1)
+    assert torch.equal(r1.scalars[1:2], r2.scalars)
+    r3 = eng.compute(f["tair"], f["u"] * 2, f["v"] * 2, f["omega"], f["geopt"], [box], time_s=time_s)
+    s3 = r3.scalars_dict()
+    assert np.array_equal(s3["Kz"], 4 * s1["Kz"]) and np.array_equal(s3["Ke"], 4 * s1["Ke"])
+    assert np.array_equal(s3["Az"], s1["Az"]) and np.array_equal(s3["Ae"], s1["Ae"])
