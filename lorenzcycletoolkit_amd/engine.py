@@ -94,12 +94,14 @@ class LECEngine:
                 geopt: Optional[torch.Tensor], boxes: Sequence[Sequence[int]], *,
                 time_s=None, dTdt: Optional[torch.Tensor] = None, t_begin: int = 0,
                 t_count: Optional[int] = None, with_q: bool = True, phi_scale: float = 1.0,
-                keep_rows: bool = False) -> LECResult:
+                keep_rows: bool = False, timing: Optional[list] = None) -> LECResult:
         """All LEC terms for time steps [t_begin, t_begin + t_count) of the cubes.
 
         ``boxes``: one (iw, ie, js, jn) quadruple (fixed framework) or one per processed time step
         (moving framework).  ``time_s`` (seconds, length nt) gives dT/dt by np.gradient over the
         cube's time axis unless a ``dTdt`` cube is supplied (moving framework).
+        ``timing``: a list that receives one (start, end) pair of HIP events recorded on the launch
+        stream around the stage-1 kernel (bench.py's roofline figure).
         """
         if tair.dim() != 4:
             raise ValueError("fields must be [time, level, lat, lon]")
@@ -151,7 +153,13 @@ class LECEngine:
             lattab_d=_ptr(dev["lattab"]), levtab_d=_ptr(self._levtab), tcoef_d=_ptr(tcoef),
             rows_d=_ptr(rows), stream=stream)
         with torch.cuda.device(tair.device):
+            if timing is not None:
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
             _lib.check(self.lib.lec_rowstats(C.byref(ra)), "lec_rowstats")
+            if timing is not None:
+                ev1.record()
+                timing.append((ev0, ev1))
             rd = _lib.ReduceArgs(
                 rows_d=_ptr(rows), t_count=t_count, nl=nl, n_box=len(boxes), nyb_max=bt.nyb_max,
                 box_d=_ptr(dev["box"]), boxtab2_d=_ptr(dev["boxtab2"]), lattab2_d=_ptr(dev["lattab2"]),
