@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblec_hip.so")
+# LEC_LIB: alternative build of the same ABI (kernel experiments only)
+LIB_PATH = os.environ.get("LEC_LIB") or os.path.join(_HERE, "liblec_hip.so")
 
 LEC_ABI_VERSION = 1
 LEC_NSTAT = 32

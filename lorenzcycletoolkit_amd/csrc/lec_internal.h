@@ -11,6 +11,10 @@
 
 // vectors per lane of the largest row kernel (rows up to 256 * LEC_MAX_ITERS vectors)
 #define LEC_MAX_ITERS 8
+// minimum waves per SIMD requested from the register allocator for the row kernel
+#ifndef LEC_MINW
+#define LEC_MINW 1
+#endif
 
 // records an error message (thread-local) and returns `code`
 int lec_set_error(int code, const char* msg);
