@@ -1,0 +1,276 @@
+"""Drop-in counterparts of the reference's L4/L3 call surface, backed by the HIP engine.
+
+* ``lec_fixed`` / ``lec_moving``: same arguments, results tree and CSV schema as
+  src/frameworks/lec_fixed_framework.py:30-303 and lec_moving_framework.py:546-745.
+* ``BoxData`` + ``EnergyContents`` / ``ConversionTerms`` / ``BoundaryTerms`` /
+  ``GenerationDissipationTerms`` with the reference's ``calc_*`` methods (box_data.py:78-90,
+  lec_fixed_framework.py:216-271): BoxData runs the two HIP stages once for the whole cube; the
+  ``calc_*`` methods hand out the finished series and append the per-level CSV rows.
+
+Where the reference loops over time steps in Python (lec_moving_framework.py:639) this module
+issues ONE engine call with one box per time step.
+"""
+from __future__ import annotations
+
+import os
+from pathlib import Path
+from typing import Optional
+
+import numpy as np
+import pandas as pd
+import torch
+
+from . import dataset as ds
+from .constants import LEVEL_TERMS, SCALAR_TERMS
+from .engine import LECEngine, LECResult
+from .tables import budgets_and_residuals
+
+FIXED_COLUMNS = ["Az", "Ae", "Kz", "Ke", "Cz", "Ca", "Ck", "Ce", "BAz", "BAe", "BKz", "BKe", "Gz", "Ge"]
+MOVING_COLUMNS = ["Az", "Ae", "Kz", "Ke", "Cz", "Ca", "Ck", "Ce", "BAz", "BAe", "BKz", "BKe", "BΦZ", "BΦE", "Gz", "Ge"]
+
+
+def _device(args=None):
+    dev = getattr(args, "device", None) or os.environ.get("LEC_DEVICE", "cuda:0")
+    if not torch.cuda.is_available():
+        raise RuntimeError("lorenzcycletoolkit_amd needs an AMD GPU (PyTorch-ROCm): there is no CPU path")
+    return torch.device(dev)
+
+
+class BoxData:
+    """Counterpart of box_data.py:58-105.  ``data`` is an LECDataset (time, level, lat, lon).
+
+    Fixed framework: one box for all time steps, dT/dt by finite differences over the cube's time axis.
+    Moving framework: pass ``boxes_limits`` = one (west, east, south, north) per time step (the four
+    scalar limits are then ignored); ``dTdt`` may be None (differentiated on the device, as
+    lorenzcycletoolkit.py:184-186 does over the same time axis) or a host cube.
+    """
+
+    def __init__(self, data: ds.LECDataset, variable_list_df: pd.DataFrame, western_limit=None, eastern_limit=None,
+                 southern_limit=None, northern_limit=None, args=None, results_subdirectory: str = ".",
+                 results_subdirectory_vertical_levels: str = ".", dTdt: Optional[np.ndarray] = None,
+                 boxes_limits=None):
+        if args is not None and not getattr(args, "residuals", True):
+            # the reference looks up "Friction Velocity" here and fails (box_data.py:190-195; SURVEY B-8)
+            raise KeyError("Friction Velocity")
+        self.args = args
+        self.results_subdirectory = results_subdirectory
+        self.results_subdirectory_vertical_levels = results_subdirectory_vertical_levels
+        self.LonIndexer = variable_list_df.loc["Longitude"]["Variable"]
+        self.LatIndexer = variable_list_df.loc["Latitude"]["Variable"]
+        self.TimeName = variable_list_df.loc["Time"]["Variable"]
+        self.VerticalCoordIndexer = variable_list_df.loc["Vertical Level"]["Variable"]
+        self.PressureData = data.level
+        self.time = data.time
+        dev = _device(args)
+        self.engine = LECEngine(data.lat, data.lon, data.level, device=dev)
+        limits = boxes_limits if boxes_limits is not None else [(western_limit, eastern_limit, southern_limit, northern_limit)]
+        self.boxes = [self.engine.box_from_limits(*lim) for lim in limits]
+        iw, ie, js, jn = self.boxes[0]
+        self.western_limit, self.eastern_limit = float(data.lon[iw]), float(data.lon[ie])
+        self.southern_limit, self.northern_limit = float(data.lat[js]), float(data.lat[jn])
+
+        geo_role = "Geopotential" if "Geopotential" in variable_list_df.index else "Geopotential Height"
+        roles = ["Air Temperature", "Eastward Wind Component", "Northward Wind Component", "Omega Velocity", geo_role]
+        cubes = []
+        for role in roles:
+            a = data.variables[str(variable_list_df.loc[role]["Variable"])]
+            scale = ds.field_scale(variable_list_df, role)
+            if role != geo_role and scale != 1.0:
+                a = a * a.dtype.type(scale)
+            cubes.append(torch.as_tensor(np.ascontiguousarray(a)).to(dev))
+        phi_scale = ds.field_scale(variable_list_df, geo_role)
+        dTdt_dev = None if dTdt is None else torch.as_tensor(np.ascontiguousarray(dTdt, dtype=cubes[0].cpu().numpy().dtype)).to(dev)
+        self.result: LECResult = self.engine.compute(cubes[0], cubes[1], cubes[2], cubes[3], cubes[4], self.boxes,
+                                                     time_s=data.time_s if dTdt is None else None, dTdt=dTdt_dev,
+                                                     phi_scale=phi_scale)
+        torch.cuda.synchronize(dev)
+        self.scalars = self.result.scalars_dict()
+        self.levels = self.result.levels_dict()
+        self.nanflag = self.result.nanflag.cpu().numpy()
+
+
+class _Terms:
+    """Shared plumbing of the four analysis classes: hand out a finished series and append its
+    per-level CSV rows exactly where the reference's calc_* would (``_save_vertical_levels``,
+    e.g. conversion_terms.py:287-308)."""
+
+    def __init__(self, box_obj: BoxData, method: str, app_logger=None):
+        if method not in ("fixed", "moving"):
+            raise ValueError("method must be 'fixed' or 'moving'")
+        self.box_obj, self.method, self.app_logger = box_obj, method, app_logger
+
+    def _save_vertical_levels(self, name: str):
+        b = self.box_obj
+        path = f"{b.results_subdirectory_vertical_levels}/{name}_{b.VerticalCoordIndexer}.csv"
+        table = b.levels[name]
+        if self.method == "fixed":
+            if name in ("Cz_1", "Ce_1"):        # level-only term: written transposed (conversion_terms.py:293-294)
+                df = pd.DataFrame({b.VerticalCoordIndexer: b.PressureData, name: table[0]}).T
+            else:
+                df = pd.DataFrame(table, index=pd.DatetimeIndex(b.time), columns=b.PressureData)
+        else:
+            idx = pd.DatetimeIndex(b.time).strftime("%Y-%m-%d %H:%M:%S")
+            df = pd.DataFrame(table, index=idx, columns=b.PressureData)
+        df.to_csv(path, mode="a", header=None)
+
+    def _series(self, name: str, tables):
+        for t in tables:
+            self._save_vertical_levels(t)
+        s = self.box_obj.scalars[name]
+        return s if self.method == "fixed" else s
+
+
+class EnergyContents(_Terms):
+    """energy_contents.py:99-165"""
+    def calc_az(self): return self._series("Az", ["Az"])
+    def calc_ae(self): return self._series("Ae", ["Ae"])
+    def calc_kz(self): return self._series("Kz", ["Kz"])
+    def calc_ke(self): return self._series("Ke", ["Ke"])
+
+
+class ConversionTerms(_Terms):
+    """conversion_terms.py:103-245"""
+    def calc_ca(self): return self._series("Ca", ["Ca_1", "Ca_2", "Ca"])
+    def calc_ce(self): return self._series("Ce", ["Ce_1", "Ce_2", "Ce"])
+    def calc_cz(self): return self._series("Cz", ["Cz_1", "Cz_2", "Cz"])
+    def calc_ck(self): return self._series("Ck", ["Ck_1", "Ck_2", "Ck_3", "Ck_4", "Ck_5", "Ck"])
+
+
+class BoundaryTerms(_Terms):
+    """boundary_terms.py:125-418"""
+    def calc_baz(self): return self._series("BAz", [])
+    def calc_bae(self): return self._series("BAe", [])
+    def calc_bkz(self): return self._series("BKz", [])
+    def calc_bke(self): return self._series("BKe", [])
+    def calc_boz(self): return self._series("BΦZ", [])
+    def calc_boe(self): return self._series("BΦE", [])
+
+
+class GenerationDissipationTerms(_Terms):
+    """generation_and_dissipation_terms.py:122-188"""
+    def calc_gz(self): return self._series("Gz", ["Gz"])
+    def calc_ge(self): return self._series("Ge", ["Ge"])
+
+    def calc_dz(self):
+        raise NotImplementedError("Dz needs friction velocities; the reference marks it unfinished "
+                                  "(generation_and_dissipation_terms.py:158) -- run with -r")
+
+    calc_de = calc_dz
+
+
+def _create_level_csvs(directory, time_name, vert_name, level_pa):
+    """lec_fixed_framework.py:172-197 / lec_moving_framework.py:583-611"""
+    for term in LEVEL_TERMS:
+        columns = [time_name] + [float(i) for i in level_pa]
+        pd.DataFrame(columns=columns).to_csv(Path(directory, f"{term}_{vert_name}.csv"), index=None)
+
+
+def _compute_all(box_obj, method, app_logger):
+    ec = EnergyContents(box_obj, method, app_logger)
+    out = {"Az": ec.calc_az(), "Ae": ec.calc_ae(), "Kz": ec.calc_kz(), "Ke": ec.calc_ke()}
+    ct = ConversionTerms(box_obj, method, app_logger)
+    out.update({"Cz": ct.calc_cz(), "Ca": ct.calc_ca(), "Ck": ct.calc_ck(), "Ce": ct.calc_ce()})
+    bt = BoundaryTerms(box_obj, method, app_logger)
+    out.update({"BAz": bt.calc_baz(), "BAe": bt.calc_bae(), "BKz": bt.calc_bkz(), "BKe": bt.calc_bke(),
+                "BΦZ": bt.calc_boz(), "BΦE": bt.calc_boe()})
+    gd = GenerationDissipationTerms(box_obj, method, app_logger)
+    out.update({"Gz": gd.calc_gz(), "Ge": gd.calc_ge()})
+    return out
+
+
+def lec_fixed(data: ds.LECDataset, variable_list_df: pd.DataFrame, results_subdirectory: str,
+              results_subdirectory_vertical_levels: str, app_logger, args):
+    """Eulerian framework, lec_fixed_framework.py:30-303 (plots are out of scope)."""
+    app_logger.info("Computing energetics using fixed framework (MI355X HIP engine)...")
+    min_lon, max_lon, min_lat, max_lat = ds.read_box_limits(args.box_limits)
+    time_name = variable_list_df.loc["Time"]["Variable"]
+    vert_name = variable_list_df.loc["Vertical Level"]["Variable"]
+    app_logger.info(f"Bounding box: lon=[{min_lon}, {max_lon}], lat=[{min_lat}, {max_lat}]")
+    _create_level_csvs(results_subdirectory_vertical_levels, time_name, vert_name, data.level)
+    try:
+        box_obj = BoxData(data, variable_list_df, min_lon, max_lon, min_lat, max_lat, args, results_subdirectory,
+                          results_subdirectory_vertical_levels)
+    except Exception:
+        app_logger.exception("An exception occurred while creating BoxData object")
+        raise
+    if int(box_obj.nanflag.sum()):
+        app_logger.warning("NaN level values were interpolated/dropped per time step (_handle_nans semantics)")
+    terms = _compute_all(box_obj, "fixed", app_logger)
+    app_logger.info("Computed energy, conversion, boundary and generation terms")
+    df = pd.DataFrame(index=pd.DatetimeIndex(data.time))
+    for col in FIXED_COLUMNS:                       # BΦZ / BΦE are computed, then dropped (:252-253,:287-290)
+        df[col] = terms[col]
+    full = budgets_and_residuals({c: df[c].values for c in df.columns}, data.time_s, residuals=True)
+    for col in full:
+        if col not in df.columns:
+            df[col] = full[col]
+    if getattr(args, "outname", None):
+        results_filename = args.outname
+    else:
+        results_filename = os.path.basename(args.infile).split(".nc")[0] + "_fixed_results"
+    results_file = Path(results_subdirectory, f"{results_filename}.csv")
+    df.to_csv(results_file)
+    app_logger.info(f"Results saved to {results_file}")
+    if getattr(args, "plots", False):
+        app_logger.warning("-p/--plots: plotting is out of scope of the MI355X engine; the CSVs feed the reference's plot scripts unchanged")
+    return df
+
+
+def get_limits(track: pd.DataFrame, t):
+    """get_limits (lec_moving_framework.py:199-266), track branch: nearest track row in time,
+    default 15 x 15 degree box unless the track has width/length columns."""
+    row = track.iloc[int(np.argmin(np.abs(track.index - t)))]
+    clat, clon = float(row["Lat"]), float(row["Lon"])
+    width, length = row.get("width", 15), row.get("length", 15)
+    return {"datestr": pd.to_datetime(t).strftime("%Y-%m-%d-%H%M"), "central_lat": clat, "central_lon": clon,
+            "length": length, "width": width, "min_lon": clon - width / 2, "max_lon": clon + width / 2,
+            "min_lat": clat - length / 2, "max_lat": clat + length / 2}
+
+
+def lec_moving(data: ds.LECDataset, variable_list_df: pd.DataFrame, dTdt, results_subdirectory: str,
+               figures_directory: str, results_subdirectory_vertical_levels: str, app_logger, args):
+    """Semi-Lagrangian framework, lec_moving_framework.py:546-745.  ``dTdt`` may be None: the engine then
+    differentiates T over the dataset's (track-selected) time axis on the device, which is what
+    run_lec_analysis computes (lorenzcycletoolkit.py:184-186)."""
+    app_logger.info("Computing energetics using moving framework (MI355X HIP engine)...")
+    if not getattr(args, "track", False):
+        raise NotImplementedError("only -t/--track is supported; -c/--choose needs an interactive map")
+    time_name = variable_list_df.loc["Time"]["Variable"]
+    vert_name = variable_list_df.loc["Vertical Level"]["Variable"]
+    _create_level_csvs(results_subdirectory_vertical_levels, time_name, vert_name, data.level)
+    times = pd.DatetimeIndex(data.time)
+    track = ds.read_track(args.trackfile, app_logger)
+    # handle_track_file (lec_moving_framework.py:58-160)
+    if track.index[0] < times.min() or track.index[-1] > times.max():
+        raise ValueError("Track time limits do not match with data time limits.")
+    for name, coord in (("Lon", data.lon), ("Lat", data.lat)):
+        word = "longitude" if name == "Lon" else "latitude"
+        if track[name].max() > coord.max():
+            raise ValueError(f"Track file {word} max limit ({track[name].max():.2f}) exceeds data max {word} limit ({float(coord.max()):.2f}).")
+        if track[name].min() < coord.min():
+            raise ValueError(f"Track file {word} min limit ({track[name].min():.2f}) is below data min {word} limit ({float(coord.min()):.2f}).")
+    if 85000.0 not in data.level:
+        raise KeyError(85000)                                   # lec_moving_framework.py:653-657 selects 85000 Pa exactly
+    limits = [get_limits(track, t) for t in times]
+    boxes = [(l["min_lon"], l["max_lon"], l["min_lat"], l["max_lat"]) for l in limits]
+    box_obj = BoxData(data, variable_list_df, args=args, results_subdirectory=results_subdirectory,
+                      results_subdirectory_vertical_levels=results_subdirectory_vertical_levels, dTdt=dTdt,
+                      boxes_limits=boxes)
+    terms = _compute_all(box_obj, "moving", app_logger)
+    df = pd.DataFrame({c: terms[c] for c in MOVING_COLUMNS}, index=times, dtype=float)
+    full = budgets_and_residuals({c: df[c].values for c in df.columns}, data.time_s,
+                                 residuals=bool(getattr(args, "residuals", False)))
+    for col in full:
+        if col not in df.columns:
+            df[col] = full[col]
+    method = "track"
+    infile_name = os.path.basename(args.infile).split(".nc")[0]
+    results_file = os.path.join(results_subdirectory, f"{infile_name}_{method}_results.csv")
+    df.to_csv(results_file)
+    app_logger.info(f"Results saved to {results_file}")
+    out_track = pd.DataFrame(limits)[["datestr", "central_lat", "central_lon", "length", "width"]]
+    for col in ("min_max_zeta_850", "min_hgt_850", "max_wind_850"):
+        out_track[col] = np.nan      # 850-hPa diagnostics: SURVEY.md 8(f)-2, parity unpinned, not computed yet
+    out_track = out_track.rename(columns={"datestr": "time", "central_lat": "Lat", "central_lon": "Lon"})
+    out_track.to_csv(os.path.join(results_subdirectory, f"{infile_name}_{method}_trackfile"), index=False, sep=";")
+    return results_file, df

@@ -1,0 +1,92 @@
+"""End-to-end drop-in runs (GPU): the reference's own smoke tests (tests/test_R2_fixed.py,
+tests/test_R2_track.py of the reference) re-stated -- copy a preset namelist and box_limits / track
+into inputs/, run the CLI with -r -f / -r -t -- plus what the reference never asserts: the numbers."""
+import os
+import shutil
+
+import numpy as np
+import pandas as pd
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from lorenzcycletoolkit_amd.constants import LEVEL_TERMS
+from oracle import lec_oracle as o
+
+
+@pytest.fixture
+def workdir(tmp_path, golden_dir, monkeypatch):
+    os.makedirs(tmp_path / "inputs")
+    shutil.copy(os.path.join(golden_dir, "inputs", "namelist_NCEP-R2"), tmp_path / "inputs" / "namelist")
+    monkeypatch.chdir(tmp_path)
+    return tmp_path
+
+
+def _main(argv):
+    import lorenzcycletoolkit
+    parser = lorenzcycletoolkit.create_arg_parser()
+    args = parser.parse_args(argv)
+    lorenzcycletoolkit.main(argv)
+    return args
+
+
+def test_catarina_fixed_cli_matches_committed_outputs(workdir, golden_dir):
+    (workdir / "inputs" / "box_limits").write_text("min_lon;-55\nmax_lon;-36\nmin_lat;-35\nmax_lat;-20\n")
+    infile = os.path.join(golden_dir, "Catarina_NCEP-R2.nc")
+    args = _main([infile, "-r", "-f", "-v"])
+    assert args.fixed and args.residuals and args.verbosity and not args.track
+    out = workdir / "LEC_Results" / "Catarina_NCEP-R2_fixed"
+    got = pd.read_csv(out / "Catarina_NCEP-R2_fixed_results.csv", index_col=0)
+    ref = pd.read_csv(os.path.join(golden_dir, "Catarina_NCEP-R2_fixed", "Catarina_NCEP-R2_fixed_results.csv"), index_col=0)
+    assert list(got.columns) == list(ref.columns)                 # same schema, same order
+    assert list(got.index) == list(ref.index)                     # same datetime formatting
+    for c in ref.columns:
+        a, r = got[c].values, ref[c].values
+        assert np.all(np.abs(a - r) <= 5e-4 * np.abs(r) + 2e-4 * np.max(np.abs(r))), c   # float32 noise of the reference
+    assert (out / "log.Catarina_NCEP-R2").exists()
+    lvdir = out / "results_vertical_levels"
+    assert sorted(os.listdir(lvdir)) == sorted(f"{t}_lv_ISBL3.csv" for t in LEVEL_TERMS)
+    az = pd.read_csv(lvdir / "Az_lv_ISBL3.csv", index_col=0)
+    refaz = pd.read_csv(os.path.join(golden_dir, "Catarina_NCEP-R2_fixed", "Az_lv_ISBL3.csv"), index_col=0)
+    assert az.shape == refaz.shape and list(az.index) == list(refaz.index)
+    assert [float(c) for c in az.columns] == [100 * float(c) for c in refaz.columns]   # Pa headers (CHANGELOG 1.0.0) vs hPa in the old sample
+    assert np.max(np.abs(az.values - refaz.values)) / np.max(np.abs(refaz.values)) < 1e-4
+    cz1 = pd.read_csv(lvdir / "Cz_1_lv_ISBL3.csv", index_col=0)
+    assert list(cz1.index) == ["lv_ISBL3", "Cz_1"]                 # level-only term written transposed
+    assert np.allclose(cz1.loc["Cz_1"].values * cz1.loc["lv_ISBL3"].values * o.G, o.RD)
+
+
+def test_testdata_track_cli(workdir, golden_dir):
+    shutil.copy(os.path.join(golden_dir, "inputs", "track_testdata_NCEP-R2"), workdir / "inputs" / "track")
+    infile = os.path.join(golden_dir, "testdata_NCEP-R2.nc")
+    _main([infile, "-r", "-t"])
+    out = workdir / "LEC_Results" / "testdata_NCEP-R2_track"
+    got = pd.read_csv(out / "testdata_NCEP-R2_track_results.csv", index_col=0)
+    want = ["Az", "Ae", "Kz", "Ke", "Cz", "Ca", "Ck", "Ce", "BAz", "BAe", "BKz", "BKe", "BΦZ", "BΦE", "Gz", "Ge",
+            "∂Az/∂t (finite diff.)", "∂Ae/∂t (finite diff.)", "∂Kz/∂t (finite diff.)", "∂Ke/∂t (finite diff.)",
+            "RGz", "RKz", "RGe", "RKe"]
+    assert list(got.columns) == want and len(got) == 5
+    # numbers: oracle on the same float32 data upcast to fp64
+    dom = o.load_ncep_sample(infile, dtype=np.float64)
+    tr = pd.read_csv(workdir / "inputs" / "track", sep=";")
+    domt = o.crop_domain_track(dom, tr.Lat.values, tr.Lon.values)
+    limits = [(lo - 7.5, lo + 7.5, la - 7.5, la + 7.5) for la, lo in zip(tr.Lat, tr.Lon)]
+    ref, reflv = o.lec_moving(domt, limits)
+    for c in want:
+        r = np.asarray(ref[c], dtype=np.float64)
+        assert np.max(np.abs(got[c].values - r)) <= 1e-9 * np.max(np.abs(r)), c
+    # per-level tables: one row per time step; the committed Reg1 track sample pins Kz / Ke / Ce rows 1-3
+    kz = pd.read_csv(out / "results_vertical_levels" / "Kz_lv_ISBL3.csv", index_col=0)
+    assert kz.shape == (5, 5) and kz.index[1] == "2005-08-08 06:00:00"
+    gold = pd.read_csv(os.path.join(golden_dir, "Reg1_track", "Kz_lv_ISBL3.csv"), index_col=0)
+    cols = ["60000.0", "70000.0", "85000.0", "92500.0", "100000.0"]
+    assert np.max(np.abs(kz.values[:3] / gold[cols].values - 1)) < 5e-7
+    trk = pd.read_csv(out / "testdata_NCEP-R2_track_trackfile", sep=";")
+    assert list(trk.columns) == ["time", "Lat", "Lon", "length", "width", "min_max_zeta_850", "min_hgt_850", "max_wind_850"]
+    assert trk["time"][0] == "2005-08-08-0000" and trk["width"][0] == 15
+
+
+def test_non_residual_mode_fails_like_the_reference(workdir, golden_dir):
+    (workdir / "inputs" / "box_limits").write_text("min_lon;-55\nmax_lon;-36\nmin_lat;-35\nmax_lat;-20\n")
+    with pytest.raises(KeyError, match="Friction Velocity"):       # SURVEY B-8: only -r works in the reference
+        _main([os.path.join(golden_dir, "Catarina_NCEP-R2.nc"), "-f"])
