@@ -150,7 +150,8 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(f"rowstats_{args.storage}_{'noq' if args.no_q else 'all'}_hbm_bytes_per_launch")
+                per_t = json.load(open(pmc)).get(f"rowstats_{args.storage}_{'noq' if args.no_q else 'all'}_hbm_bytes_per_timestep")
+                traffic = None if per_t is None else per_t * T_local
             except Exception:
                 traffic = None
         out = {
