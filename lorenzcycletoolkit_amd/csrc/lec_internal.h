@@ -11,9 +11,9 @@
 
 // vectors per lane of the largest row kernel (rows up to 256 * LEC_MAX_ITERS vectors)
 #define LEC_MAX_ITERS 8
-// minimum waves per SIMD requested from the register allocator for the row kernel
+// > 0 overrides the per-configuration waves-per-SIMD request of the row kernel (experiments)
 #ifndef LEC_MINW
-#define LEC_MINW 1
+#define LEC_MINW 0
 #endif
 
 // records an error message (thread-local) and returns `code`

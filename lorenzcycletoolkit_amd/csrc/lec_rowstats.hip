@@ -59,18 +59,15 @@ struct VecLoad<float, 1> {
     static __device__ __forceinline__ void load(const float* p, double (&o)[1]) { o[0] = (double)(NT ? __builtin_nontemporal_load(p) : *p); }
 };
 
-// elements e0 .. e0+VEC-1 of a box row of nxb points (elements outside the box read as 0)
-template <typename TIN, int VEC, bool NT = false>
-__device__ __forceinline__ void load_row_vec(const TIN* __restrict__ row, int e0, int nxb, double (&o)[VEC]) {
-    if (e0 >= 0 && e0 + VEC <= nxb) {
-        VecLoad<TIN, VEC>::template load<NT>(row + e0, o);
-    } else {
-#pragma unroll
-        for (int q = 0; q < VEC; ++q) {
-            const int e = e0 + q;
-            o[q] = (e >= 0 && e < nxb) ? (double)row[e] : 0.0;
-        }
-    }
+// Branch-free row loads.  `e0c` is the lane's first element index clamped so that the 16-byte vector
+// always lies inside the row's own memory (every vector that holds at least one box element is
+// inside the cube because rows start/end on vector boundaries in the aligned instantiation; lanes
+// wholly outside the box are clamped onto the last such vector).  Out-of-box elements are zeroed by
+// the caller with a select -- no divergent branch, so the compiler can keep every load of a row in
+// flight at once (a branchy version serialised them behind s_waitcnt vmcnt(0)).
+template <typename TIN, int VEC, bool NT>
+__device__ __forceinline__ void load_vec(const TIN* __restrict__ row, int e0c, double (&o)[VEC]) {
+    VecLoad<TIN, VEC>::template load<NT>(row + e0c, o);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -113,8 +110,8 @@ struct RowParams {
     const double* tcoef;
     double* rows;
     int order;   // block -> row mapping: 0 memory order, 1 XCD-chunked latitudes with level fastest
-    int jchunk;  // order 1: latitudes per XCD chunk
-    int nt_stream;  // nontemporal loads for the fields no other row re-reads
+    int jchunk;  // order >= 1: latitudes per XCD chunk
+    int tgroup;  // order 3: time steps per group
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -123,10 +120,24 @@ struct RowParams {
 //   VEC      elements per 16-byte load (1 = unaligned fallback)
 //   ITERS    vectors per lane
 //   UNIFORM  uniformly spaced longitudes (weights / d-dlon from two scalars instead of tables)
-//   WITH_Q   compute the diabatic-heating residual statistics (needs T at t+-1, k+-1, j+-1, i+-1)
+//   MODE     0: T,u,v,omega only (no Phi, no Q)   1: all terms, dT/dt from the cube (tcoef)
+//            2: all terms, dT/dt supplied as a cube
 // ---------------------------------------------------------------------------------------------
-template <typename TIN, int VEC, int ITERS, bool UNIFORM, bool WITH_Q>
-__global__ void __launch_bounds__(256, LEC_MINW) lec_rowstats_kernel(const RowParams p) {
+// waves per SIMD asked of the register allocator, from the round-1 A/B on MI355X (profiles/r01_notes.md):
+// the 4-field configuration gains from 4 waves (70 % vs 66 % of HBM peak), fp32 storage from 3,
+// the fp64 all-terms kernel is fastest unconstrained (170 VGPRs, 2 waves; forcing 128 spills).
+template <typename TIN, int ITERS, int MODE>
+constexpr int lec_min_waves() {
+#if LEC_MINW > 0
+    return LEC_MINW;
+#else
+    return (ITERS > 3) ? 1 : (sizeof(TIN) == 4 ? 3 : (MODE == 0 ? 4 : 1));
+#endif
+}
+
+template <typename TIN, int VEC, int ITERS, bool UNIFORM, int MODE>
+__global__ void __launch_bounds__(256, (lec_min_waves<TIN, ITERS, MODE>())) lec_rowstats_kernel(const RowParams p) {
+    constexpr bool WITH_Q = MODE != 0;
     __shared__ double red[16 * kRedStride];
     __shared__ double bc[8];
 
@@ -139,20 +150,37 @@ __global__ void __launch_bounds__(256, LEC_MINW) lec_rowstats_kernel(const RowPa
         tl = r / p.nl;
     } else {
         // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 = XCD label, speed only):
-        // give each XCD a contiguous latitude chunk and walk it level-fastest, so that the T rows at
-        // k+-1 / j+-1 needed by the diabatic-heating stencil are rows sibling workgroups on the SAME
-        // XCD stream at about the same time (L2 hits instead of fabric reads).
+        // give each XCD a contiguous latitude chunk so that the T rows at j+-1 / k+-1 needed by the
+        // diabatic-heating stencil are rows sibling workgroups on the SAME XCD stream at about the
+        // same time (L2 hits instead of fabric reads).
         const int xcd = blockIdx.x & 7;
         int q = blockIdx.x >> 3;
         const int per_t = p.jchunk * p.nl;
-        tl = q / per_t; q -= tl * per_t;
         int jl;
-        if (p.order == 1) {          // level fastest
-            jl = q / p.nl;
-            k = q - jl * p.nl;
-        } else {                     // latitude fastest inside the XCD's chunk
-            k = q / p.jchunk;
-            jl = q - k * p.jchunk;
+        if (p.order == 3) {
+            // groups of `tgroup` time steps walked together: (group, level, step in group, latitude)
+            const int per_g = per_t * p.tgroup;
+            const int g = q / per_g; q -= g * per_g;
+            const int gsize = min(p.tgroup, p.t_count - g * p.tgroup);   // last group may be short
+            const int per_k = p.jchunk * gsize;
+            k = q / per_k; q -= k * per_k;
+            if (k >= p.nl) return;
+            const int ti = q / p.jchunk;
+            jl = q - ti * p.jchunk;
+            tl = g * p.tgroup + ti;
+        } else {
+            tl = q / per_t; q -= tl * per_t;
+            if (p.order == 1) {          // level fastest
+                jl = q / p.nl;
+                k = q - jl * p.nl;
+            } else {                     // latitude fastest inside the XCD's chunk
+                k = q / p.jchunk;
+                jl = q - k * p.jchunk;
+                if (p.order == 4) {      // even latitudes first, then odd: j+-1 siblings never run at the same instant
+                    const int half = (p.jchunk + 1) >> 1;
+                    jl = (jl < half) ? 2 * jl : 2 * (jl - half) + 1;
+                }
+            }
         }
         jb = xcd * p.jchunk + jl;
         if (jb >= p.nyb_max) return;
@@ -170,12 +198,16 @@ __global__ void __launch_bounds__(256, LEC_MINW) lec_rowstats_kernel(const RowPa
     const size_t cube = plane * p.nl;
     const size_t rowoff = (size_t)t * cube + (size_t)k * plane + (size_t)j * p.nx + iw;
     const int shift = (VEC > 1) ? (int)(rowoff % VEC) : 0;
+    // first element of the last vector that still touches the row: clamp target for idle lanes
+    const int e0_last = ((nxb - 1 + shift) / VEC) * VEC - shift;
 
     const TIN* __restrict__ rT = (const TIN*)p.T + rowoff;
     const TIN* __restrict__ rU = (const TIN*)p.U + rowoff;
     const TIN* __restrict__ rV = (const TIN*)p.V + rowoff;
     const TIN* __restrict__ rW = (const TIN*)p.W + rowoff;
-    const TIN* __restrict__ rP = p.P ? (const TIN*)p.P + rowoff : nullptr;
+    // no geopotential cube: read T instead and multiply by 0 (keeps the loads branch-free)
+    const TIN* __restrict__ rP = (const TIN*)(p.P ? p.P : p.T) + rowoff;
+    const double phimul = p.P ? 1.0 : 0.0;
 
     const double inv_xlen = p.boxtab[4 * bi + 0];
     const double h_rad = p.boxtab[4 * bi + 1];
@@ -184,7 +216,7 @@ __global__ void __launch_bounds__(256, LEC_MINW) lec_rowstats_kernel(const RowPa
     const double* __restrict__ gl = UNIFORM ? nullptr : p.glon + (size_t)bi * p.nxb_max * 3;
 
     // Q neighbours (clamped to an existing row; the matching coefficient is 0 there)
-    const TIN *rTjm = rT, *rTjp = rT, *rTkm = rT, *rTkp = rT, *rTtm = rT, *rTtp = rT, *rDT = nullptr;
+    const TIN *rTjm = rT, *rTjp = rT, *rTkm = rT, *rTkp = rT, *rTtm = rT, *rTtp = rT;
     double ga = 0, gb = 0, gc = 0, inv_dx = 0, al = 0, be = 0, gm = 0, ta = 0, tb = 0, tc = 0;
     if (WITH_Q) {
         if (jb > 0) rTjm = rT - p.nx;
@@ -195,8 +227,9 @@ __global__ void __launch_bounds__(256, LEC_MINW) lec_rowstats_kernel(const RowPa
         ga = lt[0]; gb = lt[1]; gc = lt[2]; inv_dx = lt[3];
         const double* lv = p.levtab + (size_t)k * 3;
         al = lv[0]; be = lv[1]; gm = lv[2];
-        if (p.DT) {
-            rDT = (const TIN*)p.DT + rowoff;
+        if (MODE == 2) {
+            rTtm = (const TIN*)p.DT + rowoff;      // the dT/dt cube rides in the "t-1" slot
+            ta = 1.0; tb = 0.0; tc = 0.0;
         } else {
             if (t > 0) rTtm = rT - cube;
             if (t < p.nt - 1) rTtp = rT + cube;
@@ -208,101 +241,89 @@ __global__ void __launch_bounds__(256, LEC_MINW) lec_rowstats_kernel(const RowPa
     double fT[ITERS][VEC], fU[ITERS][VEC], fV[ITERS][VEC], fW[ITERS][VEC], fP[ITERS][VEC], fQ[ITERS][VEC];
     double wg[ITERS][VEC];
     double a1[6] = {0, 0, 0, 0, 0, 0};
+    double ewT = 0, ewU = 0, ewV = 0, eeT = 0, eeU = 0, eeV = 0;
+    bool has_w = false, has_e = false;
 
-    // ---------------- sweep 1: loads, Q, weighted sums ----------------
+    // ---------------- own rows: every load of the row in flight before the first use ----------------
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int e0c = min((it * nthr + tid) * VEC - shift, e0_last);
+        load_vec<TIN, VEC, MODE == 0>(rT, e0c, fT[it]);       // T is re-read by neighbour rows unless MODE 0
+        load_vec<TIN, VEC, true>(rU, e0c, fU[it]);
+        load_vec<TIN, VEC, true>(rV, e0c, fV[it]);
+        load_vec<TIN, VEC, true>(rW, e0c, fW[it]);
+        if (MODE != 0 || p.P) {                // wave-uniform
+            load_vec<TIN, VEC, true>(rP, e0c, fP[it]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) fP[it][q] = 0.0;
+        }
+    }
+
+    // ---------------- sweep 1: Q, weighted sums ----------------
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         const int e0 = (it * nthr + tid) * VEC - shift;
-        if (it * nthr * VEC - shift < nxb) {  // wave-uniform: this iteration touches the row at all
-            load_row_vec<TIN, VEC>(rT, e0, nxb, fT[it]);
-            if (p.nt_stream) {
-                load_row_vec<TIN, VEC, true>(rU, e0, nxb, fU[it]);
-                load_row_vec<TIN, VEC, true>(rV, e0, nxb, fV[it]);
-                load_row_vec<TIN, VEC, true>(rW, e0, nxb, fW[it]);
-            } else {
-                load_row_vec<TIN, VEC>(rU, e0, nxb, fU[it]);
-                load_row_vec<TIN, VEC>(rV, e0, nxb, fV[it]);
-                load_row_vec<TIN, VEC>(rW, e0, nxb, fW[it]);
-            }
-            if (rP) {
-                if (p.nt_stream) load_row_vec<TIN, VEC, true>(rP, e0, nxb, fP[it]);
-                else load_row_vec<TIN, VEC>(rP, e0, nxb, fP[it]);
-            } else {
+        const int e0c = min(e0, e0_last);
+        double tjm[VEC], tjp[VEC], tkm[VEC], tkp[VEC], tm[VEC], tp[VEC];
+        double tl_edge = 0.0, tr_edge = 0.0;
+        if (WITH_Q) {
+            load_vec<TIN, VEC, false>(rTjm, e0c, tjm);
+            load_vec<TIN, VEC, false>(rTjp, e0c, tjp);
+            load_vec<TIN, VEC, false>(rTkm, e0c, tkm);
+            load_vec<TIN, VEC, false>(rTkp, e0c, tkp);
+            load_vec<TIN, VEC, true>(rTtm, e0c, tm);
+            if (MODE == 1) load_vec<TIN, VEC, true>(rTtp, e0c, tp);
+            const int le = min(max(e0 - 1, 0), nxb - 1);
+            const int re = min(max(e0 + VEC, 0), nxb - 1);
+            tl_edge = (double)rT[le];
+            tr_edge = (double)rT[re];
+        }
 #pragma unroll
-                for (int q = 0; q < VEC; ++q) fP[it][q] = 0.0;
+        for (int q = 0; q < VEC; ++q) {
+            const int e = e0 + q;
+            const bool inside = (e >= 0) && (e < nxb) && (e0 == e0c);
+            const bool first = inside && (e == 0), last = inside && (e == nxb - 1);
+            double w;
+            if (UNIFORM) {
+                w = inside ? ((first || last) ? 0.5 * h_rad : h_rad) : 0.0;
+            } else {
+                w = inside ? wl[min(max(e, 0), nxb - 1)] : 0.0;
             }
-            double tjm[VEC], tjp[VEC], tkm[VEC], tkp[VEC], dtv[VEC];
-            double tl_edge = 0.0, tr_edge = 0.0;
+            wg[it][q] = w;
+            const double T0 = inside ? fT[it][q] : 0.0;
+            const double U0 = inside ? fU[it][q] : 0.0;
+            const double V0 = inside ? fV[it][q] : 0.0;
+            const double W0 = inside ? fW[it][q] : 0.0;
+            const double P0 = inside ? fP[it][q] * phimul : 0.0;
+            double Q = 0.0;
             if (WITH_Q) {
-                load_row_vec<TIN, VEC>(rTjm, e0, nxb, tjm);
-                load_row_vec<TIN, VEC>(rTjp, e0, nxb, tjp);
-                load_row_vec<TIN, VEC>(rTkm, e0, nxb, tkm);
-                load_row_vec<TIN, VEC>(rTkp, e0, nxb, tkp);
-                if (rDT) {
-                    load_row_vec<TIN, VEC>(rDT, e0, nxb, dtv);
-                } else {
-                    double tm[VEC], tp[VEC];
-                    if (p.nt_stream) {
-                        load_row_vec<TIN, VEC, true>(rTtm, e0, nxb, tm);
-                        load_row_vec<TIN, VEC, true>(rTtp, e0, nxb, tp);
-                    } else {
-                        load_row_vec<TIN, VEC>(rTtm, e0, nxb, tm);
-                        load_row_vec<TIN, VEC>(rTtp, e0, nxb, tp);
-                    }
-#pragma unroll
-                    for (int q = 0; q < VEC; ++q) dtv[q] = ta * tm[q] + tb * fT[it][q] + tc * tp[q];
-                }
-                const int le = min(max(e0 - 1, 0), nxb - 1);
-                const int re = min(max(e0 + VEC, 0), nxb - 1);
-                tl_edge = (double)rT[le];
-                tr_edge = (double)rT[re];
-            }
-#pragma unroll
-            for (int q = 0; q < VEC; ++q) {
-                const int e = e0 + q;
-                const bool inside = (e >= 0) && (e < nxb);
-                const bool first = (e == 0), last = (e == nxb - 1);
-                double w;
+                const double Tl = (q == 0) ? tl_edge : fT[it][q > 0 ? q - 1 : 0];
+                const double Tr = (q == VEC - 1) ? tr_edge : fT[it][q < VEC - 1 ? q + 1 : q];
+                double dTl;
                 if (UNIFORM) {
-                    w = inside ? ((first || last) ? 0.5 * h_rad : h_rad) : 0.0;
+                    dTl = first ? (Tr - T0) * inv_hdeg : (last ? (T0 - Tl) * inv_hdeg : (Tr - Tl) * (0.5 * inv_hdeg));
                 } else {
-                    w = inside ? wl[e] : 0.0;
+                    const int ec = min(max(e, 0), nxb - 1);
+                    dTl = gl[3 * ec + 0] * Tl + gl[3 * ec + 1] * T0 + gl[3 * ec + 2] * Tr;
                 }
-                wg[it][q] = w;
-                const double T0 = fT[it][q];
-                double Q = 0.0;
-                if (WITH_Q) {
-                    const double Tl = (q == 0) ? tl_edge : fT[it][q > 0 ? q - 1 : 0];
-                    const double Tr = (q == VEC - 1) ? tr_edge : fT[it][q < VEC - 1 ? q + 1 : q];
-                    double dTl;
-                    if (UNIFORM) {
-                        dTl = first ? (Tr - T0) * inv_hdeg : (last ? (T0 - Tl) * inv_hdeg : (Tr - Tl) * (0.5 * inv_hdeg));
-                    } else {
-                        const int ec = inside ? e : 0;
-                        dTl = gl[3 * ec + 0] * Tl + gl[3 * ec + 1] * T0 + gl[3 * ec + 2] * Tr;
-                    }
-                    const double dTphi = ga * tjm[q] + gb * T0 + gc * tjp[q];
-                    const double S = al * tkm[q] + be * T0 + gm * tkp[q];
-                    Q = kCp * (dtv[q] + fU[it][q] * dTl * inv_dx + fV[it][q] * dTphi - fW[it][q] * S);
-                    Q = inside ? Q : 0.0;
-                }
-                fQ[it][q] = Q;
-                a1[0] += w * T0;
-                a1[1] += w * fU[it][q];
-                a1[2] += w * fV[it][q];
-                a1[3] += w * fW[it][q];
-                a1[4] += w * fP[it][q];
-                a1[5] += w * Q;
-                // west / east box columns (boundary_terms.py:138-140 etc.)
-                if (first) { out[LEC_S_TW] = T0; out[LEC_S_UW] = fU[it][q]; out[LEC_S_VW] = fV[it][q]; }
-                if (last)  { out[LEC_S_TE] = T0; out[LEC_S_UE] = fU[it][q]; out[LEC_S_VE] = fV[it][q]; }
+                const double dTdt = (MODE == 1) ? (ta * tm[q] + tb * T0 + tc * tp[q]) : tm[q];
+                const double dTphi = ga * tjm[q] + gb * T0 + gc * tjp[q];
+                const double S = al * tkm[q] + be * T0 + gm * tkp[q];
+                Q = kCp * (dTdt + U0 * dTl * inv_dx + V0 * dTphi - W0 * S);
+                Q = inside ? Q : 0.0;
             }
-        } else {
-#pragma unroll
-            for (int q = 0; q < VEC; ++q) {
-                fT[it][q] = fU[it][q] = fV[it][q] = fW[it][q] = fP[it][q] = fQ[it][q] = 0.0;
-                wg[it][q] = 0.0;
-            }
+            fT[it][q] = T0; fU[it][q] = U0; fV[it][q] = V0; fW[it][q] = W0; fP[it][q] = P0; fQ[it][q] = Q;
+            a1[0] += w * T0;
+            a1[1] += w * U0;
+            a1[2] += w * V0;
+            a1[3] += w * W0;
+            a1[4] += w * P0;
+            a1[5] += w * Q;
+            // west / east box columns (boundary_terms.py:138-140 etc.): captured with selects, stored once
+            // after the sweeps so that no store sits between the loads of later iterations
+            ewT = first ? T0 : ewT; ewU = first ? U0 : ewU; ewV = first ? V0 : ewV; has_w = has_w || first;
+            eeT = last ? T0 : eeT;  eeU = last ? U0 : eeU;  eeV = last ? V0 : eeV;  has_e = has_e || last;
         }
     }
 
@@ -357,6 +378,8 @@ __global__ void __launch_bounds__(256, LEC_MINW) lec_rowstats_kernel(const RowPa
         const int rshift = (nthr == 256) ? 3 : (nthr == 128 ? 2 : 1);
         if ((tid & ((1 << rshift) - 1)) == 0 && (tid >> rshift) < 16) out[LEC_S_TT + (tid >> rshift)] = tot * inv_xlen;
     }
+    if (has_w) { out[LEC_S_TW] = ewT; out[LEC_S_UW] = ewU; out[LEC_S_VW] = ewV; }
+    if (has_e) { out[LEC_S_TE] = eeT; out[LEC_S_UE] = eeU; out[LEC_S_VE] = eeV; }
     if (tid < 4) out[LEC_S_SPARE + tid] = 0.0;
 }
 
@@ -364,28 +387,31 @@ __global__ void __launch_bounds__(256, LEC_MINW) lec_rowstats_kernel(const RowPa
 // host-side dispatch
 // ---------------------------------------------------------------------------------------------
 template <typename TIN, int VEC, int ITERS>
-void launch_cfg(const RowParams& p, bool uniform, bool with_q, int nthr, int nblocks, hipStream_t st) {
+void launch_cfg(const RowParams& p, bool uniform, int mode, int nthr, int nblocks, hipStream_t st) {
     dim3 grid(nblocks), block(nthr);
+#define LEC_LAUNCH(U, M) hipLaunchKernelGGL((lec_rowstats_kernel<TIN, VEC, ITERS, U, M>), grid, block, 0, st, p)
     if (uniform) {
-        if (with_q) hipLaunchKernelGGL((lec_rowstats_kernel<TIN, VEC, ITERS, true, true>), grid, block, 0, st, p);
-        else        hipLaunchKernelGGL((lec_rowstats_kernel<TIN, VEC, ITERS, true, false>), grid, block, 0, st, p);
+        if (mode == 0) LEC_LAUNCH(true, 0); else if (mode == 1) LEC_LAUNCH(true, 1); else LEC_LAUNCH(true, 2);
     } else {
-        if (with_q) hipLaunchKernelGGL((lec_rowstats_kernel<TIN, VEC, ITERS, false, true>), grid, block, 0, st, p);
-        else        hipLaunchKernelGGL((lec_rowstats_kernel<TIN, VEC, ITERS, false, false>), grid, block, 0, st, p);
+        if (mode == 0) LEC_LAUNCH(false, 0); else if (mode == 1) LEC_LAUNCH(false, 1); else LEC_LAUNCH(false, 2);
     }
+#undef LEC_LAUNCH
 }
 
 template <typename TIN, int VEC>
-int launch_vec(const RowParams& p, bool uniform, bool with_q, int nblocks, hipStream_t st) {
+int launch_vec(const RowParams& p, bool uniform, int mode, int nblocks, hipStream_t st) {
     // vectors needed to cover the longest row, plus one for the alignment shift
     const int nvec = (p.nxb_max + VEC - 1) / VEC + (VEC > 1 ? 1 : 0);
     int nthr = 256;
     if (nvec <= 64) nthr = 64;
     else if (nvec <= 128) nthr = 128;
     const int iters = (nvec + nthr - 1) / nthr;
-    if (iters <= 1) launch_cfg<TIN, VEC, 1>(p, uniform, with_q, nthr, nblocks, st);
-    else if (iters <= 3) launch_cfg<TIN, VEC, 3>(p, uniform, with_q, nthr, nblocks, st);
-    else if (iters <= LEC_MAX_ITERS) launch_cfg<TIN, VEC, LEC_MAX_ITERS>(p, uniform, with_q, nthr, nblocks, st);
+    if (iters <= 1) launch_cfg<TIN, VEC, 1>(p, uniform, mode, nthr, nblocks, st);
+    else if (iters <= 2) launch_cfg<TIN, VEC, 2>(p, uniform, mode, nthr, nblocks, st);
+    else if (iters <= 3) launch_cfg<TIN, VEC, 3>(p, uniform, mode, nthr, nblocks, st);
+    else if (iters <= 4) launch_cfg<TIN, VEC, 4>(p, uniform, mode, nthr, nblocks, st);
+    else if (iters <= 6) launch_cfg<TIN, VEC, 6>(p, uniform, mode, nthr, nblocks, st);
+    else if (iters <= LEC_MAX_ITERS) launch_cfg<TIN, VEC, LEC_MAX_ITERS>(p, uniform, mode, nthr, nblocks, st);
     else return LEC_ERR_UNSUPPORTED;
     return LEC_OK;
 }
@@ -435,21 +461,24 @@ extern "C" int lec_rowstats(const lec_rowstats_args* a) {
     p.rows = a->rows_d;
     // defaults from the round-1 A/B on MI355X (profiles/r01_notes.md): XCD-chunked latitude-fastest order and
     // nontemporal loads for the once-read fields cut fabric reads by 36 % and time by 10-20 %
-    p.order = 2; p.jchunk = 0; p.nt_stream = 1;
+    p.order = 2; p.jchunk = 0;
     long long nblocks = nrows;
     {   // experiment knobs (defaults chosen from measurements)
         const char* eo = getenv("LEC_ORDER");
-        const char* en = getenv("LEC_NT");
         if (eo) p.order = atoi(eo);
-        if (en) p.nt_stream = atoi(en);
+        const char* eg = getenv("LEC_TGROUP");
+        p.tgroup = eg ? atoi(eg) : 4;
+        if (p.tgroup < 1) p.tgroup = 1;
         if (p.order) {
             p.jchunk = (a->nyb_max + 7) / 8;
-            nblocks = (long long)a->t_count * 8 * p.jchunk * a->nl;
+            const long long tpad = (p.order == 3) ? (long long)((a->t_count + p.tgroup - 1) / p.tgroup) * p.tgroup : a->t_count;
+            nblocks = tpad * 8 * p.jchunk * a->nl;
             if (nblocks > 0x7fffffffLL) { p.order = 0; nblocks = nrows; }
         }
     }
     hipStream_t st = (hipStream_t)a->stream;
-    const bool uni = a->lon_uniform != 0, wq = a->with_q != 0;
+    const bool uni = a->lon_uniform != 0;
+    const int wq = !a->with_q ? 0 : (a->dTdt_d ? 2 : 1);
     int rc;
     if (a->dtype == LEC_F64) rc = aligned ? launch_vec<double, 2>(p, uni, wq, (int)nblocks, st) : launch_vec<double, 1>(p, uni, wq, (int)nblocks, st);
     else                     rc = aligned ? launch_vec<float, 4>(p, uni, wq, (int)nblocks, st) : launch_vec<float, 1>(p, uni, wq, (int)nblocks, st);
