@@ -15,6 +15,10 @@
 #ifndef LEC_MINW
 #define LEC_MINW 0
 #endif
+// waves per SIMD requested for the 384-thread row kernel
+#ifndef LEC_MINW_BIG
+#define LEC_MINW_BIG 3
+#endif
 
 // records an error message (thread-local) and returns `code`
 int lec_set_error(int code, const char* msg);

@@ -15,104 +15,11 @@
 
 #include "../../include/lec_hip.h"
 #include "lec_internal.h"
+#include "lec_rowcommon.h"
 
 namespace {
 
-constexpr double kCp = LEC_CP_D;
-
-// ---------------------------------------------------------------------------------------------
-// vector loads: VEC elements of TIN -> double[VEC]
-// ---------------------------------------------------------------------------------------------
-template <typename TIN, int VEC>
-struct VecLoad;
-
-typedef double dbl2_t __attribute__((ext_vector_type(2)));
-typedef float flt4_t __attribute__((ext_vector_type(4)));
-
-// NT = nontemporal (streaming) load: the line is not kept in L2 ahead of re-used rows
-template <>
-struct VecLoad<double, 2> {
-    template <bool NT>
-    static __device__ __forceinline__ void load(const double* p, double (&o)[2]) {
-        const dbl2_t* q = reinterpret_cast<const dbl2_t*>(p);
-        const dbl2_t v = NT ? __builtin_nontemporal_load(q) : *q;
-        o[0] = v.x; o[1] = v.y;
-    }
-};
-template <>
-struct VecLoad<double, 1> {
-    template <bool NT>
-    static __device__ __forceinline__ void load(const double* p, double (&o)[1]) { o[0] = NT ? __builtin_nontemporal_load(p) : *p; }
-};
-template <>
-struct VecLoad<float, 4> {
-    template <bool NT>
-    static __device__ __forceinline__ void load(const float* p, double (&o)[4]) {
-        const flt4_t* q = reinterpret_cast<const flt4_t*>(p);
-        const flt4_t v = NT ? __builtin_nontemporal_load(q) : *q;
-        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
-    }
-};
-template <>
-struct VecLoad<float, 1> {
-    template <bool NT>
-    static __device__ __forceinline__ void load(const float* p, double (&o)[1]) { o[0] = (double)(NT ? __builtin_nontemporal_load(p) : *p); }
-};
-
-// Branch-free row loads.  `e0c` is the lane's first element index clamped so that the 16-byte vector
-// always lies inside the row's own memory (every vector that holds at least one box element is
-// inside the cube because rows start/end on vector boundaries in the aligned instantiation; lanes
-// wholly outside the box are clamped onto the last such vector).  Out-of-box elements are zeroed by
-// the caller with a select -- no divergent branch, so the compiler can keep every load of a row in
-// flight at once (a branchy version serialised them behind s_waitcnt vmcnt(0)).
-template <typename TIN, int VEC, bool NT>
-__device__ __forceinline__ void load_vec(const TIN* __restrict__ row, int e0c, double (&o)[VEC]) {
-    VecLoad<TIN, VEC>::template load<NT>(row + e0c, o);
-}
-
-// ---------------------------------------------------------------------------------------------
-// block-wide sums of N per-thread values through an LDS transpose.
-// nthr in {64,128,256}; R = nthr/32 lanes cooperate on one statistic, each adds 32 partials in a
-// fixed order, then an R-lane butterfly.  On return the lanes with (tid % R) == 0 and tid / R < N
-// hold the total of statistic tid / R.  `red` needs N * kRedStride doubles.
-// ---------------------------------------------------------------------------------------------
-constexpr int kRedStride = 264;  // 256 + 8: the 8 statistics of a wave's lanes land on disjoint LDS banks
-
-template <int N>
-__device__ __forceinline__ double block_sums(const double (&v)[N], double* red, int tid, int nthr) {
-#pragma unroll
-    for (int s = 0; s < N; ++s) red[s * kRedStride + tid] = v[s];
-    __syncthreads();
-    const int rshift = (nthr == 256) ? 3 : (nthr == 128 ? 2 : 1);
-    const int R = 1 << rshift;
-    const int s = tid >> rshift, part = tid & (R - 1);
-    double acc = 0.0;
-    if (s < N) {
-        const double* src = red + s * kRedStride + part;
-#pragma unroll 8
-        for (int m = 0; m < 32; ++m) acc += src[m << rshift];
-    }
-    for (int o = R >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    return acc;
-}
-
-struct RowParams {
-    const void* T; const void* U; const void* V; const void* W; const void* P; const void* DT;
-    int nt, nl, ny, nx;
-    int t_begin, t_count;
-    int n_box, nxb_max, nyb_max;
-    const int* box;
-    const double* boxtab;
-    const double* wlon;
-    const double* glon;
-    const double* lattab;
-    const double* levtab;
-    const double* tcoef;
-    double* rows;
-    int order;   // block -> row mapping: 0 memory order, 1 XCD-chunked latitudes with level fastest
-    int jchunk;  // order >= 1: latitudes per XCD chunk
-    int tgroup;  // order 3: time steps per group
-};
+using namespace lec;
 
 // ---------------------------------------------------------------------------------------------
 // the row kernel
@@ -126,22 +33,23 @@ struct RowParams {
 // waves per SIMD asked of the register allocator, from the round-1 A/B on MI355X (profiles/r01_notes.md):
 // the 4-field configuration gains from 4 waves (70 % vs 66 % of HBM peak), fp32 storage from 3,
 // the fp64 all-terms kernel is fastest unconstrained (170 VGPRs, 2 waves; forcing 128 spills).
-template <typename TIN, int ITERS, int MODE>
+template <typename TIN, int NTHR, int ITERS, int MODE>
 constexpr int lec_min_waves() {
 #if LEC_MINW > 0
     return LEC_MINW;
 #else
-    return (ITERS > 3) ? 1 : (sizeof(TIN) == 4 ? 3 : (MODE == 0 ? 4 : 1));
+    return (NTHR > 256) ? LEC_MINW_BIG : ((ITERS > 3) ? 1 : (sizeof(TIN) == 4 ? 3 : (MODE == 0 ? 4 : 1)));
 #endif
 }
 
-template <typename TIN, int VEC, int ITERS, bool UNIFORM, int MODE>
-__global__ void __launch_bounds__(256, (lec_min_waves<TIN, ITERS, MODE>())) lec_rowstats_kernel(const RowParams p) {
+template <typename TIN, int VEC, int NTHR, int ITERS, bool UNIFORM, int MODE>
+__global__ void __launch_bounds__(NTHR, (lec_min_waves<TIN, NTHR, ITERS, MODE>())) lec_rowstats_kernel(const RowParams p) {
     constexpr bool WITH_Q = MODE != 0;
-    __shared__ double red[16 * kRedStride];
+    __shared__ double red[16 * red_stride(NTHR)];
     __shared__ double bc[8];
 
-    const int tid = threadIdx.x, nthr = blockDim.x;
+    constexpr int nthr = NTHR;
+    const int tid = threadIdx.x;
     int jb, k, tl;
     if (p.order == 0) {
         int r = blockIdx.x;
@@ -247,13 +155,13 @@ __global__ void __launch_bounds__(256, (lec_min_waves<TIN, ITERS, MODE>())) lec_
     // ---------------- own rows: every load of the row in flight before the first use ----------------
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
-        const int e0c = min((it * nthr + tid) * VEC - shift, e0_last);
-        load_vec<TIN, VEC, MODE == 0>(rT, e0c, fT[it]);       // T is re-read by neighbour rows unless MODE 0
-        load_vec<TIN, VEC, true>(rU, e0c, fU[it]);
-        load_vec<TIN, VEC, true>(rV, e0c, fV[it]);
-        load_vec<TIN, VEC, true>(rW, e0c, fW[it]);
+        const unsigned eo = (unsigned)(min((it * nthr + tid) * VEC - shift, e0_last) + shift);
+        load_vec<TIN, VEC, MODE == 0>(rT - shift, eo, fT[it]);       // T is re-read by neighbour rows unless MODE 0
+        load_vec<TIN, VEC, true>(rU - shift, eo, fU[it]);
+        load_vec<TIN, VEC, true>(rV - shift, eo, fV[it]);
+        load_vec<TIN, VEC, true>(rW - shift, eo, fW[it]);
         if (MODE != 0 || p.P) {                // wave-uniform
-            load_vec<TIN, VEC, true>(rP, e0c, fP[it]);
+            load_vec<TIN, VEC, true>(rP - shift, eo, fP[it]);
         } else {
 #pragma unroll
             for (int q = 0; q < VEC; ++q) fP[it][q] = 0.0;
@@ -265,15 +173,16 @@ __global__ void __launch_bounds__(256, (lec_min_waves<TIN, ITERS, MODE>())) lec_
     for (int it = 0; it < ITERS; ++it) {
         const int e0 = (it * nthr + tid) * VEC - shift;
         const int e0c = min(e0, e0_last);
+        const unsigned eo = (unsigned)(e0c + shift);
         double tjm[VEC], tjp[VEC], tkm[VEC], tkp[VEC], tm[VEC], tp[VEC];
         double tl_edge = 0.0, tr_edge = 0.0;
         if (WITH_Q) {
-            load_vec<TIN, VEC, false>(rTjm, e0c, tjm);
-            load_vec<TIN, VEC, false>(rTjp, e0c, tjp);
-            load_vec<TIN, VEC, false>(rTkm, e0c, tkm);
-            load_vec<TIN, VEC, false>(rTkp, e0c, tkp);
-            load_vec<TIN, VEC, true>(rTtm, e0c, tm);
-            if (MODE == 1) load_vec<TIN, VEC, true>(rTtp, e0c, tp);
+            load_vec<TIN, VEC, false>(rTjm - shift, eo, tjm);
+            load_vec<TIN, VEC, false>(rTjp - shift, eo, tjp);
+            load_vec<TIN, VEC, false>(rTkm - shift, eo, tkm);
+            load_vec<TIN, VEC, false>(rTkp - shift, eo, tkp);
+            load_vec<TIN, VEC, true>(rTtm - shift, eo, tm);
+            if (MODE == 1) load_vec<TIN, VEC, true>(rTtp - shift, eo, tp);
             const int le = min(max(e0 - 1, 0), nxb - 1);
             const int re = min(max(e0 + VEC, 0), nxb - 1);
             tl_edge = (double)rT[le];
@@ -328,8 +237,8 @@ __global__ void __launch_bounds__(256, (lec_min_waves<TIN, ITERS, MODE>())) lec_
     }
 
     {
-        const double tot = block_sums<6>(a1, red, tid, nthr);
-        const int rshift = (nthr == 256) ? 3 : (nthr == 128 ? 2 : 1);
+        const double tot = block_sums<6, NTHR>(a1, red, tid);
+        constexpr int rshift = red_rshift(NTHR);
         if ((tid & ((1 << rshift) - 1)) == 0 && (tid >> rshift) < 6) {
             const double m = tot * inv_xlen;
             bc[tid >> rshift] = m;
@@ -374,8 +283,8 @@ __global__ void __launch_bounds__(256, (lec_min_waves<TIN, ITERS, MODE>())) lec_
         }
     }
     {
-        const double tot = block_sums<16>(a2, red, tid, nthr);
-        const int rshift = (nthr == 256) ? 3 : (nthr == 128 ? 2 : 1);
+        const double tot = block_sums<16, NTHR>(a2, red, tid);
+        constexpr int rshift = red_rshift(NTHR);
         if ((tid & ((1 << rshift) - 1)) == 0 && (tid >> rshift) < 16) out[LEC_S_TT + (tid >> rshift)] = tot * inv_xlen;
     }
     if (has_w) { out[LEC_S_TW] = ewT; out[LEC_S_UW] = ewU; out[LEC_S_VW] = ewV; }
@@ -386,10 +295,10 @@ __global__ void __launch_bounds__(256, (lec_min_waves<TIN, ITERS, MODE>())) lec_
 // ---------------------------------------------------------------------------------------------
 // host-side dispatch
 // ---------------------------------------------------------------------------------------------
-template <typename TIN, int VEC, int ITERS>
-void launch_cfg(const RowParams& p, bool uniform, int mode, int nthr, int nblocks, hipStream_t st) {
-    dim3 grid(nblocks), block(nthr);
-#define LEC_LAUNCH(U, M) hipLaunchKernelGGL((lec_rowstats_kernel<TIN, VEC, ITERS, U, M>), grid, block, 0, st, p)
+template <typename TIN, int VEC, int NTHR, int ITERS>
+void launch_cfg(const RowParams& p, bool uniform, int mode, int nblocks, hipStream_t st) {
+    dim3 grid(nblocks), block(NTHR);
+#define LEC_LAUNCH(U, M) hipLaunchKernelGGL((lec_rowstats_kernel<TIN, VEC, NTHR, ITERS, U, M>), grid, block, 0, st, p)
     if (uniform) {
         if (mode == 0) LEC_LAUNCH(true, 0); else if (mode == 1) LEC_LAUNCH(true, 1); else LEC_LAUNCH(true, 2);
     } else {
@@ -402,21 +311,24 @@ template <typename TIN, int VEC>
 int launch_vec(const RowParams& p, bool uniform, int mode, int nblocks, hipStream_t st) {
     // vectors needed to cover the longest row, plus one for the alignment shift
     const int nvec = (p.nxb_max + VEC - 1) / VEC + (VEC > 1 ? 1 : 0);
-    int nthr = 256;
-    if (nvec <= 64) nthr = 64;
-    else if (nvec <= 128) nthr = 128;
-    const int iters = (nvec + nthr - 1) / nthr;
-    if (iters <= 1) launch_cfg<TIN, VEC, 1>(p, uniform, mode, nthr, nblocks, st);
-    else if (iters <= 2) launch_cfg<TIN, VEC, 2>(p, uniform, mode, nthr, nblocks, st);
-    else if (iters <= 3) launch_cfg<TIN, VEC, 3>(p, uniform, mode, nthr, nblocks, st);
-    else if (iters <= 4) launch_cfg<TIN, VEC, 4>(p, uniform, mode, nthr, nblocks, st);
-    else if (iters <= 6) launch_cfg<TIN, VEC, 6>(p, uniform, mode, nthr, nblocks, st);
-    else if (iters <= LEC_MAX_ITERS) launch_cfg<TIN, VEC, LEC_MAX_ITERS>(p, uniform, mode, nthr, nblocks, st);
+    const char* eb = getenv("LEC_BLOCK");          // experiments: 384-thread workgroups, 2 vectors per lane
+    const int big = eb ? atoi(eb) : 0;
+    if (nvec <= 64) launch_cfg<TIN, VEC, 64, 1>(p, uniform, mode, nblocks, st);
+    else if (nvec <= 128) launch_cfg<TIN, VEC, 128, 1>(p, uniform, mode, nblocks, st);
+    else if (nvec <= 256) launch_cfg<TIN, VEC, 256, 1>(p, uniform, mode, nblocks, st);
+    else if (nvec <= 512) launch_cfg<TIN, VEC, 256, 2>(p, uniform, mode, nblocks, st);
+    else if (nvec <= 768 && big == 384) launch_cfg<TIN, VEC, 384, 2>(p, uniform, mode, nblocks, st);
+    else if (nvec <= 768) launch_cfg<TIN, VEC, 256, 3>(p, uniform, mode, nblocks, st);
+    else if (nvec <= 1024) launch_cfg<TIN, VEC, 256, 4>(p, uniform, mode, nblocks, st);
+    else if (nvec <= 1536) launch_cfg<TIN, VEC, 256, 6>(p, uniform, mode, nblocks, st);
+    else if (nvec <= 256 * LEC_MAX_ITERS) launch_cfg<TIN, VEC, 256, LEC_MAX_ITERS>(p, uniform, mode, nblocks, st);
     else return LEC_ERR_UNSUPPORTED;
     return LEC_OK;
 }
 
 }  // namespace
+
+int lec_launch_rowsweep(lec::RowParams& p, int dtype, bool aligned, bool uniform, int mode, hipStream_t st);
 
 extern "C" int lec_max_row(int dtype, int aligned) {
     const int vec = aligned ? (dtype == LEC_F32 ? 4 : 2) : 1;
@@ -480,7 +392,10 @@ extern "C" int lec_rowstats(const lec_rowstats_args* a) {
     const bool uni = a->lon_uniform != 0;
     const int wq = !a->with_q ? 0 : (a->dTdt_d ? 2 : 1);
     int rc;
-    if (a->dtype == LEC_F64) rc = aligned ? launch_vec<double, 2>(p, uni, wq, (int)nblocks, st) : launch_vec<double, 1>(p, uni, wq, (int)nblocks, st);
+    const char* ek = getenv("LEC_KERNEL");      // 0: one workgroup per row (two sweeps), 1: latitude-sweeping workgroups
+    const int kernel = ek ? atoi(ek) : 0;
+    if (kernel == 1) rc = lec_launch_rowsweep(p, a->dtype, aligned, uni, wq, st);
+    else if (a->dtype == LEC_F64) rc = aligned ? launch_vec<double, 2>(p, uni, wq, (int)nblocks, st) : launch_vec<double, 1>(p, uni, wq, (int)nblocks, st);
     else                     rc = aligned ? launch_vec<float, 4>(p, uni, wq, (int)nblocks, st) : launch_vec<float, 1>(p, uni, wq, (int)nblocks, st);
     if (rc != LEC_OK) return lec_set_error(rc, "lec_rowstats: row too long for the compiled kernels");
     const hipError_t e = hipGetLastError();
