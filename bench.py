@@ -77,13 +77,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        # nccl == RCCL on ROCm; LEC_DIST_BACKEND=gloo is only for rehearsing the N > 1 path on a 1-GPU box
+        dist.init_process_group(backend=os.environ.get("LEC_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
     from lorenzcycletoolkit_amd import _lib
     from lorenzcycletoolkit_amd.engine import LECEngine
-    from lorenzcycletoolkit_amd.parallel import shard_range
+    from lorenzcycletoolkit_amd.parallel import compute_shard, gather_result, halo_range, shard_range
     from lorenzcycletoolkit_amd.synthetic import era5_like_levels, synthetic_cube
 
     level = era5_like_levels()
@@ -97,26 +99,22 @@ def main():
     T_local = args.timesteps
     T_global = T_local * world
     t0, t1 = shard_range(T_global, world, rank)
-    h0, h1 = max(t0 - 1, 0), min(t1 + 1, T_global)          # one-step halo for dT/dt (thermodynamics.py:109-110)
+    h0, h1 = halo_range(t0, t1, T_global)                    # one-step halo for dT/dt (thermodynamics.py:109-110)
     fields = synthetic_cube(h1 - h0, level, lat, lon, device=device, dtype=tdtype, seed=1234, t0_global=h0)
-    time_s = np.arange(h0, h1) * 3600.0
+    time_s = np.arange(T_global) * 3600.0
     eng = LECEngine(lat, lon, level, device=device)
-    box = [eng.box_from_limits(lon[0], lon[-1], lat[0], lat[-1])]
+    box = eng.box_from_limits(lon[0], lon[-1], lat[0], lat[-1])
     with_q = not args.no_q
-    geopt = None if args.no_q else fields["geopt"]
-    n_out = _lib.LEC_NSCALAR + _lib.LEC_NLEVTAB * nl
-    gathered = torch.empty((world * T_local, n_out), dtype=torch.float64, device=device) if world > 1 else None
+    if args.no_q:
+        fields = dict(fields, geopt=None)
 
     kernel_ms = []
 
     def step(record=False):
         timing = [] if record else None
-        res = eng.compute(fields["tair"], fields["u"], fields["v"], fields["omega"], geopt, box,
-                          time_s=time_s if with_q else None, t_begin=t0 - h0, t_count=t1 - t0, with_q=with_q,
-                          timing=timing)
+        res = compute_shard(eng, fields, time_s, T_global, world, rank, box, with_q=with_q, timing=timing)
         if world > 1:
-            local = torch.cat([res.scalars, res.levels.reshape(T_local, -1)], dim=1)
-            dist.all_gather_into_tensor(gathered, local)
+            gather_result(res, T_global)      # the job's only collective (RCCL all_gather over xGMI)
         if record:
             kernel_ms.append(timing)
         return res

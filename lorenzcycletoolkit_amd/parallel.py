@@ -50,3 +50,29 @@ def gather_timeseries(local: torch.Tensor, n_steps: int, group=None) -> torch.Te
         a, b = shard_range(n_steps, world, r)
         parts.append(out[r * width: r * width + (b - a)])
     return torch.cat(parts, dim=0)
+
+
+def compute_shard(engine, fields, time_s_global, n_steps: int, world: int, rank: int, box, *, with_q=True,
+                  phi_scale=1.0, timing=None):
+    """Runs the engine on this rank's contiguous block of time steps.
+
+    ``fields``: dict with this rank's cubes (tair, u, v, omega, geopt) covering the HALO range
+    ``halo_range(*shard_range(...))`` of the global series -- every rank holds its own steps plus one
+    step either side, so dT/dt (np.gradient over the global time axis) needs no exchange.
+    ``time_s_global``: seconds of all n_steps.  Returns the LECResult of the rank's own steps."""
+    t0, t1 = shard_range(n_steps, world, rank)
+    h0, h1 = halo_range(t0, t1, n_steps)
+    if fields["tair"].shape[0] != h1 - h0:
+        raise ValueError(f"rank {rank}: cube must hold time steps [{h0}, {h1}) (own steps plus halo)")
+    return engine.compute(fields["tair"], fields["u"], fields["v"], fields["omega"], fields.get("geopt"), [box],
+                          time_s=time_s_global[h0:h1] if with_q else None, t_begin=t0 - h0, t_count=t1 - t0,
+                          with_q=with_q, phi_scale=phi_scale, timing=timing)
+
+
+def gather_result(res, n_steps: int, group=None):
+    """One collective: [T_local, 16 + 21 nl] rows of every rank -> full series on every rank.
+    With the gloo backend (CPU rehearsal) the rows are staged through host memory."""
+    local = torch.cat([res.scalars, res.levels.reshape(res.levels.shape[0], -1)], dim=1)
+    if dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "gloo":
+        return gather_timeseries(local.cpu(), n_steps, group).to(local.device)
+    return gather_timeseries(local, n_steps, group)

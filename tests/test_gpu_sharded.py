@@ -1,0 +1,66 @@
+"""The N > 1 path on the GPU box's single card: two processes (gloo rendezvous, both on cuda:0) each
+compute their contiguous block of time steps from their own halo'd cube, gather, and must reproduce
+the single-process series bit for bit.  (RCCL needs one GPU per rank; the collective itself is also
+covered on CPU in test_parallel_cpu.py.)"""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+from tests.helpers import synthetic_domain
+
+N_STEPS = 7
+
+
+def _dom():
+    return synthetic_domain(N_STEPS, 5, 12, 128, seed=21)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from lorenzcycletoolkit_amd.engine import LECEngine
+        from lorenzcycletoolkit_amd.parallel import compute_shard, gather_result, halo_range, shard_range
+        dom = _dom()
+        t0, t1 = shard_range(N_STEPS, world, rank)
+        h0, h1 = halo_range(t0, t1, N_STEPS)
+        dev = lambda a: torch.as_tensor(np.ascontiguousarray(a[h0:h1])).to("cuda:0")
+        fields = {"tair": dev(dom.tair), "u": dev(dom.u), "v": dev(dom.v), "omega": dev(dom.omega), "geopt": dev(dom.geopt)}
+        eng = LECEngine(dom.lat, dom.lon, dom.level, device="cuda:0")
+        box = eng.box_from_limits(dom.lon[2], dom.lon[-3], dom.lat[1], dom.lat[-2])
+        res = compute_shard(eng, fields, dom.time_s, N_STEPS, world, rank, box)
+        full = gather_result(res, N_STEPS)
+        np.save(os.path.join(out_dir, f"full_{rank}.npy"), full.cpu().numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_series_equals_single_process(tmp_path, world):
+    from lorenzcycletoolkit_amd.engine import LECEngine
+    dom = _dom()
+    dev = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to("cuda:0")
+    eng = LECEngine(dom.lat, dom.lon, dom.level, device="cuda:0")
+    box = eng.box_from_limits(dom.lon[2], dom.lon[-3], dom.lat[1], dom.lat[-2])
+    res = eng.compute(dev(dom.tair), dev(dom.u), dev(dom.v), dev(dom.omega), dev(dom.geopt), [box], time_s=dom.time_s)
+    want = torch.cat([res.scalars, res.levels.reshape(N_STEPS, -1)], dim=1).cpu().numpy()
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        got = np.load(tmp_path / f"full_{r}.npy")
+        assert got.shape == want.shape
+        assert np.array_equal(got, want), f"rank {r}: sharded series differs from the single-process one"
