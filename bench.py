@@ -33,6 +33,8 @@ def parse_args():
     ap.add_argument("--storage", choices=["f64", "f32"], default="f64", help="storage dtype of the field cubes")
     ap.add_argument("--no-q", action="store_true", help="conversion-terms configuration: T,u,v,omega only (no Q, no Phi)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--moving", action="store_true", help="semi-Lagrangian configuration: one 15x15 degree box per time step "
+                    "on a track-extent crop of the 0.25 degree grid (BASELINE config 5)")
     ap.add_argument("--ny", type=int, default=721)
     ap.add_argument("--nx", type=int, default=1440)
     return ap.parse_args()
@@ -91,6 +93,11 @@ def main():
     level = era5_like_levels()
     lat = np.linspace(-90.0, 90.0, args.ny)
     lon = np.linspace(-180.0, 180.0 - 360.0 / args.nx, args.nx)
+    if args.moving:
+        # the reference crops the data to the track extent +- (half box + one grid step) first
+        # (select_area.py:297-313); the synthetic track wanders over 25 x 45 degrees
+        lat = np.arange(-57.75, -17.5 + 1e-9, 0.25)
+        lon = np.arange(-80.25, -19.75 + 1e-9, 0.25)
     nl = level.size
     tdtype = torch.float64 if args.storage == "f64" else torch.float32
     esz = 8 if args.storage == "f64" else 4
@@ -104,6 +111,12 @@ def main():
     time_s = np.arange(T_global) * 3600.0
     eng = LECEngine(lat, lon, level, device=device)
     box = eng.box_from_limits(lon[0], lon[-1], lat[0], lat[-1])
+    boxes = None
+    if args.moving:
+        tg = np.arange(t0, t1)
+        clat = -37.5 + 12.0 * np.sin(2 * np.pi * tg / 400.0)
+        clon = -50.0 + 22.0 * np.cos(2 * np.pi * tg / 700.0)
+        boxes = [eng.box_from_limits(lo - 7.5, lo + 7.5, la - 7.5, la + 7.5) for la, lo in zip(clat, clon)]
     with_q = not args.no_q
     if args.no_q:
         fields = dict(fields, geopt=None)
@@ -112,7 +125,12 @@ def main():
 
     def step(record=False):
         timing = [] if record else None
-        res = compute_shard(eng, fields, time_s, T_global, world, rank, box, with_q=with_q, timing=timing)
+        if boxes is not None:
+            res = eng.compute(fields["tair"], fields["u"], fields["v"], fields["omega"], fields["geopt"], boxes,
+                              time_s=time_s[h0:h1] if with_q else None, t_begin=t0 - h0, t_count=t1 - t0,
+                              with_q=with_q, timing=timing)
+        else:
+            res = compute_shard(eng, fields, time_s, T_global, world, rank, box, with_q=with_q, timing=timing)
         if world > 1:
             gather_result(res, T_global)      # the job's only collective (RCCL all_gather over xGMI)
         if record:
@@ -140,20 +158,23 @@ def main():
     if rank == 0:
         finite = bool(torch.isfinite(res.scalars).all().item())
         nfields = 4 if args.no_q else 5
-        bytes_per_step_t = nfields * nl * args.ny * args.nx * esz          # algorithmic bytes per time step
+        bytes_per_step_t = nfields * nl * lat.size * lon.size * esz        # algorithmic bytes per time step
+        if args.moving:
+            bytes_per_step_t = nfields * nl * 61 * 61 * esz                # only the box is read
         launch_ms = [a.elapsed_time(b) for pair in kernel_ms for (a, b) in pair]
         avg_launch_ms = float(np.mean(launch_ms))
         achieved = bytes_per_step_t * T_local / (avg_launch_ms * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and not args.moving and (args.ny, args.nx) == (721, 1440):
             try:
                 per_t = json.load(open(pmc)).get(f"rowstats_{args.storage}_{'noq' if args.no_q else 'all'}_hbm_bytes_per_timestep")
                 traffic = None if per_t is None else per_t * T_local
             except Exception:
                 traffic = None
         out = {
-            "metric": "LEC timesteps/sec (all energy+conversion+boundary+generation terms) at 37x721x1440",
+            "metric": ("LEC timesteps/sec (all terms), moving 61x61x37 box per time step" if args.moving else
+                       "LEC timesteps/sec (all energy+conversion+boundary+generation terms) at 37x721x1440"),
             "value": T_global * args.steps / elapsed,
             "unit": "timesteps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -161,8 +182,11 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {
-                "workload": f"synthetic ERA5-res {nl} lev x {args.ny} x {args.nx}, T={T_local} per GPU resident in HBM, "
-                            f"fixed box = whole grid, storage {args.storage}, terms = "
+                "workload": (f"synthetic 0.25-degree {nl} lev x {lat.size} x {lon.size} track-extent crop, T={T_local} per GPU, "
+                             f"moving 15x15-degree box (61 x 61 points) per time step, storage {args.storage}, terms = "
+                             if args.moving else
+                             f"synthetic ERA5-res {nl} lev x {args.ny} x {args.nx}, T={T_local} per GPU resident in HBM, "
+                             f"fixed box = whole grid, storage {args.storage}, terms = ")
                             + ("Az Ae Kz Ke Cz Ca Ck Ce BAz BAe BKz BKe (T,u,v,omega only)" if args.no_q else "all 16 (incl. BPhi, Gz, Ge)"),
                 "timesteps_per_gpu": T_local, "timesteps_global": T_global,
                 "parallelism": f"time-sharded x{world}, RCCL all_gather of per-time-step results",
