@@ -15,6 +15,10 @@
 #ifndef LEC_MINW
 #define LEC_MINW 0
 #endif
+// waves per SIMD requested for the single-sweep row kernel
+#ifndef LEC_MINW_SINGLE
+#define LEC_MINW_SINGLE 4
+#endif
 // waves per SIMD requested for the 384-thread row kernel
 #ifndef LEC_MINW_BIG
 #define LEC_MINW_BIG 3

@@ -43,6 +43,16 @@ struct VecLoad<float, 4> {
         o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
     }
 };
+typedef float flt2_t __attribute__((ext_vector_type(2)));
+template <>
+struct VecLoad<float, 2> {
+    template <bool NT>
+    static __device__ __forceinline__ void load(const float* p, double (&o)[2]) {
+        const flt2_t* q = reinterpret_cast<const flt2_t*>(p);
+        const flt2_t v = NT ? __builtin_nontemporal_load(q) : *q;
+        o[0] = v.x; o[1] = v.y;
+    }
+};
 template <>
 struct VecLoad<float, 1> {
     template <bool NT>

@@ -328,10 +328,11 @@ int launch_vec(const RowParams& p, bool uniform, int mode, int nblocks, hipStrea
 
 }  // namespace
 
-int lec_launch_rowsweep(lec::RowParams& p, int dtype, bool aligned, bool uniform, int mode, hipStream_t st);
+int lec_launch_rowsweep(lec::RowParams& p, int dtype, bool aligned, bool aligned8, bool uniform, int mode, int nblocks, hipStream_t st);
 
 extern "C" int lec_max_row(int dtype, int aligned) {
-    const int vec = aligned ? (dtype == LEC_F32 ? 4 : 2) : 1;
+    (void)dtype;                       // both storage types move two elements per lane and trip
+    const int vec = aligned ? 2 : 1;
     return (256 * LEC_MAX_ITERS - (vec > 1 ? 1 : 0)) * vec;
 }
 
@@ -353,13 +354,14 @@ extern "C" int lec_rowstats(const lec_rowstats_args* a) {
     const size_t esz = a->dtype == LEC_F32 ? 4 : 8;
     const int vecw = (int)(16 / esz);
     const void* cubes[6] = {a->tair_d, a->u_d, a->v_d, a->omega_d, a->geopt_d, a->dTdt_d};
-    bool aligned = (a->nx % vecw) == 0;
+    bool aligned = (a->nx % vecw) == 0, aligned8 = (a->nx % 2) == 0;
     for (const void* c : cubes) {
         if (!c) continue;
         if ((uintptr_t)c % esz) return lec_set_error(LEC_ERR_ARG, "lec_rowstats: cube pointer not aligned to its element size");
         if ((uintptr_t)c % 16) aligned = false;
+        if ((uintptr_t)c % 8) aligned8 = false;
     }
-    if (a->nxb_max > lec_max_row(a->dtype, aligned)) return lec_set_error(LEC_ERR_UNSUPPORTED, "lec_rowstats: box row longer than lec_max_row()");
+    if (a->nxb_max > lec_max_row(a->dtype, a->dtype == LEC_F32 ? aligned8 : aligned)) return lec_set_error(LEC_ERR_UNSUPPORTED, "lec_rowstats: box row longer than lec_max_row()");
     const long long nrows = (long long)a->t_count * a->nl * a->nyb_max;
     if (nrows > 0x7fffffffLL) return lec_set_error(LEC_ERR_UNSUPPORTED, "lec_rowstats: more than 2^31-1 rows in one call");
 
@@ -392,9 +394,11 @@ extern "C" int lec_rowstats(const lec_rowstats_args* a) {
     const bool uni = a->lon_uniform != 0;
     const int wq = !a->with_q ? 0 : (a->dTdt_d ? 2 : 1);
     int rc;
-    const char* ek = getenv("LEC_KERNEL");      // 0: one workgroup per row (two sweeps), 1: latitude-sweeping workgroups
-    const int kernel = ek ? atoi(ek) : 0;
-    if (kernel == 1) rc = lec_launch_rowsweep(p, a->dtype, aligned, uni, wq, st);
+    // 1 (default): single-sweep shifted-moment kernel (lec_rowsweep.hip); 0: two-sweep kernel (this file), kept as
+    // an independent formulation (deviation from the zonal mean, then products) for cross-checks
+    const char* ek = getenv("LEC_KERNEL");
+    const int kernel = ek ? atoi(ek) : 1;
+    if (kernel == 1) rc = lec_launch_rowsweep(p, a->dtype, aligned, aligned8, uni, wq, (int)nblocks, st);
     else if (a->dtype == LEC_F64) rc = aligned ? launch_vec<double, 2>(p, uni, wq, (int)nblocks, st) : launch_vec<double, 1>(p, uni, wq, (int)nblocks, st);
     else                     rc = aligned ? launch_vec<float, 4>(p, uni, wq, (int)nblocks, st) : launch_vec<float, 1>(p, uni, wq, (int)nblocks, st);
     if (rc != LEC_OK) return lec_set_error(rc, "lec_rowstats: row too long for the compiled kernels");

@@ -141,6 +141,24 @@ def test_synthetic_moving_variable_boxes():
     compare(res.scalars_dict(), res.levels_dict(), ref_s, ref_l, TOL, "moving variable boxes")
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_two_kernel_formulations_agree(monkeypatch, dtype):
+    """The default single-sweep kernel (sums about a shift, centred afterwards) and the two-sweep kernel
+    (deviation from the zonal mean, then products -- the reference's own order) are independent
+    formulations of the same row statistics."""
+    dom = synthetic_domain(4, 6, 14, 1000, seed=77, dtype=dtype)
+    limits = (dom.lon[3], dom.lon[-4], dom.lat[1], dom.lat[-2])
+    monkeypatch.setenv("LEC_KERNEL", "1")
+    a = run_fixed(dom, limits, keep_rows=True)
+    monkeypatch.setenv("LEC_KERNEL", "0")
+    b = run_fixed(dom, limits, keep_rows=True)
+    ra, rb = a.rows.cpu().numpy(), b.rows.cpu().numpy()
+    for s in range(28):
+        scale = np.max(np.abs(rb[..., s]))
+        assert np.max(np.abs(ra[..., s] - rb[..., s])) <= 1e-11 * max(scale, 1e-300), f"row statistic {s}"
+    assert torch.allclose(a.scalars, b.scalars, rtol=1e-10, atol=0)
+
+
 def test_time_shard_invariance():
     """Processing [t0, t1) of a cube gives bit-identical results to processing the whole cube."""
     dom = synthetic_domain(6, 5, 10, 128, seed=3)
