@@ -64,32 +64,9 @@ __global__ void __launch_bounds__(NTHR, (lec_min_waves<TIN, NTHR, ITERS, MODE>()
         const int xcd = blockIdx.x & 7;
         int q = blockIdx.x >> 3;
         const int per_t = p.jchunk * p.nl;
-        int jl;
-        if (p.order == 3) {
-            // groups of `tgroup` time steps walked together: (group, level, step in group, latitude)
-            const int per_g = per_t * p.tgroup;
-            const int g = q / per_g; q -= g * per_g;
-            const int gsize = min(p.tgroup, p.t_count - g * p.tgroup);   // last group may be short
-            const int per_k = p.jchunk * gsize;
-            k = q / per_k; q -= k * per_k;
-            if (k >= p.nl) return;
-            const int ti = q / p.jchunk;
-            jl = q - ti * p.jchunk;
-            tl = g * p.tgroup + ti;
-        } else {
-            tl = q / per_t; q -= tl * per_t;
-            if (p.order == 1) {          // level fastest
-                jl = q / p.nl;
-                k = q - jl * p.nl;
-            } else {                     // latitude fastest inside the XCD's chunk
-                k = q / p.jchunk;
-                jl = q - k * p.jchunk;
-                if (p.order == 4) {      // even latitudes first, then odd: j+-1 siblings never run at the same instant
-                    const int half = (p.jchunk + 1) >> 1;
-                    jl = (jl < half) ? 2 * jl : 2 * (jl - half) + 1;
-                }
-            }
-        }
+        tl = q / per_t; q -= tl * per_t;
+        k = q / p.jchunk;                    // latitude fastest inside the XCD's chunk
+        const int jl = q - k * p.jchunk;
         jb = xcd * p.jchunk + jl;
         if (jb >= p.nyb_max) return;
     }
@@ -379,14 +356,11 @@ extern "C" int lec_rowstats(const lec_rowstats_args* a) {
     long long nblocks = nrows;
     {   // experiment knobs (defaults chosen from measurements)
         const char* eo = getenv("LEC_ORDER");
-        if (eo) p.order = atoi(eo);
-        const char* eg = getenv("LEC_TGROUP");
-        p.tgroup = eg ? atoi(eg) : 4;
-        if (p.tgroup < 1) p.tgroup = 1;
+        if (eo) p.order = atoi(eo) ? 2 : 0;
+        p.tgroup = 1;
         if (p.order) {
             p.jchunk = (a->nyb_max + 7) / 8;
-            const long long tpad = (p.order == 3) ? (long long)((a->t_count + p.tgroup - 1) / p.tgroup) * p.tgroup : a->t_count;
-            nblocks = tpad * 8 * p.jchunk * a->nl;
+            nblocks = (long long)a->t_count * 8 * p.jchunk * a->nl;
             if (nblocks > 0x7fffffffLL) { p.order = 0; nblocks = nrows; }
         }
     }
