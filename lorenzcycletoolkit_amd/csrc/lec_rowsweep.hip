@@ -42,12 +42,87 @@ constexpr int sweep_min_waves() {
 #endif
 }
 
+// the 22 shifted sums of one element (see the header comment)
+__device__ __forceinline__ void accum22(double (&acc)[22], double w, double a, double b, double c, double d, double ee, double f) {
+    const double wa = w * a, wb = w * b, wc = w * c, wd = w * d;
+    const double waa = wa * a, wbb = wb * b, wcc = wc * c;
+    acc[0] += wa; acc[1] += wb; acc[2] += wc; acc[3] += wd;
+    acc[4] += w * ee; acc[5] += w * f;
+    acc[6] += waa; acc[7] += wbb; acc[8] += wcc;
+    acc[9] += wc * a;      // <ca>
+    acc[10] += wd * a;     // <da>
+    acc[11] += wb * c;     // <bc>
+    acc[12] += wd * b;     // <db>
+    acc[13] += wd * c;     // <dc>
+    acc[14] += wd * ee;    // <de>
+    acc[15] += wa * f;     // <fa>
+    acc[16] += waa * c;    // <caa>
+    acc[17] += waa * d;    // <daa>
+    acc[18] += wbb * c;    // <bbc>
+    acc[19] += wcc * c;    // <ccc>
+    acc[20] += wbb * d;    // <bbd>
+    acc[21] += wcc * d;    // <ccd>
+}
+
+// block sums of the 22 accumulators (two rounds of 11 through the same LDS tile), then the centred
+// statistics from the shifted sums (lanes 0..21) written to the row record.  Ends with every read of
+// `red` / `tot` complete only after the caller's next barrier.
+template <int NTHR, int NR = kHalf>
+__device__ __forceinline__ void finish_row(const double (&acc)[22], double* red, double* tot, int tid, double inv_xlen,
+                                           double cT, double cU, double cV, double cW, double cP, double* __restrict__ out) {
+    constexpr int rshift = red_rshift(NTHR);
+#pragma unroll
+    for (int r0 = 0; r0 < 22; r0 += NR) {      // rounds of NR statistics through the same LDS tile
+        double h[NR];
+#pragma unroll
+        for (int s = 0; s < NR; ++s) h[s] = (r0 + s < 22) ? acc[(r0 + s < 22) ? r0 + s : 0] : 0.0;
+        const double t0 = block_sums<NR, NTHR>(h, red, tid);
+        if ((tid & ((1 << rshift) - 1)) == 0 && (tid >> rshift) < NR && r0 + (tid >> rshift) < 22)
+            tot[r0 + (tid >> rshift)] = t0 * inv_xlen;
+        __syncthreads();
+    }
+    if (tid < 22) {
+        const double da = tot[0], db = tot[1], dc = tot[2], dd = tot[3], de = tot[4], df = tot[5];
+        const double mT = cT + da, mU = cU + db, mV = cV + dc, mW = cW + dd;
+        const double sTT = tot[6] - da * da, sUU = tot[7] - db * db, sVV = tot[8] - dc * dc;
+        const double sUV = tot[11] - db * dc, sWU = tot[12] - dd * db, sWV = tot[13] - dd * dc;
+        double o;
+        switch (tid) {
+            case 0: o = mT; break;
+            case 1: o = mU; break;
+            case 2: o = mV; break;
+            case 3: o = mW; break;
+            case 4: o = cP + de; break;
+            case 5: o = df; break;
+            case 6: o = sTT; break;
+            case 7: o = sUU; break;
+            case 8: o = sVV; break;
+            case 9: o = tot[9] - dc * da; break;                       // [v'T']
+            case 10: o = tot[10] - dd * da; break;                     // [w'T']
+            case 11: o = sUV; break;
+            case 12: o = sWU; break;
+            case 13: o = sWV; break;
+            case 14: o = tot[14] - dd * de; break;                     // [w'Phi']
+            case 15: o = tot[15] - df * da; break;                     // [Q'T']
+            case 16: o = tot[16] - 2 * da * tot[9] + da * da * dc + cV * sTT; break;     // [v T'T']
+            case 17: o = tot[17] - 2 * da * tot[10] + da * da * dd + cW * sTT; break;    // [w T'T']
+            case 18: o = 2 * mU * sUV + mU * mU * mV + 2 * mV * sVV + mV * mV * mV; break;   // [K v]
+            case 19: o = 2 * mU * sWU + mU * mU * mW + 2 * mV * sWV + mV * mV * mW; break;   // [K w]
+            case 20: o = (tot[18] - 2 * db * tot[11] + db * db * dc) + (tot[19] - 2 * dc * tot[8] + dc * dc * dc)
+                         + cV * (sUU + sVV); break;                                           // [E v]
+            default: o = (tot[20] - 2 * db * tot[12] + db * db * dd) + (tot[21] - 2 * dc * tot[13] + dc * dc * dd)
+                         + cW * (sUU + sVV); break;                                           // [E w]
+        }
+        out[tid] = o;
+    }
+    if (tid < 4) out[LEC_S_SPARE + tid] = 0.0;
+}
+
 // one workgroup per (time, level, box-latitude) row, ONE sweep over the row (see the header comment)
 template <typename TIN, int VEC, int NTHR, int ITERS, bool UNIFORM, int MODE>
 __global__ void __launch_bounds__(NTHR, (sweep_min_waves<TIN, VEC, ITERS, MODE>())) lec_rowsweep_kernel(const RowParams p) {
     constexpr bool WITH_Q = MODE != 0;
     constexpr int nthr = NTHR;
-    constexpr int rshift = red_rshift(NTHR);
     __shared__ double red[kHalf * red_stride(NTHR)];
     __shared__ double tot[24];
 
@@ -187,83 +262,15 @@ __global__ void __launch_bounds__(NTHR, (sweep_min_waves<TIN, VEC, ITERS, MODE>(
                 f = kCp * (dTdt + Uv * dTl * inv_dx + Vv * dTphi - Wv * S);
                 f = inside ? f : 0.0;
             }
-            const double a = Tv - cT, b = Uv - cU, c = Vv - cV, d = Wv - cW, ee = Pv - cP;
-            const double wa = w * a, wb = w * b, wc = w * c, wd = w * d;
-            const double waa = wa * a, wbb = wb * b, wcc = wc * c;
-            acc[0] += wa; acc[1] += wb; acc[2] += wc; acc[3] += wd;
-            acc[4] += w * ee; acc[5] += w * f;
-            acc[6] += waa; acc[7] += wbb; acc[8] += wcc;
-            acc[9] += wc * a;      // <ca>
-            acc[10] += wd * a;     // <da>
-            acc[11] += wb * c;     // <bc>
-            acc[12] += wd * b;     // <db>
-            acc[13] += wd * c;     // <dc>
-            acc[14] += wd * ee;    // <de>
-            acc[15] += wa * f;     // <fa>
-            acc[16] += waa * c;    // <caa>
-            acc[17] += waa * d;    // <daa>
-            acc[18] += wbb * c;    // <bbc>
-            acc[19] += wcc * c;    // <ccc>
-            acc[20] += wbb * d;    // <bbd>
-            acc[21] += wcc * d;    // <ccd>
+            accum22(acc, w, Tv - cT, Uv - cU, Vv - cV, Wv - cW, Pv - cP, f);
             ewT = first ? Tv : ewT; ewU = first ? Uv : ewU; ewV = first ? Vv : ewV; has_w = has_w || first;
             eeT = last ? Tv : eeT;  eeU = last ? Uv : eeU;  eeV = last ? Vv : eeV;  has_e = has_e || last;
         }
     }
 
-    // ---- block sums, two rounds of 11 through the same LDS tile ----
-    {
-        double h[kHalf];
-#pragma unroll
-        for (int s = 0; s < kHalf; ++s) h[s] = acc[s];
-        const double t0 = block_sums<kHalf, NTHR>(h, red, tid);
-        if ((tid & ((1 << rshift) - 1)) == 0 && (tid >> rshift) < kHalf) tot[tid >> rshift] = t0 * inv_xlen;
-        __syncthreads();
-#pragma unroll
-        for (int s = 0; s < kHalf; ++s) h[s] = acc[kHalf + s];
-        const double t1 = block_sums<kHalf, NTHR>(h, red, tid);
-        if ((tid & ((1 << rshift) - 1)) == 0 && (tid >> rshift) < kHalf) tot[kHalf + (tid >> rshift)] = t1 * inv_xlen;
-        __syncthreads();
-    }
-
-    // ---- centred statistics from the shifted sums (lanes 0..21), edge columns, spare ----
-    if (tid < 22) {
-        const double da = tot[0], db = tot[1], dc = tot[2], dd = tot[3], de = tot[4], df = tot[5];
-        const double mT = cT + da, mU = cU + db, mV = cV + dc, mW = cW + dd;
-        const double sTT = tot[6] - da * da, sUU = tot[7] - db * db, sVV = tot[8] - dc * dc;
-        const double sUV = tot[11] - db * dc, sWU = tot[12] - dd * db, sWV = tot[13] - dd * dc;
-        double o;
-        switch (tid) {
-            case 0: o = mT; break;
-            case 1: o = mU; break;
-            case 2: o = mV; break;
-            case 3: o = mW; break;
-            case 4: o = cP + de; break;
-            case 5: o = df; break;
-            case 6: o = sTT; break;
-            case 7: o = sUU; break;
-            case 8: o = sVV; break;
-            case 9: o = tot[9] - dc * da; break;                       // [v'T']
-            case 10: o = tot[10] - dd * da; break;                     // [w'T']
-            case 11: o = sUV; break;
-            case 12: o = sWU; break;
-            case 13: o = sWV; break;
-            case 14: o = tot[14] - dd * de; break;                     // [w'Phi']
-            case 15: o = tot[15] - df * da; break;                     // [Q'T']
-            case 16: o = tot[16] - 2 * da * tot[9] + da * da * dc + cV * sTT; break;     // [v T'T']
-            case 17: o = tot[17] - 2 * da * tot[10] + da * da * dd + cW * sTT; break;    // [w T'T']
-            case 18: o = 2 * mU * sUV + mU * mU * mV + 2 * mV * sVV + mV * mV * mV; break;   // [K v]
-            case 19: o = 2 * mU * sWU + mU * mU * mW + 2 * mV * sWV + mV * mV * mW; break;   // [K w]
-            case 20: o = (tot[18] - 2 * db * tot[11] + db * db * dc) + (tot[19] - 2 * dc * tot[8] + dc * dc * dc)
-                         + cV * (sUU + sVV); break;                                           // [E v]
-            default: o = (tot[20] - 2 * db * tot[12] + db * db * dd) + (tot[21] - 2 * dc * tot[13] + dc * dc * dd)
-                         + cW * (sUU + sVV); break;                                           // [E w]
-        }
-        out[tid] = o;
-    }
+    finish_row<NTHR>(acc, red, tot, tid, inv_xlen, cT, cU, cV, cW, cP, out);
     if (has_w) { out[LEC_S_TW] = ewT; out[LEC_S_UW] = ewU; out[LEC_S_VW] = ewV; }
     if (has_e) { out[LEC_S_TE] = eeT; out[LEC_S_UE] = eeU; out[LEC_S_VE] = eeV; }
-    if (tid < 4) out[LEC_S_SPARE + tid] = 0.0;
 }
 
 template <typename TIN, int VEC, int NTHR, int ITERS>

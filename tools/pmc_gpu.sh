@@ -11,7 +11,7 @@ import csv, glob, collections
 rows = collections.defaultdict(list)
 for f in glob.glob("$OUT/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "rowstats" in r["Kernel_Name"]:
+        if "lec_row" in r["Kernel_Name"]:
             rows[r["Counter_Name"]].append(float(r["Counter_Value"]))
             vg = r["VGPR_Count"], r["SGPR_Count"], r["LDS_Block_Size"], r["Workgroup_Size"], r["Grid_Size"]
 print("$TAG", "vgpr,sgpr,lds,wg,grid=", vg if rows else "(no rows)")

@@ -26,13 +26,13 @@ with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
     w.writeheader()
     for r in rows[:12]:
         w.writerow(r)
-row_k = [r for r in rows if "lec_rowstats_kernel" in r["Name"]][0]
+row_k = [r for r in rows if "lec_row" in r["Name"]][0]
 
 
 def counter(sub, name):
     f = glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv"))[0]
     vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
-            if "lec_rowstats_kernel" in r["Kernel_Name"] and r["Counter_Name"] == name]
+            if "lec_row" in r["Kernel_Name"] and r["Counter_Name"] == name]
     return sum(vals) / len(vals), len(vals)
 
 
