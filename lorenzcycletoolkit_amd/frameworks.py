@@ -268,9 +268,10 @@ def lec_moving(data: ds.LECDataset, variable_list_df: pd.DataFrame, dTdt, result
     results_file = os.path.join(results_subdirectory, f"{infile_name}_{method}_results.csv")
     df.to_csv(results_file)
     app_logger.info(f"Results saved to {results_file}")
-    out_track = pd.DataFrame(limits)[["datestr", "central_lat", "central_lon", "length", "width"]]
-    for col in ("min_max_zeta_850", "min_hgt_850", "max_wind_850"):
-        out_track[col] = np.nan      # 850-hPa diagnostics: SURVEY.md 8(f)-2, parity unpinned, not computed yet
+    # 850-hPa diagnostics of every box (lec_moving_framework.py:650-709); parity unpinned, see diagnostics.py
+    from .diagnostics import track_diagnostics
+    positions = track_diagnostics(data, variable_list_df, limits, track, use_track_zeta=bool(getattr(args, "zeta", False)))
+    out_track = pd.DataFrame([{**l, **p} for l, p in zip(limits, positions)])
     out_track = out_track.rename(columns={"datestr": "time", "central_lat": "Lat", "central_lon": "Lon"})
     out_track.to_csv(os.path.join(results_subdirectory, f"{infile_name}_{method}_trackfile"), index=False, sep=";")
     return results_file, df

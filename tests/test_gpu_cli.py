@@ -82,8 +82,13 @@ def test_testdata_track_cli(workdir, golden_dir):
     cols = ["60000.0", "70000.0", "85000.0", "92500.0", "100000.0"]
     assert np.max(np.abs(kz.values[:3] / gold[cols].values - 1)) < 5e-7
     trk = pd.read_csv(out / "testdata_NCEP-R2_track_trackfile", sep=";")
-    assert list(trk.columns) == ["time", "Lat", "Lon", "length", "width", "min_max_zeta_850", "min_hgt_850", "max_wind_850"]
+    assert list(trk.columns) == ["time", "Lat", "Lon", "length", "width", "min_lon", "max_lon", "min_lat", "max_lat",
+                                 "min_max_zeta_850_lat", "min_max_zeta_850_lon", "min_max_zeta_850",
+                                 "min_hgt_850_lat", "min_hgt_850_lon", "min_hgt_850",
+                                 "max_wind_850_lat", "max_wind_850_lon", "max_wind_850"]
     assert trk["time"][0] == "2005-08-08-0000" and trk["width"][0] == 15
+    assert (trk["min_max_zeta_850"] < 0).all() and (trk["max_wind_850"] > 0).all()       # southern-hemisphere box
+    assert trk["min_hgt_850_lat"].between(-30, -15).all() and trk["max_wind_850_lon"].between(-52.5, -37.5).all()
 
 
 def test_non_residual_mode_fails_like_the_reference(workdir, golden_dir):
