@@ -111,7 +111,10 @@ def test_testdata_moving(golden_dir):
     (300, np.float64, False),    # 256-thread blocks, 1 vector per lane
     (1000, np.float64, False),   # 256-thread blocks, 2-3 vectors per lane
     (1001, np.float64, False),   # odd row length -> scalar-load kernel
-    (2400, np.float64, False),   # up to 8 vectors per lane
+    (1800, np.float64, False),   # 4 vectors per lane
+    (2400, np.float64, False),   # 6 vectors per lane
+    (3500, np.float64, False),   # 8 vectors per lane
+    (3500, np.float32, False),
     (300, np.float32, False),    # float4 loads
     (1000, np.float32, False),
     (303, np.float32, False),    # float, unaligned
@@ -214,6 +217,21 @@ def test_nan_levels_are_repaired_like_handle_nans():
 # ---------------------------------------------------------------------------------------------
 # argument checking mirrors the reference's error behaviour
 # ---------------------------------------------------------------------------------------------
+def test_row_length_limit_is_reported():
+    """Rows longer than lec_max_row() are refused with LEC_ERR_UNSUPPORTED (no silent truncation)."""
+    from lorenzcycletoolkit_amd import _lib
+    from lorenzcycletoolkit_amd.engine import LECEngine
+    lib = _lib.load()
+    nmax = lib.lec_max_row(_lib.LEC_F64, 1)
+    dom = synthetic_domain(2, 3, 4, nmax + 10, seed=1)
+    eng = LECEngine(dom.lat, dom.lon, dom.level, device="cuda:0")
+    T = _dev(dom.tair)
+    ok = eng.compute(T, T, T, T, T, [(0, nmax - 1, 0, 3)], time_s=dom.time_s)          # longest supported row
+    assert torch.isfinite(ok.scalars[:, :4]).all()
+    with pytest.raises(_lib.LecLibraryError, match="longer than lec_max_row"):
+        eng.compute(T, T, T, T, T, [(0, nmax + 1, 0, 3)], time_s=dom.time_s)
+
+
 def test_errors():
     from lorenzcycletoolkit_amd.engine import LECEngine
     dom = synthetic_domain(3, 5, 10, 64, seed=9)
