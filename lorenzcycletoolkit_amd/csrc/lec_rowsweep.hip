@@ -8,9 +8,9 @@
 //    once per chunk instead of three times (measured: the j+-1 re-reads were the most expensive
 //    neighbour loads, 17 % of the kernel).
 //  * One sweep per row.  Sums are formed about a shift c (the row's first element) instead of about
-//    the row mean: with a = T - cT, b = u - cU, c = v - cV, d = w - cW, e = Phi - cP, f = Q the 22
+//    the row mean: with a = T - cT, b = u - cU, c = v - cV, d = w - cW, e = Phi - cP, f = Q the 20
 //    weighted sums  <a> <b> <c> <d> <e> <f>  <aa> <bb> <cc> <ca> <da> <bc> <db> <dc> <de> <fa>
-//    <caa> <daa> <bbc> <ccc> <bbd> <ccd>  give every centred statistic exactly, e.g.
+//    <caa> <daa> <(bb+cc)c> <(bb+cc)d>  give every centred statistic exactly, e.g.
 //    [T'T'] = <aa> - <a>^2,  [vT'T'] = <caa> - 2<a><ca> + <a>^2<c> + cV [T'T'],
 //    [Kv] = 2[u][u'v'] + [u]^2[v] + 2[v][v'v'] + [v]^3   (K = u^2+v^2-u'^2-v'^2 = 2u[u]-[u]^2+2v[v]-[v]^2).
 //    The shift keeps the cancellation benign (|row mean - first element| is of the order of the eddy
@@ -31,7 +31,8 @@ using namespace lec;
 
 namespace {
 
-constexpr int kHalf = 11;   // statistics per reduction round (2 rounds x 11 = 22)
+constexpr int kNA = 20;     // shifted sums per row
+constexpr int kHalf = 10;   // statistics per reduction round (2 rounds x 10)
 
 template <typename TIN, int VEC, int ITERS, int MODE>
 constexpr int sweep_min_waves() {
@@ -42,8 +43,8 @@ constexpr int sweep_min_waves() {
 #endif
 }
 
-// the 22 shifted sums of one element (see the header comment)
-__device__ __forceinline__ void accum22(double (&acc)[22], double w, double a, double b, double c, double d, double ee, double f) {
+// the 20 shifted sums of one element (see the header comment)
+__device__ __forceinline__ void accum20(double (&acc)[kNA], double w, double a, double b, double c, double d, double ee, double f) {
     const double wa = w * a, wb = w * b, wc = w * c, wd = w * d;
     const double waa = wa * a, wbb = wb * b, wcc = wc * c;
     acc[0] += wa; acc[1] += wb; acc[2] += wc; acc[3] += wd;
@@ -58,26 +59,25 @@ __device__ __forceinline__ void accum22(double (&acc)[22], double w, double a, d
     acc[15] += wa * f;     // <fa>
     acc[16] += waa * c;    // <caa>
     acc[17] += waa * d;    // <daa>
-    acc[18] += wbb * c;    // <bbc>
-    acc[19] += wcc * c;    // <ccc>
-    acc[20] += wbb * d;    // <bbd>
-    acc[21] += wcc * d;    // <ccd>
+    const double wee = wbb + wcc;      // only the sums <bbc>+<ccc> and <bbd>+<ccd> are ever needed ([Ev], [Ew])
+    acc[18] += wee * c;    // <(bb+cc) c>
+    acc[19] += wee * d;    // <(bb+cc) d>
 }
 
-// block sums of the 22 accumulators (two rounds of 11 through the same LDS tile), then the centred
+// block sums of the accumulators (two rounds through the same LDS tile), then the centred
 // statistics from the shifted sums (lanes 0..21) written to the row record.  Ends with every read of
 // `red` / `tot` complete only after the caller's next barrier.
 template <int NTHR, int NR = kHalf>
-__device__ __forceinline__ void finish_row(const double (&acc)[22], double* red, double* tot, int tid, double inv_xlen,
+__device__ __forceinline__ void finish_row(const double (&acc)[kNA], double* red, double* tot, int tid, double inv_xlen,
                                            double cT, double cU, double cV, double cW, double cP, double* __restrict__ out) {
     constexpr int rshift = red_rshift(NTHR);
 #pragma unroll
-    for (int r0 = 0; r0 < 22; r0 += NR) {      // rounds of NR statistics through the same LDS tile
+    for (int r0 = 0; r0 < kNA; r0 += NR) {      // rounds of NR statistics through the same LDS tile
         double h[NR];
 #pragma unroll
-        for (int s = 0; s < NR; ++s) h[s] = (r0 + s < 22) ? acc[(r0 + s < 22) ? r0 + s : 0] : 0.0;
+        for (int s = 0; s < NR; ++s) h[s] = (r0 + s < kNA) ? acc[(r0 + s < kNA) ? r0 + s : 0] : 0.0;
         const double t0 = block_sums<NR, NTHR>(h, red, tid);
-        if ((tid & ((1 << rshift) - 1)) == 0 && (tid >> rshift) < NR && r0 + (tid >> rshift) < 22)
+        if ((tid & ((1 << rshift) - 1)) == 0 && (tid >> rshift) < NR && r0 + (tid >> rshift) < kNA)
             tot[r0 + (tid >> rshift)] = t0 * inv_xlen;
         __syncthreads();
     }
@@ -108,9 +108,9 @@ __device__ __forceinline__ void finish_row(const double (&acc)[22], double* red,
             case 17: o = tot[17] - 2 * da * tot[10] + da * da * dd + cW * sTT; break;    // [w T'T']
             case 18: o = 2 * mU * sUV + mU * mU * mV + 2 * mV * sVV + mV * mV * mV; break;   // [K v]
             case 19: o = 2 * mU * sWU + mU * mU * mW + 2 * mV * sWV + mV * mV * mW; break;   // [K w]
-            case 20: o = (tot[18] - 2 * db * tot[11] + db * db * dc) + (tot[19] - 2 * dc * tot[8] + dc * dc * dc)
+            case 20: o = tot[18] - 2 * db * tot[11] + db * db * dc - 2 * dc * tot[8] + dc * dc * dc
                          + cV * (sUU + sVV); break;                                           // [E v]
-            default: o = (tot[20] - 2 * db * tot[12] + db * db * dd) + (tot[21] - 2 * dc * tot[13] + dc * dc * dd)
+            default: o = tot[19] - 2 * db * tot[12] + db * db * dd - 2 * dc * tot[13] + dc * dc * dd
                          + cW * (sUU + sVV); break;                                           // [E w]
         }
         out[tid] = o;
@@ -196,13 +196,13 @@ __global__ void __launch_bounds__(NTHR, (sweep_min_waves<TIN, VEC, ITERS, MODE>(
     const double cT = (double)rT[0], cU = (double)rU[0], cV = (double)rV[0], cW = (double)rW[0];
     const double cP = has_p ? (double)rP[0] * phimul : 0.0;
 
-    double acc[22];
+    double acc[kNA];
 #pragma unroll
-    for (int s = 0; s < 22; ++s) acc[s] = 0.0;
+    for (int s = 0; s < kNA; ++s) acc[s] = 0.0;
     double ewT = 0, ewU = 0, ewV = 0, eeT = 0, eeU = 0, eeV = 0;
     bool has_w = false, has_e = false;
 
-    // a real loop (not unrolled): one vector of every row per trip keeps the live state at the 22
+    // a real loop (not unrolled): one vector of every row per trip keeps the live state at the 20
     // accumulators plus one vector's worth of operands, which is what lets 4 waves/SIMD fit
 #pragma unroll 1
     for (int it = 0; it < ITERS; ++it) {
@@ -262,7 +262,7 @@ __global__ void __launch_bounds__(NTHR, (sweep_min_waves<TIN, VEC, ITERS, MODE>(
                 f = kCp * (dTdt + Uv * dTl * inv_dx + Vv * dTphi - Wv * S);
                 f = inside ? f : 0.0;
             }
-            accum22(acc, w, Tv - cT, Uv - cU, Vv - cV, Wv - cW, Pv - cP, f);
+            accum20(acc, w, Tv - cT, Uv - cU, Vv - cV, Wv - cW, Pv - cP, f);
             ewT = first ? Tv : ewT; ewU = first ? Uv : ewU; ewV = first ? Vv : ewV; has_w = has_w || first;
             eeT = last ? Tv : eeT;  eeU = last ? Uv : eeU;  eeV = last ? Vv : eeV;  has_e = has_e || last;
         }
