@@ -138,7 +138,8 @@ struct RowParams {
     double* rows;
     int order;   // block -> row mapping: 0 memory order, 1 XCD-chunked latitudes with level fastest
     int jchunk;  // order >= 1: latitudes per XCD chunk
-    int tgroup;  // order 3: time steps per group
+    int tgroup;  // order 7: time steps per tile
+    int jgroup;  // order 7: latitudes per tile
     int jrows;   // sweep kernel: latitudes per workgroup
     int cpx;     // sweep kernel: latitude chunks per XCD
 };

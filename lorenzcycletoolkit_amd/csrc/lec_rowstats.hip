@@ -307,6 +307,8 @@ int launch_vec(const RowParams& p, bool uniform, int mode, int nblocks, hipStrea
 
 int lec_launch_rowsweep(lec::RowParams& p, int dtype, bool aligned, bool aligned8, bool uniform, int mode, int nblocks, hipStream_t st);
 
+static bool kernel_is_two_sweep() { const char* ek = getenv("LEC_KERNEL"); return ek && atoi(ek) == 0; }
+
 extern "C" int lec_max_row(int dtype, int aligned) {
     (void)dtype;                       // both storage types move two elements per lane and trip
     const int vec = aligned ? 2 : 1;
@@ -352,15 +354,27 @@ extern "C" int lec_rowstats(const lec_rowstats_args* a) {
     p.rows = a->rows_d;
     // defaults from the round-1 A/B on MI355X (profiles/r01_notes.md): XCD-chunked latitude-fastest order and
     // nontemporal loads for the once-read fields cut fabric reads by 36 % and time by 10-20 %
+    const int wq_mode = !a->with_q ? 0 : (a->dTdt_d ? 2 : 1);
     p.order = 2; p.jchunk = 0;
     long long nblocks = nrows;
     {   // experiment knobs (defaults chosen from measurements)
         const char* eo = getenv("LEC_ORDER");
-        if (eo) p.order = atoi(eo) ? 2 : 0;
-        p.tgroup = 1;
+        // all terms with dT/dt from the cube on a fixed box: tiled order (see lec_rowsweep.hip); else latitude-fastest
+        if (wq_mode == 1 && a->n_box == 1 && a->t_count >= 2 && !kernel_is_two_sweep()) p.order = 7;
+        if (eo) p.order = atoi(eo);
+        const char* etg = getenv("LEC_TG"); const char* ejg = getenv("LEC_JG");
+        const int ntile = (a->t_count + 7) / 8;                   // time tiles of (almost) equal size, at most 8 steps each
+        p.tgroup = etg ? atoi(etg) : (a->t_count + ntile - 1) / ntile; p.jgroup = ejg ? atoi(ejg) : 8;
+        if (p.tgroup < 1) p.tgroup = 1;
+        if (p.jgroup < 1) p.jgroup = 1;
+        if (p.order == 7 && (wq_mode != 1 || a->n_box != 1 || kernel_is_two_sweep())) p.order = 2;
         if (p.order) {
             p.jchunk = (a->nyb_max + 7) / 8;
             nblocks = (long long)a->t_count * 8 * p.jchunk * a->nl;
+            if (p.order == 7) {
+                const long long tgc = (a->t_count + p.tgroup - 1) / p.tgroup, jgc = (p.jchunk + p.jgroup - 1) / p.jgroup;
+                nblocks = 8LL * jgc * tgc * a->nl * p.tgroup * p.jgroup;
+            }
             if (nblocks > 0x7fffffffLL) { p.order = 0; nblocks = nrows; }
         }
     }
