@@ -43,6 +43,19 @@ constexpr int sweep_min_waves() {
 #endif
 }
 
+// value of the neighbouring lane of the wave (DPP wave shift: VALU only, no LDS, no memory); lanes at
+// the end of the wave keep `edge`
+__device__ __forceinline__ double from_prev_lane(double v, double edge) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(edge), __double2loint(v), 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), __double2hiint(v), 0x138, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double from_next_lane(double v, double edge) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(edge), __double2loint(v), 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), __double2hiint(v), 0x130, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
 // the 20 shifted sums of one element (see the header comment)
 __device__ __forceinline__ void accum20(double (&acc)[kNA], double w, double a, double b, double c, double d, double ee, double f) {
     const double wa = w * a, wb = w * b, wc = w * c, wd = w * d;
@@ -254,8 +267,19 @@ __global__ void __launch_bounds__(NTHR, (sweep_min_waves<TIN, VEC, ITERS, MODE>(
                 load_vec<TIN, VEC, true>(rTtm - shift, eo, tm);
                 if (MODE == 1) load_vec<TIN, VEC, true>(rTtp - shift, eo, tp);
             }
-            tl_edge = (double)rT[min(max(e0 - 1, 0), nxb - 1)];
-            tr_edge = (double)rT[min(max(e0 + VEC, 0), nxb - 1)];
+            // in-row neighbours T[i-1], T[i+1]: from the adjacent lanes' registers; only the first / last lane
+            // of a wave reads memory (consecutive lanes hold consecutive vectors)
+            // (fp64 storage only: with fp32 storage the extra live values tip the kernel into scratch)
+            if (sizeof(TIN) == 8) {
+                const int lane = tid & 63;
+                if (lane == 0) tl_edge = (double)rT[min(max(e0 - 1, 0), nxb - 1)];
+                if (lane == 63) tr_edge = (double)rT[min(max(e0 + VEC, 0), nxb - 1)];
+                tl_edge = from_prev_lane(fT[VEC - 1], tl_edge);
+                tr_edge = from_next_lane(fT[0], tr_edge);
+            } else {
+                tl_edge = (double)rT[min(max(e0 - 1, 0), nxb - 1)];
+                tr_edge = (double)rT[min(max(e0 + VEC, 0), nxb - 1)];
+            }
         }
 #pragma unroll
         for (int q = 0; q < VEC; ++q) {
