@@ -5,7 +5,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/pmc_$TAG; rm -rf $OUT
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 150 rocprofv3 --pmc $CTRS --output-format csv -d $OUT -- python3 $REPO/bench.py --timesteps 8 --steps 2 --warmup 1 --no-cpu-baseline "$@" > $OUT/bench.json 2> $OUT/err.log
+timeout -k 10 150 rocprofv3 --pmc $CTRS --output-format csv -d $OUT -- python3 $REPO/bench.py --timesteps 64 --steps 2 --warmup 1 --no-cpu-baseline "$@" > $OUT/bench.json 2> $OUT/err.log
 python3 - <<PY
 import csv, glob, collections
 rows = collections.defaultdict(list)
