@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define LEC_ABI_VERSION 1
+#define LEC_ABI_VERSION 2
 
 /* number of fp64 values per (time, level, lat) row record written by lec_rowstats */
 #define LEC_NSTAT 32
@@ -43,6 +43,7 @@ extern "C" {
 #define LEC_NLEVRAW 40
 /* per-time outputs of lec_reduce */
 #define LEC_NSCALAR 16 /* Az Ae Kz Ke Cz Ca Ck Ce BAz BAe BKz BKe BPhiZ BPhiE Gz Ge */
+#define LEC_NLEVFUN 28 /* functions of level that _handle_nans repairs (10 terms + 3 x 6 boundary pieces) */
 #define LEC_NLEVTAB 21 /* Az Ae Kz Ke Ge Gz Cz Cz_1 Cz_2 Ca Ca_1 Ca_2 Ce Ce_1 Ce_2 Ck Ck_1..Ck_5 */
 
 enum lec_dtype { LEC_F64 = 0, LEC_F32 = 1 };
@@ -116,6 +117,11 @@ typedef struct lec_reduce_args {
     const double* lattab2_d;    /* [n_box][nyb_max][8]  cos*wphi/ylen, wphi, cos, tan, d/dphi[rad] a,b,c, spare */
     const double* levtab2_d;    /* [nl][4]  p [Pa], d/dp a,b,c */
     double phi_scale;           /* multiplies the geopotential statistics (g when the file holds height) */
+    int32_t drop_any_time;      /* 1 (fixed framework): a level that is still NaN after the _handle_nans interpolation at ANY
+                                   processed time step is dropped from the pressure integrals of EVERY time step, as xarray's
+                                   dropna(dim=level) does on a [time, level] array (energy_contents.py:203-207); 0: per time step */
+    int32_t reserved0;
+    int32_t* dropmask_d;        /* workspace [LEC_NLEVFUN][nl] (needed when drop_any_time), zeroed by the call */
     double* am_d;               /* workspace [t_count][nl][8]  area means */
     double* levraw_d;           /* workspace [t_count][nl][LEC_NLEVRAW] */
     double* scalars_d;          /* out [t_count][LEC_NSCALAR] */

@@ -10,11 +10,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # LEC_LIB: alternative build of the same ABI (kernel experiments only)
 LIB_PATH = os.environ.get("LEC_LIB") or os.path.join(_HERE, "liblec_hip.so")
 
-LEC_ABI_VERSION = 1
+LEC_ABI_VERSION = 2
 LEC_NSTAT = 32
 LEC_NLEVRAW = 40
 LEC_NSCALAR = 16
 LEC_NLEVTAB = 21
+LEC_NLEVFUN = 28
 LEC_F64, LEC_F32 = 0, 1
 
 EXPORTS = ["lec_version", "lec_last_error", "lec_max_row", "lec_rowstats", "lec_reduce"]
@@ -42,6 +43,7 @@ class ReduceArgs(C.Structure):
         ("t_count", C.c_int32), ("nl", C.c_int32), ("n_box", C.c_int32), ("nyb_max", C.c_int32),
         ("box_d", C.c_void_p), ("boxtab2_d", C.c_void_p), ("lattab2_d", C.c_void_p), ("levtab2_d", C.c_void_p),
         ("phi_scale", C.c_double),
+        ("drop_any_time", C.c_int32), ("reserved0", C.c_int32), ("dropmask_d", C.c_void_p),
         ("am_d", C.c_void_p), ("levraw_d", C.c_void_p), ("scalars_d", C.c_void_p), ("levels_d", C.c_void_p),
         ("nanflag_d", C.c_void_p), ("stream", C.c_void_p),
     ]

@@ -39,6 +39,8 @@ struct RedParams {
     const double* lattab2;
     const double* levtab2;
     double phi_scale;
+    int drop_any_time;      // fixed framework: a level still NaN at ANY time step is dropped for every time step
+    int* dropmask;          // [F_COUNT][nl], filled by lec_dropmask_kernel
     double* am;
     double* levraw;
     double* scalars;
@@ -210,6 +212,64 @@ enum {
     F_B1 = 10, F_B2 = 16, F_B3 = 22, F_COUNT = 28
 };
 
+// Builds function `f` of level for time step `tl` into row[0..nl) and applies the interpolation half of
+// _handle_nans (energy_contents.py:190-208): linear in p across interior gaps, no extrapolation.
+// Returns the number of NaN levels found before the repair.
+__device__ int build_level_function(const RedParams& p, int tl, int f, double* row) {
+    const int nl = p.nl;
+    const double* raw = p.levraw + (size_t)tl * nl * LEC_NLEVRAW;
+    const double* lv = p.levtab2;
+    int nnan = 0;
+    for (int k = 0; k < nl; ++k) {
+        const double* o = raw + (size_t)k * LEC_NLEVRAW;
+        const double c1k = kRd / (lv[4 * k] * kG);   // Rd / (p g), conversion_terms.py:146,172
+        double x;
+        switch (f) {
+            case F_AZ: x = o[V_AZ]; break;
+            case F_AE: x = o[V_AE]; break;
+            case F_KZ: x = o[V_KZ]; break;
+            case F_KE: x = o[V_KE]; break;
+            case F_CZ: x = -(c1k * o[V_CZ2]); break;
+            case F_CA: x = -(o[V_CA1] + o[V_CA2]); break;
+            case F_CK: x = o[V_CK1] + o[V_CK2] + o[V_CK3] + o[V_CK4] + o[V_CK5]; break;
+            case F_CE: x = -(c1k * o[V_CE2]); break;
+            case F_GZ: x = o[V_GZ]; break;
+            case F_GE: x = o[V_GE]; break;
+            default: x = o[V_B1 + (f - F_B1)]; break;   // V_B1.. V_B3 are contiguous like F_B1..F_B3
+        }
+        row[k] = x;
+        nnan += isnan(x) ? 1 : 0;
+    }
+    if (nnan) {
+        int last_ok = -1;
+        for (int k = 0; k < nl; ++k) {
+            if (!isnan(row[k])) { last_ok = k; continue; }
+            int nxt = k + 1;
+            while (nxt < nl && isnan(row[nxt])) ++nxt;
+            if (last_ok >= 0 && nxt < nl) {
+                const double xl = lv[4 * last_ok], xr = lv[4 * nxt], yl = row[last_ok], yr = row[nxt];
+                const double slope = (yr - yl) / (xr - xl);
+                for (int q = k; q < nxt; ++q) row[q] = slope * (lv[4 * q] - xl) + yl;
+            }
+            k = nxt - 1;
+        }
+    }
+    return nnan;
+}
+
+// grid (t_count), block 64: marks the levels that are still NaN after the interpolation at this time step.
+// xarray's dropna(dim=level) on a [time, level] array drops such a level for EVERY time step.
+__global__ void __launch_bounds__(64) lec_dropmask_kernel(const RedParams p) {
+    __shared__ double fn[F_COUNT][kMaxNl];
+    const int tl = blockIdx.x, lane = threadIdx.x;
+    if (lane < F_COUNT) {
+        if (build_level_function(p, tl, lane, fn[lane])) {
+            for (int k = 0; k < p.nl; ++k)
+                if (isnan(fn[lane][k])) atomicOr(&p.dropmask[lane * p.nl + k], 1);
+        }
+    }
+}
+
 // grid (t_count), block 64
 __global__ void __launch_bounds__(64) lec_vertical_kernel(const RedParams p) {
     __shared__ double fn[F_COUNT][kMaxNl];
@@ -223,42 +283,16 @@ __global__ void __launch_bounds__(64) lec_vertical_kernel(const RedParams p) {
     int nnan = 0;
     if (lane < F_COUNT) {
         const int f = lane;
-        // build the function of level
-        for (int k = 0; k < nl; ++k) {
-            const double* o = raw + (size_t)k * LEC_NLEVRAW;
-            const double c1k = kRd / (lv[4 * k] * kG);   // Rd / (p g), conversion_terms.py:146,172
-            double x;
-            switch (f) {
-                case F_AZ: x = o[V_AZ]; break;
-                case F_AE: x = o[V_AE]; break;
-                case F_KZ: x = o[V_KZ]; break;
-                case F_KE: x = o[V_KE]; break;
-                case F_CZ: x = -(c1k * o[V_CZ2]); break;
-                case F_CA: x = -(o[V_CA1] + o[V_CA2]); break;
-                case F_CK: x = o[V_CK1] + o[V_CK2] + o[V_CK3] + o[V_CK4] + o[V_CK5]; break;
-                case F_CE: x = -(c1k * o[V_CE2]); break;
-                case F_GZ: x = o[V_GZ]; break;
-                case F_GE: x = o[V_GE]; break;
-                default: x = o[V_B1 + (f - F_B1)]; break;   // V_B1.. V_B3 are contiguous like F_B1..F_B3
-            }
-            fn[f][k] = x;
-            nnan += isnan(x) ? 1 : 0;
-        }
-        // _handle_nans: linear interpolation in p across interior gaps, remaining (leading/trailing) levels dropped
+        nnan = build_level_function(p, tl, f, fn[f]);
+        // the dropping half of _handle_nans: levels that are still NaN (here, or at any time step in the fixed framework)
         int k0 = 0, k1 = nl - 1;
+        if (p.drop_any_time) {
+            const int* dm = p.dropmask + f * nl;
+            bool any = false;
+            for (int k = 0; k < nl; ++k) if (dm[k]) { fn[f][k] = nan(""); any = true; }
+            if (any && !nnan) nnan = 1;
+        }
         if (nnan) {
-            int last_ok = -1;
-            for (int k = 0; k < nl; ++k) {
-                if (!isnan(fn[f][k])) { last_ok = k; continue; }
-                int nxt = k + 1;
-                while (nxt < nl && isnan(fn[f][nxt])) ++nxt;
-                if (last_ok >= 0 && nxt < nl) {
-                    const double xl = lv[4 * last_ok], xr = lv[4 * nxt], yl = fn[f][last_ok], yr = fn[f][nxt];
-                    const double slope = (yr - yl) / (xr - xl);
-                    for (int q = k; q < nxt; ++q) fn[f][q] = slope * (lv[4 * q] - xl) + yl;
-                }
-                k = nxt - 1;
-            }
             while (k0 < nl && isnan(fn[f][k0])) ++k0;
             while (k1 >= 0 && isnan(fn[f][k1])) --k1;
         }
@@ -335,15 +369,21 @@ extern "C" int lec_reduce(const lec_reduce_args* a) {
     if (a->nl > kMaxNl) return lec_set_error(LEC_ERR_UNSUPPORTED, "lec_reduce: more than 160 levels");
     if (a->t_count > 65535) return lec_set_error(LEC_ERR_UNSUPPORTED, "lec_reduce: more than 65535 time steps in one call");
     if (a->n_box != 1 && a->n_box != a->t_count) return lec_set_error(LEC_ERR_ARG, "lec_reduce: n_box must be 1 or t_count");
+    if (a->drop_any_time && !a->dropmask_d) return lec_set_error(LEC_ERR_ARG, "lec_reduce: drop_any_time needs dropmask_d");
     RedParams p;
     p.rows = a->rows_d; p.t_count = a->t_count; p.nl = a->nl; p.n_box = a->n_box; p.nyb_max = a->nyb_max;
     p.box = a->box_d; p.boxtab2 = a->boxtab2_d; p.lattab2 = a->lattab2_d; p.levtab2 = a->levtab2_d;
     p.phi_scale = a->phi_scale; p.am = a->am_d; p.levraw = a->levraw_d; p.scalars = a->scalars_d;
     p.levels = a->levels_d; p.nanflag = a->nanflag_d;
+    p.drop_any_time = (a->drop_any_time && a->dropmask_d) ? 1 : 0; p.dropmask = a->dropmask_d;
     hipStream_t st = (hipStream_t)a->stream;
     const dim3 grid2(a->nl, a->t_count);
     hipLaunchKernelGGL(lec_area_means_kernel, grid2, dim3(64), 0, st, p);
     hipLaunchKernelGGL(lec_level_terms_kernel, grid2, dim3(64), 0, st, p);
+    if (p.drop_any_time) {
+        if (hipMemsetAsync(p.dropmask, 0, sizeof(int) * F_COUNT * a->nl, st) != hipSuccess) return lec_set_error(LEC_ERR_LAUNCH, "lec_reduce: hipMemsetAsync failed");
+        hipLaunchKernelGGL(lec_dropmask_kernel, dim3(a->t_count), dim3(64), 0, st, p);
+    }
     hipLaunchKernelGGL(lec_vertical_kernel, dim3(a->t_count), dim3(64), 0, st, p);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return lec_set_error(LEC_ERR_LAUNCH, hipGetErrorString(e));

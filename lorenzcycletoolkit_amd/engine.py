@@ -94,12 +94,16 @@ class LECEngine:
                 geopt: Optional[torch.Tensor], boxes: Sequence[Sequence[int]], *,
                 time_s=None, dTdt: Optional[torch.Tensor] = None, t_begin: int = 0,
                 t_count: Optional[int] = None, with_q: bool = True, phi_scale: float = 1.0,
-                keep_rows: bool = False, timing: Optional[list] = None) -> LECResult:
+                keep_rows: bool = False, timing: Optional[list] = None,
+                drop_any_time: Optional[bool] = None) -> LECResult:
         """All LEC terms for time steps [t_begin, t_begin + t_count) of the cubes.
 
         ``boxes``: one (iw, ie, js, jn) quadruple (fixed framework) or one per processed time step
         (moving framework).  ``time_s`` (seconds, length nt) gives dT/dt by np.gradient over the
         cube's time axis unless a ``dTdt`` cube is supplied (moving framework).
+        ``drop_any_time``: _handle_nans' dropna semantics -- True drops a level that stays NaN at any processed
+        time step from every time step's integrals (what the fixed framework's [time, level] arrays do); default:
+        True for one fixed box, False for per-time-step boxes (the moving framework builds one BoxData per step).
         ``timing``: a list that receives one (start, end) pair of HIP events recorded on the launch
         stream around the stage-1 kernel (bench.py's roofline figure).
         """
@@ -142,6 +146,9 @@ class LECEngine:
         scalars = torch.empty((t_count, _lib.LEC_NSCALAR), **f64)
         levels = torch.empty((t_count, _lib.LEC_NLEVTAB, nl), **f64)
         nanflag = torch.empty((t_count,), dtype=torch.int32, device=tair.device)
+        if drop_any_time is None:
+            drop_any_time = len(boxes) == 1
+        dropmask = torch.empty((_lib.LEC_NLEVFUN, nl), dtype=torch.int32, device=tair.device) if drop_any_time else None
         stream = C.c_void_p(torch.cuda.current_stream(tair.device).cuda_stream)
 
         ra = _lib.RowstatsArgs(
@@ -164,6 +171,7 @@ class LECEngine:
                 rows_d=_ptr(rows), t_count=t_count, nl=nl, n_box=len(boxes), nyb_max=bt.nyb_max,
                 box_d=_ptr(dev["box"]), boxtab2_d=_ptr(dev["boxtab2"]), lattab2_d=_ptr(dev["lattab2"]),
                 levtab2_d=_ptr(self._levtab2), phi_scale=float(phi_scale),
+                drop_any_time=int(bool(drop_any_time)), reserved0=0, dropmask_d=_ptr(dropmask),
                 am_d=_ptr(am), levraw_d=_ptr(levraw), scalars_d=_ptr(scalars), levels_d=_ptr(levels),
                 nanflag_d=_ptr(nanflag), stream=stream)
             _lib.check(self.lib.lec_reduce(C.byref(rd)), "lec_reduce")

@@ -89,21 +89,26 @@ def select_nearest(coord: np.ndarray, value: float) -> int:
 
 
 def interpolate_and_drop_nan_levels(f: np.ndarray, p: np.ndarray):
-    """``_handle_nans`` (energy_contents.py:190-208 and its three copies) for a [time, level]
-    array: linear interpolation along level across interior gaps (no extrapolation), then
-    levels that still hold a NaN at any time are dropped.  Returns (f_clean, p_clean)."""
+    """``_handle_nans`` (energy_contents.py:190-208 and its three copies) for an array whose axis 1 is
+    level ([time, level] or [time, level, lat]): linear interpolation along level across interior gaps
+    (no extrapolation), then levels that still hold a NaN anywhere (any time, any latitude) are
+    dropped -- xarray's ``dropna(dim=level)``.  Returns (f_clean, p_clean)."""
     f = np.array(f, dtype=np.result_type(f.dtype, np.float32), copy=True)
     if not np.isnan(f).any():
         return f, p
-    for t in range(f.shape[0]):
-        row = f[t]
+    g = np.moveaxis(f, 1, -1)                    # view: level last
+    rows = g.reshape(-1, g.shape[-1])
+    for r in range(rows.shape[0]):
+        row = rows[r]
         ok = ~np.isnan(row)
         if ok.any() and not ok.all():
             filled = np.interp(p, p[ok], row[ok], left=np.nan, right=np.nan)
-            f[t] = np.where(ok, row, filled)
+            rows[r] = np.where(ok, row, filled)
+    g = rows.reshape(g.shape)
+    f = np.moveaxis(g, -1, 1)
     if np.isnan(f).any():
-        keep = ~np.isnan(f).any(axis=0)
-        f, p = f[:, keep], p[keep]
+        keep = ~np.isnan(g).reshape(-1, g.shape[-1]).any(axis=0)
+        f, p = np.compress(keep, f, axis=1), p[keep]
     return f, p
 
 
@@ -334,7 +339,9 @@ def boundary_terms(b: Box):
     t2 = ns(t2) / (2 * s)
     t2 = _int_p(t2, b.level) * c2
     t3 = za(2 * f["omega_ZE"] * f["tair_ZE"]) * f["tair_AE"] + f["omega_ZA"] * f["tair_AE"] ** 2
-    t3 = area_average(t3, b.rlats, b.coslats) / (2 * s)
+    t3, p3 = interpolate_and_drop_nan_levels(t3, b.level)                  # on [time, level, lat] (boundary_terms.py:169)
+    keep3 = np.isin(b.level, p3)
+    t3 = area_average(t3, b.rlats, b.coslats) / (2 * s[:, keep3])
     out["BAz"] = t1 + t2 - bt(t3)
 
     # BAe (boundary_terms.py:185-232)
@@ -346,6 +353,7 @@ def boundary_terms(b: Box):
     t2 = _int_p(t2, b.level) * c2
     t3 = (f["omega"] * f["tair_ZE"] ** 2) / (2 * s4)
     t3 = area_average(t3, b.rlats, b.coslats, b.xlength, b.rlons)
+    t3, _ = interpolate_and_drop_nan_levels(t3, b.level)
     out["BAe"] = t1 + t2 - bt(t3)
 
     # BKz / BKe (boundary_terms.py:234-326)
@@ -357,6 +365,7 @@ def boundary_terms(b: Box):
         t2 = ns(za(K * f["v"] * _c4(b.coslats)))
         t2 = _int_p(t2 / (2 * G), b.level) * c2
         t3 = area_average(K * f["omega"], b.rlats, b.coslats, b.xlength, b.rlons) / (2 * G)
+        t3, _ = interpolate_and_drop_nan_levels(t3, b.level)
         out[name] = t1 + t2 - bt(t3)
 
     # BΦZ (boundary_terms.py:328-366): no east-west difference in the first term
@@ -365,6 +374,7 @@ def boundary_terms(b: Box):
     t2 = ns((f["v_ZA"] * f["geopt_AE"]) * _c3(b.coslats) / G)
     t2 = _int_p(t2, b.level) * c2
     t3 = area_average(f["omega_AE"] * f["geopt_AE"], b.rlats, b.coslats) / G
+    t3, _ = interpolate_and_drop_nan_levels(t3, b.level)
     out["BΦZ"] = t1 + t2 - bt(t3)
 
     # BΦE (boundary_terms.py:368-418): second term built from zonal means (:390)
@@ -374,6 +384,7 @@ def boundary_terms(b: Box):
     t2 = ns((f["v_ZA"] * f["geopt_AE"]) * _c3(b.coslats) / G)
     t2 = _int_p(t2, b.level) * c2
     t3 = area_average(f["omega_ZE"] * f["geopt_ZE"], b.rlats, b.coslats, b.xlength, b.rlons) / G
+    t3, _ = interpolate_and_drop_nan_levels(t3, b.level)
     out["BΦE"] = t1 + t2 - bt(t3)
     return out
 

@@ -214,6 +214,31 @@ def test_nan_levels_are_repaired_like_handle_nans():
         assert scale_err(got[name], ref_s[name]) <= 1e-8, name
 
 
+def test_nan_at_top_level_drops_that_level_for_every_time_step():
+    """xarray's dropna(dim=level) works on the whole [time, level] array: a top level that is NaN at ONE time
+    step (nothing above it to interpolate from) leaves the pressure integrals of ALL time steps
+    (energy_contents.py:203-207).  The moving framework builds one BoxData per time step, so there only
+    that step loses the level."""
+    dom = synthetic_domain(4, 7, 10, 64, seed=12)
+    dom.v[2, 0, :, :] = np.nan                       # top level, one time step
+    limits = (dom.lon[1], dom.lon[-2], dom.lat[1], dom.lat[-2])
+    res = run_fixed(dom, limits)
+    ref_s, _ = o.lec_fixed(dom, *limits)
+    got = res.scalars_dict()
+    for name in ["Kz", "Ke", "Ck", "BKz", "BKe"]:
+        assert np.isfinite(got[name]).all(), name
+        assert scale_err(got[name], ref_s[name]) <= 1e-9, name
+    # per-time-step semantics (drop_any_time=False): the other time steps keep the level
+    eng = _engine(dom)
+    box = eng.box_from_limits(*limits)
+    per = eng.compute(_dev(dom.tair), _dev(dom.u), _dev(dom.v), _dev(dom.omega), _dev(dom.geopt), [box],
+                      time_s=dom.time_s, drop_any_time=False).scalars_dict()
+    clean = synthetic_domain(4, 7, 10, 64, seed=12)
+    ref_clean, _ = o.lec_fixed(clean, *limits)
+    assert scale_err(per["Kz"][[0, 1, 3]], np.asarray(ref_clean["Kz"])[[0, 1, 3]]) <= 1e-9
+    assert abs(per["Kz"][2] - ref_s["Kz"][2]) <= 1e-9 * abs(ref_s["Kz"][2])
+
+
 # ---------------------------------------------------------------------------------------------
 # argument checking mirrors the reference's error behaviour
 # ---------------------------------------------------------------------------------------------

@@ -94,9 +94,9 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_sizes_match_header_layout():
-    # 6 pointers + 12 int32 + 7 pointers + 2 pointers ; 1 pointer + 4 int32 + 4 pointers + double + 6 pointers
+    # 6 pointers + 12 int32 + 7 pointers + 2 pointers ; 1 pointer + 4 int32 + 4 pointers + double + 2 int32 + 7 pointers
     assert ctypes.sizeof(_lib.RowstatsArgs) == 6 * 8 + 12 * 4 + 9 * 8
-    assert ctypes.sizeof(_lib.ReduceArgs) == 8 + 4 * 4 + 4 * 8 + 8 + 6 * 8
+    assert ctypes.sizeof(_lib.ReduceArgs) == 8 + 4 * 4 + 4 * 8 + 8 + 2 * 4 + 8 + 6 * 8
 
 
 def test_argument_errors_without_gpu():
