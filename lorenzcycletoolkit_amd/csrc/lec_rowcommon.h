@@ -138,6 +138,7 @@ struct RowParams {
     double* rows;
     int order;   // block -> row mapping: 0 memory order, 1 XCD-chunked latitudes with level fastest
     int jchunk;  // order >= 1: latitudes per XCD chunk
+    int ntrips;  // single-sweep kernel: trips of 64 vectors that cover the longest row
     int tgroup;  // order 7: time steps per tile
     int jgroup;  // order 7: latitudes per tile
     int jrows;   // sweep kernel: latitudes per workgroup

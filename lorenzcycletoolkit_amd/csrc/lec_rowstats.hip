@@ -305,14 +305,16 @@ int launch_vec(const RowParams& p, bool uniform, int mode, int nblocks, hipStrea
 
 }  // namespace
 
-int lec_launch_rowsweep(lec::RowParams& p, int dtype, bool aligned, bool aligned8, bool uniform, int mode, int nblocks, hipStream_t st);
-
 static bool kernel_is_two_sweep() { const char* ek = getenv("LEC_KERNEL"); return ek && atoi(ek) == 0; }
 
+int lec_launch_rowsweep(lec::RowParams& p, int dtype, bool aligned, bool aligned8, bool uniform, int mode, int nblocks, hipStream_t st);
+
 extern "C" int lec_max_row(int dtype, int aligned) {
-    (void)dtype;                       // both storage types move two elements per lane and trip
-    const int vec = aligned ? 2 : 1;
-    return (256 * LEC_MAX_ITERS - (vec > 1 ? 1 : 0)) * vec;
+    (void)dtype;
+    // the default (single-sweep) kernel walks a row in trips of 64 vectors, so any row the cube can hold is fine;
+    // the two-sweep cross-check kernel (LEC_KERNEL=0) keeps a whole row in registers: 256 * LEC_MAX_ITERS vectors
+    if (kernel_is_two_sweep()) return (256 * LEC_MAX_ITERS - 1) * (aligned ? 2 : 1);
+    return 1 << 24;
 }
 
 extern "C" int lec_rowstats(const lec_rowstats_args* a) {
@@ -363,8 +365,9 @@ extern "C" int lec_rowstats(const lec_rowstats_args* a) {
         if (wq_mode == 1 && a->n_box == 1 && a->t_count >= 2 && !kernel_is_two_sweep()) p.order = 7;
         if (eo) p.order = atoi(eo);
         const char* etg = getenv("LEC_TG"); const char* ejg = getenv("LEC_JG");
-        const int ntile = (a->t_count + 7) / 8;                   // time tiles of (almost) equal size, at most 8 steps each
+        const int ntile = (a->t_count + 3) / 4;                   // time tiles of (almost) equal size, at most 4 steps each
         p.tgroup = etg ? atoi(etg) : (a->t_count + ntile - 1) / ntile; p.jgroup = ejg ? atoi(ejg) : 8;
+        if (p.jgroup > (a->nyb_max + 7) / 8) p.jgroup = (a->nyb_max + 7) / 8;    // never wider than an XCD's latitude chunk
         if (p.tgroup < 1) p.tgroup = 1;
         if (p.jgroup < 1) p.jgroup = 1;
         if (p.order == 7 && (wq_mode != 1 || a->n_box != 1 || kernel_is_two_sweep())) p.order = 2;

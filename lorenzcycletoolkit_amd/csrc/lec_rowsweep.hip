@@ -31,10 +31,11 @@ using namespace lec;
 
 namespace {
 
+constexpr int kThreads = 64; // one wave per row: measured best (64 / 128 / 256 threads: 19.0 / 19.1 / 20.1 ms per 64 steps)
 constexpr int kNA = 20;     // shifted sums per row
 constexpr int kHalf = 10;   // statistics per reduction round (2 rounds x 10)
 
-template <typename TIN, int VEC, int ITERS, int MODE>
+template <typename TIN, int VEC, int MODE>
 constexpr int sweep_min_waves() {
 #if LEC_MINW > 0
     return LEC_MINW;
@@ -132,8 +133,9 @@ __device__ __forceinline__ void finish_row(const double (&acc)[kNA], double* red
 }
 
 // one workgroup per (time, level, box-latitude) row, ONE sweep over the row (see the header comment)
-template <typename TIN, int VEC, int NTHR, int ITERS, bool UNIFORM, int MODE>
-__global__ void __launch_bounds__(NTHR, (sweep_min_waves<TIN, VEC, ITERS, MODE>())) lec_rowsweep_kernel(const RowParams p) {
+template <typename TIN, int VEC, bool UNIFORM, int MODE, bool ONE_TRIP>
+__global__ void __launch_bounds__(kThreads, (sweep_min_waves<TIN, VEC, MODE>())) lec_rowsweep_kernel(const RowParams p) {
+    constexpr int NTHR = kThreads;
     constexpr bool WITH_Q = MODE != 0;
     constexpr int nthr = NTHR;
     __shared__ double red[kHalf * red_stride(NTHR)];
@@ -149,7 +151,7 @@ __global__ void __launch_bounds__(NTHR, (sweep_min_waves<TIN, VEC, ITERS, MODE>(
     } else {
         // XCD label (speed only): every XCD owns a contiguous latitude chunk.  Order 2 walks it latitude-fastest
         // per (time, level).  Order 7 (all terms, fixed box) walks tiles of tgroup time steps x jgroup latitudes
-        // at one level, levels next: the ~128 workgroups resident on an XCD then cover a compact (t, k, j)
+        // at one level, levels next: the ~500 one-wave workgroups resident on an XCD then cover a compact (t, k, j)
         // neighbourhood, so T rows at t+-1 as well as j+-1 / k+-1 are rows a sibling is fetching right now
         // (measured: fabric traffic 1.39 -> 1.29 x algorithmic, -8 % time).
         const int xcd = blockIdx.x & 7;
@@ -237,8 +239,9 @@ __global__ void __launch_bounds__(NTHR, (sweep_min_waves<TIN, VEC, ITERS, MODE>(
 
     // a real loop (not unrolled): one vector of every row per trip keeps the live state at the 20
     // accumulators plus one vector's worth of operands, which is what lets 4 waves/SIMD fit
+    const int ntrips = ONE_TRIP ? 1 : p.ntrips;      // short rows (moving boxes): one trip, no loop
 #pragma unroll 1
-    for (int it = 0; it < ITERS; ++it) {
+    for (int it = 0; it < ntrips; ++it) {
         const int e0 = (it * nthr + tid) * VEC - shift;
         const bool lane_in = (e0 <= e0_last);
         const unsigned eo = (unsigned)(min(e0, e0_last) + shift);
@@ -317,41 +320,30 @@ __global__ void __launch_bounds__(NTHR, (sweep_min_waves<TIN, VEC, ITERS, MODE>(
         }
     }
 
-    finish_row<NTHR>(acc, red, tot, tid, inv_xlen, cT, cU, cV, cW, cP, out);
+    finish_row<NTHR, kHalf>(acc, red, tot, tid, inv_xlen, cT, cU, cV, cW, cP, out);
     if (has_w) { out[LEC_S_TW] = ewT; out[LEC_S_UW] = ewU; out[LEC_S_VW] = ewV; }
     if (has_e) { out[LEC_S_TE] = eeT; out[LEC_S_UE] = eeU; out[LEC_S_VE] = eeV; }
 }
 
-template <typename TIN, int VEC, int NTHR, int ITERS>
-void launch_cfg(const RowParams& p, bool uniform, int mode, int nblocks, hipStream_t st) {
-    dim3 grid(nblocks), block(NTHR);
-#define LEC_LAUNCH(U, M) hipLaunchKernelGGL((lec_rowsweep_kernel<TIN, VEC, NTHR, ITERS, U, M>), grid, block, 0, st, p)
+template <typename TIN, int VEC>
+int launch_vec(RowParams& p, bool uniform, int mode, int nblocks, hipStream_t st) {
+    // vectors needed to cover the longest row, plus one for the alignment shift; one wave walks them in trips of 64
+    const int nvec = (p.nxb_max + VEC - 1) / VEC + (VEC > 1 ? 1 : 0);
+    p.ntrips = (nvec + kThreads - 1) / kThreads;
+    dim3 grid(nblocks), block(kThreads);
+#define LEC_LAUNCH(U, M) do { if (p.ntrips == 1) hipLaunchKernelGGL((lec_rowsweep_kernel<TIN, VEC, U, M, true>), grid, block, 0, st, p); \
+                              else hipLaunchKernelGGL((lec_rowsweep_kernel<TIN, VEC, U, M, false>), grid, block, 0, st, p); } while (0)
     if (uniform) {
         if (mode == 0) LEC_LAUNCH(true, 0); else if (mode == 1) LEC_LAUNCH(true, 1); else LEC_LAUNCH(true, 2);
     } else {
         if (mode == 0) LEC_LAUNCH(false, 0); else if (mode == 1) LEC_LAUNCH(false, 1); else LEC_LAUNCH(false, 2);
     }
 #undef LEC_LAUNCH
-}
-
-template <typename TIN, int VEC>
-int launch_vec(const RowParams& p, bool uniform, int mode, int nblocks, hipStream_t st) {
-    const int nvec = (p.nxb_max + VEC - 1) / VEC + (VEC > 1 ? 1 : 0);
-    if (nvec <= 64) launch_cfg<TIN, VEC, 64, 1>(p, uniform, mode, nblocks, st);
-    else if (nvec <= 128) launch_cfg<TIN, VEC, 128, 1>(p, uniform, mode, nblocks, st);
-    else if (nvec <= 256) launch_cfg<TIN, VEC, 256, 1>(p, uniform, mode, nblocks, st);
-    else if (nvec <= 512) launch_cfg<TIN, VEC, 256, 2>(p, uniform, mode, nblocks, st);
-    else if (nvec <= 768) launch_cfg<TIN, VEC, 256, 3>(p, uniform, mode, nblocks, st);
-    else if (nvec <= 1024) launch_cfg<TIN, VEC, 256, 4>(p, uniform, mode, nblocks, st);
-    else if (nvec <= 1536) launch_cfg<TIN, VEC, 256, 6>(p, uniform, mode, nblocks, st);
-    else if (nvec <= 256 * LEC_MAX_ITERS) launch_cfg<TIN, VEC, 256, LEC_MAX_ITERS>(p, uniform, mode, nblocks, st);
-    else return LEC_ERR_UNSUPPORTED;
     return LEC_OK;
 }
 
 }  // namespace
 
-// Called by lec_rowstats() (lec_rowstats.hip) once the arguments are validated.
 // `aligned` = every cube base is 16-byte aligned and nx is a multiple of the 16-byte vector;
 // `aligned8` (fp32 only) = 8-byte aligned bases and even nx.  fp32 storage uses float2 vectors: the
 // same two elements per lane and trip as fp64, which is what keeps the kernel at 4 waves/SIMD

@@ -242,19 +242,18 @@ def test_nan_at_top_level_drops_that_level_for_every_time_step():
 # ---------------------------------------------------------------------------------------------
 # argument checking mirrors the reference's error behaviour
 # ---------------------------------------------------------------------------------------------
-def test_row_length_limit_is_reported():
-    """Rows longer than lec_max_row() are refused with LEC_ERR_UNSUPPORTED (no silent truncation)."""
+def test_long_rows_and_the_two_sweep_limit(monkeypatch):
+    """The default kernel walks a row in trips, so long rows just take more trips; the two-sweep cross-check
+    kernel holds the row in registers and refuses rows beyond lec_max_row() (no silent truncation)."""
     from lorenzcycletoolkit_amd import _lib
-    from lorenzcycletoolkit_amd.engine import LECEngine
-    lib = _lib.load()
-    nmax = lib.lec_max_row(_lib.LEC_F64, 1)
-    dom = synthetic_domain(2, 3, 4, nmax + 10, seed=1)
-    eng = LECEngine(dom.lat, dom.lon, dom.level, device="cuda:0")
-    T = _dev(dom.tair)
-    ok = eng.compute(T, T, T, T, T, [(0, nmax - 1, 0, 3)], time_s=dom.time_s)          # longest supported row
-    assert torch.isfinite(ok.scalars[:, :4]).all()
+    dom = synthetic_domain(2, 3, 4, 6000, seed=1)
+    limits = (dom.lon[1], dom.lon[-2], dom.lat[0], dom.lat[-1])
+    monkeypatch.setenv("LEC_KERNEL", "1")
+    check_fixed(dom, limits, what="6000-point rows")
+    monkeypatch.setenv("LEC_KERNEL", "0")
+    assert _lib.load().lec_max_row(_lib.LEC_F64, 1) < 5000
     with pytest.raises(_lib.LecLibraryError, match="longer than lec_max_row"):
-        eng.compute(T, T, T, T, T, [(0, nmax + 1, 0, 3)], time_s=dom.time_s)
+        run_fixed(dom, limits)
 
 
 def test_errors():
