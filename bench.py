@@ -42,11 +42,11 @@ def parse_args():
 
 def cpu_baseline():
     """The NumPy oracle (single thread, like the reference) on a bounded sample of the same workload:
-    3 time steps of a 181-row latitude band of the 37 x 721 x 1440 grid, scaled by 721/181."""
+    3 time steps of a 361-row latitude band of the 37 x 721 x 1440 grid, scaled by 721/361 (10-20 s of CPU work)."""
     from oracle import lec_oracle as o
     from lorenzcycletoolkit_amd.synthetic import era5_like_levels
     rng = np.random.default_rng(1234)
-    nt, ny, nx = 3, 181, 1440
+    nt, ny, nx = 3, 361, 1440
     level = era5_like_levels()
     lat = -45.0 + 0.25 * np.arange(ny)
     lon = np.linspace(-180.0, 179.75, nx)
