@@ -306,3 +306,32 @@ def test_full_size_band_and_properties(dtype):
     s3 = r3.scalars_dict()
     assert np.array_equal(s3["Kz"], 4 * s1["Kz"]) and np.array_equal(s3["Ke"], 4 * s1["Ke"])
     assert np.array_equal(s3["Az"], s1["Az"]) and np.array_equal(s3["Ae"], s1["Ae"])
+
+
+def test_full_size_zonally_symmetric_fields_have_no_eddy_energy():
+    """Fields that do not depend on longitude: every eddy statistic vanishes exactly (T - [T] == 0 point by
+    point), so Ae, Ke, Ca, Ce, Ck, Ge, BAe and BKe are exactly 0 on the whole 37 x 721 x 1440 grid while the
+    zonal terms are not."""
+    from lorenzcycletoolkit_amd.engine import LECEngine
+    from lorenzcycletoolkit_amd.synthetic import era5_grid, era5_like_levels
+    lat, lon = era5_grid()
+    level = era5_like_levels()
+    nt = 2
+    dev = torch.device("cuda:0")
+    p = torch.as_tensor(level, device=dev)[None, :, None, None]
+    phi = torch.deg2rad(torch.as_tensor(lat, device=dev))[None, None, :, None]
+    tt = torch.arange(nt, device=dev, dtype=torch.float64)[:, None, None, None]
+    shape = (nt, level.size, lat.size, lon.size)
+    mk = lambda a: a.expand(shape).contiguous()
+    T = mk(288.0 * (p / 1e5) ** 0.19 + 10.0 * torch.cos(2 * phi) * (p / 1e5) + 0.5 * tt)
+    u = mk(25.0 * torch.cos(phi) * (1 - p / 1.2e5) + 0 * tt)
+    v = mk(0.3 * torch.cos(phi) * torch.sin(3 * phi) + 0 * p + 0 * tt)
+    w = mk(0.02 * torch.sin(2 * phi) * (p / 1e5) + 0 * tt)
+    ph = mk(9.80665 * 7000.0 * torch.log(1e5 / p) + 50.0 * torch.cos(phi) + 0 * tt)
+    eng = LECEngine(lat, lon, level, device=dev)
+    box = eng.box_from_limits(-180, 179.75, -89.75, 89.75)
+    s = eng.compute(T, u, v, w, ph, [box], time_s=np.arange(nt) * 3600.0).scalars_dict()
+    for name in ["Ae", "Ke", "Ca", "Ce", "Ck", "Ge", "BAe", "BKe"]:
+        assert np.all(s[name] == 0.0), (name, s[name])
+    for name in ["Az", "Kz", "Cz", "Gz"]:
+        assert np.all(np.isfinite(s[name])) and np.all(s[name] != 0.0), name
