@@ -1,0 +1,186 @@
+// lec_sweep.h -- pieces shared by the single-sweep stage-1 kernels (lec_rowsweep.hip, lec_rowblock.hip):
+// the 20 shifted sums of one element, the in-wave neighbour shifts and the row epilogue.
+#ifndef LEC_SWEEP_H
+#define LEC_SWEEP_H
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/lec_hip.h"
+#include "lec_internal.h"
+#include "lec_rowcommon.h"
+
+namespace lec {
+
+constexpr int kNA = 20;     // shifted sums per row
+constexpr int kHalf = 10;   // statistics per reduction round (2 rounds x 10)
+
+template <typename TIN, int VEC, int MODE>
+constexpr int sweep_min_waves() {
+#if LEC_MINW > 0
+    return LEC_MINW;
+#else
+    return (sizeof(TIN) == 4 && MODE != 0 && VEC == 4) ? LEC_MINW_SINGLE - 1 : LEC_MINW_SINGLE;
+#endif
+}
+
+// value of the neighbouring lane of the wave (DPP wave shift: VALU only, no LDS, no memory); lanes at
+// the end of the wave keep `edge`
+__device__ __forceinline__ double from_prev_lane(double v, double edge) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(edge), __double2loint(v), 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), __double2hiint(v), 0x138, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double from_next_lane(double v, double edge) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(edge), __double2loint(v), 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), __double2hiint(v), 0x130, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
+// The element arithmetic below is shared by two kernels whose results must be bit-identical (shard
+// invariance and kernel choice are tested bit-exact), so nothing is left to the compiler's contraction
+// heuristics: contraction is off and every fused multiply-add is written out.
+
+// c0 x0 + c1 x1 + cm xm with the two outer products rounded before their (commutative) add: the result
+// does not depend on which neighbour is called x0 -- the row-block kernel swaps sides per wave
+__device__ __forceinline__ double stencil3(double c0, double x0, double c1, double x1, double cm, double xm) {
+#pragma clang fp contract(off)
+    const double p0 = c0 * x0, p1 = c1 * x1;
+    return fma(cm, xm, p0 + p1);
+}
+
+// the 20 shifted sums of one element (see lec_rowsweep.hip); UNIT: weight 1 (no multiplies by w)
+template <bool UNIT>
+__device__ __forceinline__ void accum20(double (&acc)[kNA], double w, double a, double b, double c, double d, double ee, double f) {
+#pragma clang fp contract(off)
+    const double wa = UNIT ? a : w * a, wb = UNIT ? b : w * b, wc = UNIT ? c : w * c, wd = UNIT ? d : w * d;
+    const double waa = wa * a, wbb = wb * b, wcc = wc * c;
+    acc[0] += wa; acc[1] += wb; acc[2] += wc; acc[3] += wd;
+    if (UNIT) { acc[4] += ee; acc[5] += f; } else { acc[4] = fma(w, ee, acc[4]); acc[5] = fma(w, f, acc[5]); }
+    acc[6] += waa; acc[7] += wbb; acc[8] += wcc;
+    acc[9] = fma(wc, a, acc[9]);       // <ca>
+    acc[10] = fma(wd, a, acc[10]);     // <da>
+    acc[11] = fma(wb, c, acc[11]);     // <bc>
+    acc[12] = fma(wd, b, acc[12]);     // <db>
+    acc[13] = fma(wd, c, acc[13]);     // <dc>
+    acc[14] = fma(wd, ee, acc[14]);    // <de>
+    acc[15] = fma(wa, f, acc[15]);     // <fa>
+    acc[16] = fma(waa, c, acc[16]);    // <caa>
+    acc[17] = fma(waa, d, acc[17]);    // <daa>
+    const double wee = wbb + wcc;      // only the sums <bbc>+<ccc> and <bbd>+<ccd> are ever needed ([Ev], [Ew])
+    acc[18] = fma(wee, c, acc[18]);    // <(bb+cc) c>
+    acc[19] = fma(wee, d, acc[19]);    // <(bb+cc) d>
+}
+
+// wave-uniform constants of one row sweep
+struct SweepRow {
+    int nxb;                        // box points in the row
+    double cT, cU, cV, cW, cP;      // shifts: the row's first box element
+    double cx;                      // uniform longitudes: 0.5 / h_deg / dx_j  (centred d/dlon -> d/dx)
+    double inv_dx;                  // table longitudes: 1 / dx_j
+    const double* wl;               // table longitudes: trapezoid weights
+    const double* gl;               // table longitudes: d/dlon coefficients
+};
+
+// One vector (VEC consecutive longitudes starting at box element e0) of every operand -> the 20 sums.
+//   EDGE = false: every element of the trip lies strictly inside the row (1 <= e <= nxb - 2): no selects,
+//                 and with uniform longitudes the weight is the constant 1 (the row epilogue multiplies by h).
+//   EDGE = true : the first / last trips: half weights at the row ends, lanes outside the row contribute 0.
+// With uniform longitudes the sums carry RELATIVE trapezoid weights (1, 1/2, 0); Q is accumulated without
+// the factor cp (applied in the epilogue).  sT, sP, sS: dT/dt, dT/dy and the static-stability stencil.
+template <int VEC, bool UNIFORM, bool EDGE, bool WITH_Q>
+__device__ __forceinline__ void sweep_elems(double (&acc)[kNA], const SweepRow& r, int e0, bool lane_in,
+                                            const double (&fT)[VEC], const double (&fU)[VEC], const double (&fV)[VEC],
+                                            const double (&fW)[VEC], const double (&fP)[VEC], double tl_edge, double tr_edge,
+                                            const double (&sT)[VEC], const double (&sP)[VEC], const double (&sS)[VEC]) {
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) {
+        const int e = e0 + q;
+        const bool inside = !EDGE || ((e >= 0) && (e < r.nxb) && lane_in);
+        const bool first = EDGE && inside && (e == 0), last = EDGE && inside && (e == r.nxb - 1);
+        double w = 1.0;
+        if (UNIFORM) { if (EDGE) w = inside ? ((first || last) ? 0.5 : 1.0) : 0.0; }
+        else w = EDGE ? (inside ? r.wl[min(max(e, 0), r.nxb - 1)] : 0.0) : r.wl[e];
+        const double Tv = inside ? fT[q] : r.cT;
+        const double Uv = inside ? fU[q] : r.cU;
+        const double Vv = inside ? fV[q] : r.cV;
+        const double Wv = inside ? fW[q] : r.cW;
+        const double Pv = inside ? fP[q] : r.cP;
+        double f = 0.0;
+        if (WITH_Q) {
+            const double Tl = (q == 0) ? tl_edge : fT[q > 0 ? q - 1 : 0];
+            const double Tr = (q == VEC - 1) ? tr_edge : fT[q < VEC - 1 ? q + 1 : q];
+            double adv;                                     // u dT/dx
+            if (UNIFORM) {
+                double d = Tr - Tl;
+                if (EDGE) d = first ? 2.0 * (Tr - Tv) : (last ? 2.0 * (Tv - Tl) : d);      // one-sided at the row ends
+                adv = (Uv * r.cx) * d;
+            } else {
+                const int ec = EDGE ? min(max(e, 0), r.nxb - 1) : e;
+                adv = Uv * fma(r.gl[3 * ec + 2], Tr, fma(r.gl[3 * ec + 1], Tv, r.gl[3 * ec + 0] * Tl)) * r.inv_dx;
+            }
+            f = fma(-Wv, sS[q], fma(Vv, sP[q], sT[q] + adv));
+            if (EDGE) f = inside ? f : 0.0;
+        }
+        accum20<UNIFORM && !EDGE>(acc, w, Tv - r.cT, Uv - r.cU, Vv - r.cV, Wv - r.cW, Pv - r.cP, f);
+    }
+}
+
+// block sums of the accumulators (two rounds through the same LDS tile), scaled by `scale` (1 / xlength,
+// times the longitude step when the sums carry relative weights), then the centred
+// statistics from the shifted sums (lanes 0..21) written to the row record.  Ends with every read of
+// `red` / `tot` complete only after the caller's next barrier.
+template <int NTHR, int NR = kHalf>
+__device__ __forceinline__ void finish_row(const double (&acc)[kNA], double* red, double* tot, int tid, double scale,
+                                           double cT, double cU, double cV, double cW, double cP, double* __restrict__ out,
+                                           bool store = true) {
+    constexpr int rshift = red_rshift(NTHR);
+#pragma unroll
+    for (int r0 = 0; r0 < kNA; r0 += NR) {      // rounds of NR statistics through the same LDS tile
+        double h[NR];
+#pragma unroll
+        for (int s = 0; s < NR; ++s) h[s] = (r0 + s < kNA) ? acc[(r0 + s < kNA) ? r0 + s : 0] : 0.0;
+        const double t0 = block_sums<NR, NTHR>(h, red, tid);
+        if ((tid & ((1 << rshift) - 1)) == 0 && (tid >> rshift) < NR && r0 + (tid >> rshift) < kNA)
+            tot[r0 + (tid >> rshift)] = t0 * ((r0 + (tid >> rshift) == 5 || r0 + (tid >> rshift) == 15) ? scale * kCp : scale);   // <f>, <fa>: Q = cp f
+        __syncthreads();
+    }
+    if (tid < 22) {
+        const double da = tot[0], db = tot[1], dc = tot[2], dd = tot[3], de = tot[4], df = tot[5];
+        const double mT = cT + da, mU = cU + db, mV = cV + dc, mW = cW + dd;
+        const double sTT = tot[6] - da * da, sUU = tot[7] - db * db, sVV = tot[8] - dc * dc;
+        const double sUV = tot[11] - db * dc, sWU = tot[12] - dd * db, sWV = tot[13] - dd * dc;
+        double o;
+        switch (tid) {
+            case 0: o = mT; break;
+            case 1: o = mU; break;
+            case 2: o = mV; break;
+            case 3: o = mW; break;
+            case 4: o = cP + de; break;
+            case 5: o = df; break;
+            case 6: o = sTT; break;
+            case 7: o = sUU; break;
+            case 8: o = sVV; break;
+            case 9: o = tot[9] - dc * da; break;                       // [v'T']
+            case 10: o = tot[10] - dd * da; break;                     // [w'T']
+            case 11: o = sUV; break;
+            case 12: o = sWU; break;
+            case 13: o = sWV; break;
+            case 14: o = tot[14] - dd * de; break;                     // [w'Phi']
+            case 15: o = tot[15] - df * da; break;                     // [Q'T']
+            case 16: o = tot[16] - 2 * da * tot[9] + da * da * dc + cV * sTT; break;     // [v T'T']
+            case 17: o = tot[17] - 2 * da * tot[10] + da * da * dd + cW * sTT; break;    // [w T'T']
+            case 18: o = 2 * mU * sUV + mU * mU * mV + 2 * mV * sVV + mV * mV * mV; break;   // [K v]
+            case 19: o = 2 * mU * sWU + mU * mU * mW + 2 * mV * sWV + mV * mV * mW; break;   // [K w]
+            case 20: o = tot[18] - 2 * db * tot[11] + db * db * dc - 2 * dc * tot[8] + dc * dc * dc
+                         + cV * (sUU + sVV); break;                                           // [E v]
+            default: o = tot[19] - 2 * db * tot[12] + db * db * dd - 2 * dc * tot[13] + dc * dc * dd
+                         + cW * (sUU + sVV); break;                                           // [E w]
+        }
+        if (store) out[tid] = o;
+    }
+    if (store && tid < 4) out[LEC_S_SPARE + tid] = 0.0;
+}
+
+}  // namespace lec
+#endif

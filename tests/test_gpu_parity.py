@@ -162,6 +162,23 @@ def test_two_kernel_formulations_agree(monkeypatch, dtype):
     assert torch.allclose(a.scalars, b.scalars, rtol=1e-10, atol=0)
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("blk", ["212", "222", "122", "211", "121", "112"])
+def test_row_block_kernel_is_bit_identical_to_one_wave_per_row(monkeypatch, dtype, blk):
+    """The row-block kernel (default for all terms on a fixed box: block mates exchange T through LDS) must give
+    the very same row records as the one-wave-per-row kernel; odd extents exercise partial blocks, the shard
+    exercises halo time steps on both sides."""
+    dom = synthetic_domain(7, 5, 13, 600, seed=21, dtype=dtype)
+    limits = (dom.lon[3], dom.lon[-4], dom.lat[1], dom.lat[-2])
+    for kw in ({}, {"t_begin": 1, "t_count": 5}):
+        monkeypatch.setenv("LEC_BLK", "0")
+        a = run_fixed(dom, limits, keep_rows=True, **kw)
+        monkeypatch.setenv("LEC_BLK", blk)
+        b = run_fixed(dom, limits, keep_rows=True, **kw)
+        assert torch.equal(a.rows, b.rows), f"rows differ for block shape {blk} {kw}"
+        assert torch.equal(a.scalars, b.scalars)
+
+
 def test_time_shard_invariance():
     """Processing [t0, t1) of a cube gives bit-identical results to processing the whole cube."""
     dom = synthetic_domain(6, 5, 10, 128, seed=3)
