@@ -13,6 +13,12 @@
  *                 ConversionTerms.calc_*       src/analysis/conversion_terms.py:103-245
  *                 BoundaryTerms.calc_*         src/analysis/boundary_terms.py:125-418
  *                 GenerationDissipationTerms   src/analysis/generation_and_dissipation_terms.py:122-152
+ *   lec_ingest    replaces, for data that is already in device memory as raw file bytes, the decode of
+ *                 xr.open_dataset (CF scale_factor / add_offset / _FillValue; get_data,
+ *                 src/utils/preprocessing.py:35-146), the longitude wrap + sorts + >= 10 hPa filter of
+ *                 process_data (preprocessing.py:275-365), the crop of slice_domain
+ *                 (src/utils/select_area.py:254-338) and the unit conversion of BoxData._extract_data
+ *                 (box_data.py:297-310): one gather pass instead of four host copies.
  *   lec_reduce    replaces the (level x lat) math of the same calc_* methods: CalcAreaAverage
  *                 (calc_averages.py:46-78), StaticStability (thermodynamics.py:26-73), the
  *                 differentiate("rlats"/level) calls, _handle_nans (energy_contents.py:190-208),
@@ -35,7 +41,7 @@
 extern "C" {
 #endif
 
-#define LEC_ABI_VERSION 2
+#define LEC_ABI_VERSION 3
 
 /* number of fp64 values per (time, level, lat) row record written by lec_rowstats */
 #define LEC_NSTAT 32
@@ -46,7 +52,7 @@ extern "C" {
 #define LEC_NLEVFUN 28 /* functions of level that _handle_nans repairs (10 terms + 3 x 6 boundary pieces) */
 #define LEC_NLEVTAB 21 /* Az Ae Kz Ke Ge Gz Cz Cz_1 Cz_2 Ca Ca_1 Ca_2 Ce Ce_1 Ce_2 Ck Ck_1..Ck_5 */
 
-enum lec_dtype { LEC_F64 = 0, LEC_F32 = 1 };
+enum lec_dtype { LEC_F64 = 0, LEC_F32 = 1, LEC_I16 = 2 /* lec_ingest source only */ };
 
 enum lec_status {
     LEC_OK = 0,
@@ -117,11 +123,15 @@ typedef struct lec_reduce_args {
     const double* lattab2_d;    /* [n_box][nyb_max][8]  cos*wphi/ylen, wphi, cos, tan, d/dphi[rad] a,b,c, spare */
     const double* levtab2_d;    /* [nl][4]  p [Pa], d/dp a,b,c */
     double phi_scale;           /* multiplies the geopotential statistics (g when the file holds height) */
-    int32_t drop_any_time;      /* 1 (fixed framework): a level that is still NaN after the _handle_nans interpolation at ANY
-                                   processed time step is dropped from the pressure integrals of EVERY time step, as xarray's
-                                   dropna(dim=level) does on a [time, level] array (energy_contents.py:203-207); 0: per time step */
+    int32_t drop_any_time;      /* _handle_nans' dropna(dim=level) on a [time, level] array (energy_contents.py:203-207), fixed framework:
+                                   a level that is still NaN after the interpolation at ANY time step is dropped from the pressure
+                                   integrals of EVERY time step.
+                                   0: per time step (moving framework: one BoxData per step);
+                                   1: any-time over the time steps of this call (mask computed by the call);
+                                   2: any-time with the mask in dropmask_d taken as given: the caller ran lec_dropmask on every
+                                      shard / chunk of the series and merged the masks (element-wise max) */
     int32_t reserved0;
-    int32_t* dropmask_d;        /* workspace [LEC_NLEVFUN][nl] (needed when drop_any_time), zeroed by the call */
+    int32_t* dropmask_d;        /* [LEC_NLEVFUN][nl] (needed when drop_any_time): workspace zeroed by the call (mode 1), input (mode 2) */
     double* am_d;               /* workspace [t_count][nl][8]  area means */
     double* levraw_d;           /* workspace [t_count][nl][LEC_NLEVRAW] */
     double* scalars_d;          /* out [t_count][LEC_NSCALAR] */
@@ -130,6 +140,35 @@ typedef struct lec_reduce_args {
     void* stream;
 } lec_reduce_args;
 
+/*
+ * Ingest: raw source cube [nt][nl_in][ny_in][nx_in] (file order, file byte order, possibly CF-packed) ->
+ * field cube [nt][nl][ny][nx] in the order lec_rowstats wants (level ascending in Pa, lat S->N, lon W->E),
+ * cropped to the analysis domain, in SI units.
+ *
+ *   value = decode(src[t][kmap[k]][jmap[j]][imap[i]])            source element, byte-swapped if asked
+ *   packed (has_packing):  v = (double)value * scale_factor + add_offset   (product rounded, then the sum: what
+ *                          the reference's xarray decode does on float64 data), arithmetic in fp64
+ *   not packed:            v = value, arithmetic in the source's own precision (the reference keeps file dtype)
+ *   fill:                  value == fill_value (compared before scaling) -> NaN
+ *   out = v * unit_scale   rounded to out_dtype
+ */
+typedef struct lec_ingest_args {
+    const void* src_d;          /* device copy of the raw variable bytes for nt time steps */
+    int32_t src_dtype;          /* LEC_I16, LEC_F32 or LEC_F64 */
+    int32_t swap_bytes;         /* 1: source is in the opposite byte order (classic NetCDF is big-endian) */
+    int32_t nt, nl_in, ny_in, nx_in;
+    int32_t nl, ny, nx;         /* output extents */
+    const int32_t* kmap_d;      /* [nl] output level -> source level */
+    const int32_t* jmap_d;      /* [ny] output latitude -> source latitude */
+    const int32_t* imap_d;      /* [nx] output longitude -> source longitude */
+    int32_t has_packing, has_fill;
+    double scale_factor, add_offset, fill_value, unit_scale;
+    int32_t out_dtype;          /* LEC_F64 or LEC_F32 */
+    int32_t reserved0;
+    void* out_d;                /* [nt][nl][ny][nx] */
+    void* stream;
+} lec_ingest_args;
+
 int lec_version(void);
 const char* lec_last_error(void);
 
@@ -137,7 +176,13 @@ const char* lec_last_error(void);
 int lec_max_row(int dtype, int aligned);
 
 int lec_rowstats(const lec_rowstats_args* args);
+int lec_ingest(const lec_ingest_args* args);
 int lec_reduce(const lec_reduce_args* args);
+
+/* The any-time NaN-level mask of the time steps in `args` alone -> dropmask_d (zeroed first; non-zero = drop).
+ * Uses am_d / levraw_d as workspace; scalars_d, levels_d, nanflag_d are not touched and may be NULL.
+ * For series processed in shards or chunks: merge the masks, then call lec_reduce with drop_any_time = 2. */
+int lec_dropmask(const lec_reduce_args* args);
 
 #ifdef __cplusplus
 }

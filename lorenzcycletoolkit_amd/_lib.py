@@ -10,15 +10,15 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # LEC_LIB: alternative build of the same ABI (kernel experiments only)
 LIB_PATH = os.environ.get("LEC_LIB") or os.path.join(_HERE, "liblec_hip.so")
 
-LEC_ABI_VERSION = 2
+LEC_ABI_VERSION = 3
 LEC_NSTAT = 32
 LEC_NLEVRAW = 40
 LEC_NSCALAR = 16
 LEC_NLEVTAB = 21
 LEC_NLEVFUN = 28
-LEC_F64, LEC_F32 = 0, 1
+LEC_F64, LEC_F32, LEC_I16 = 0, 1, 2
 
-EXPORTS = ["lec_version", "lec_last_error", "lec_max_row", "lec_rowstats", "lec_reduce"]
+EXPORTS = ["lec_version", "lec_last_error", "lec_max_row", "lec_rowstats", "lec_reduce", "lec_dropmask", "lec_ingest"]
 
 
 class RowstatsArgs(C.Structure):
@@ -49,6 +49,20 @@ class ReduceArgs(C.Structure):
     ]
 
 
+class IngestArgs(C.Structure):
+    """struct lec_ingest_args (include/lec_hip.h)."""
+    _fields_ = [
+        ("src_d", C.c_void_p), ("src_dtype", C.c_int32), ("swap_bytes", C.c_int32),
+        ("nt", C.c_int32), ("nl_in", C.c_int32), ("ny_in", C.c_int32), ("nx_in", C.c_int32),
+        ("nl", C.c_int32), ("ny", C.c_int32), ("nx", C.c_int32),
+        ("kmap_d", C.c_void_p), ("jmap_d", C.c_void_p), ("imap_d", C.c_void_p),
+        ("has_packing", C.c_int32), ("has_fill", C.c_int32),
+        ("scale_factor", C.c_double), ("add_offset", C.c_double), ("fill_value", C.c_double), ("unit_scale", C.c_double),
+        ("out_dtype", C.c_int32), ("reserved0", C.c_int32),
+        ("out_d", C.c_void_p), ("stream", C.c_void_p),
+    ]
+
+
 class LecLibraryError(RuntimeError):
     pass
 
@@ -74,6 +88,10 @@ def load():
     lib.lec_rowstats.argtypes = [C.POINTER(RowstatsArgs)]
     lib.lec_reduce.restype = C.c_int
     lib.lec_reduce.argtypes = [C.POINTER(ReduceArgs)]
+    lib.lec_dropmask.restype = C.c_int
+    lib.lec_dropmask.argtypes = [C.POINTER(ReduceArgs)]
+    lib.lec_ingest.restype = C.c_int
+    lib.lec_ingest.argtypes = [C.POINTER(IngestArgs)]
     if lib.lec_version() != LEC_ABI_VERSION:
         raise LecLibraryError(f"liblec_hip.so ABI {lib.lec_version()} != expected {LEC_ABI_VERSION}")
     _lib = lib

@@ -360,32 +360,37 @@ __global__ void __launch_bounds__(64) lec_vertical_kernel(const RedParams p) {
 
 }  // namespace
 
-extern "C" int lec_reduce(const lec_reduce_args* a) {
+static int reduce_impl(const lec_reduce_args* a, bool mask_only, const char* who) {
     if (!a) return lec_set_error(LEC_ERR_ARG, "lec_reduce: null args");
-    if (!a->rows_d || !a->box_d || !a->boxtab2_d || !a->lattab2_d || !a->levtab2_d || !a->am_d || !a->levraw_d ||
-        !a->scalars_d || !a->levels_d || !a->nanflag_d)
-        return lec_set_error(LEC_ERR_ARG, "lec_reduce: null pointer argument");
+    if (!a->rows_d || !a->box_d || !a->boxtab2_d || !a->lattab2_d || !a->levtab2_d || !a->am_d || !a->levraw_d)
+        return lec_set_error(LEC_ERR_ARG, "lec_reduce / lec_dropmask: null pointer argument");
+    if (!mask_only && (!a->scalars_d || !a->levels_d || !a->nanflag_d)) return lec_set_error(LEC_ERR_ARG, "lec_reduce: null output pointer");
     if (a->t_count < 1 || a->nl < 2 || a->nyb_max < 2) return lec_set_error(LEC_ERR_ARG, "lec_reduce: needs t_count>=1, nl>=2, nyb_max>=2");
     if (a->nl > kMaxNl) return lec_set_error(LEC_ERR_UNSUPPORTED, "lec_reduce: more than 160 levels");
     if (a->t_count > 65535) return lec_set_error(LEC_ERR_UNSUPPORTED, "lec_reduce: more than 65535 time steps in one call");
     if (a->n_box != 1 && a->n_box != a->t_count) return lec_set_error(LEC_ERR_ARG, "lec_reduce: n_box must be 1 or t_count");
-    if (a->drop_any_time && !a->dropmask_d) return lec_set_error(LEC_ERR_ARG, "lec_reduce: drop_any_time needs dropmask_d");
+    if (a->drop_any_time < 0 || a->drop_any_time > 2) return lec_set_error(LEC_ERR_ARG, "lec_reduce: drop_any_time must be 0, 1 or 2");
+    if ((a->drop_any_time || mask_only) && !a->dropmask_d) return lec_set_error(LEC_ERR_ARG, "lec_reduce / lec_dropmask: drop_any_time needs dropmask_d");
+    (void)who;
     RedParams p;
     p.rows = a->rows_d; p.t_count = a->t_count; p.nl = a->nl; p.n_box = a->n_box; p.nyb_max = a->nyb_max;
     p.box = a->box_d; p.boxtab2 = a->boxtab2_d; p.lattab2 = a->lattab2_d; p.levtab2 = a->levtab2_d;
     p.phi_scale = a->phi_scale; p.am = a->am_d; p.levraw = a->levraw_d; p.scalars = a->scalars_d;
     p.levels = a->levels_d; p.nanflag = a->nanflag_d;
-    p.drop_any_time = (a->drop_any_time && a->dropmask_d) ? 1 : 0; p.dropmask = a->dropmask_d;
+    p.drop_any_time = (a->drop_any_time || mask_only) ? 1 : 0; p.dropmask = a->dropmask_d;
     hipStream_t st = (hipStream_t)a->stream;
     const dim3 grid2(a->nl, a->t_count);
     hipLaunchKernelGGL(lec_area_means_kernel, grid2, dim3(64), 0, st, p);
     hipLaunchKernelGGL(lec_level_terms_kernel, grid2, dim3(64), 0, st, p);
-    if (p.drop_any_time) {
+    if (mask_only || a->drop_any_time == 1) {
         if (hipMemsetAsync(p.dropmask, 0, sizeof(int) * F_COUNT * a->nl, st) != hipSuccess) return lec_set_error(LEC_ERR_LAUNCH, "lec_reduce: hipMemsetAsync failed");
         hipLaunchKernelGGL(lec_dropmask_kernel, dim3(a->t_count), dim3(64), 0, st, p);
     }
-    hipLaunchKernelGGL(lec_vertical_kernel, dim3(a->t_count), dim3(64), 0, st, p);
+    if (!mask_only) hipLaunchKernelGGL(lec_vertical_kernel, dim3(a->t_count), dim3(64), 0, st, p);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return lec_set_error(LEC_ERR_LAUNCH, hipGetErrorString(e));
     return LEC_OK;
 }
+
+extern "C" int lec_reduce(const lec_reduce_args* a) { return reduce_impl(a, false, "lec_reduce"); }
+extern "C" int lec_dropmask(const lec_reduce_args* a) { return reduce_impl(a, true, "lec_dropmask"); }

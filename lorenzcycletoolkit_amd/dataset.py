@@ -137,9 +137,21 @@ def _decode_time(values: np.ndarray, units: str) -> np.ndarray:
     return (np.datetime64(origin.to_datetime64(), "s") + off.astype("timedelta64[s]")).astype("datetime64[ns]")
 
 
-def open_dataset(path: str, variable_list_df: pd.DataFrame) -> LECDataset:
-    """get_data (preprocessing.py:35-146) for classic NetCDF files, then validate_variable_match /
-    validate_required_coordinates (validation.py:247-356)."""
+FIELD_ROLES = ("Air Temperature", "Omega Velocity", "Eastward Wind Component", "Northward Wind Component")
+
+
+def _attr(v, name):
+    a = getattr(v, name, None)
+    if isinstance(a, bytes):
+        a = a.decode()
+    if isinstance(a, np.ndarray) and a.size == 1:
+        a = a.reshape(()).item()
+    return a
+
+
+def _open_nc(path: str, variable_list_df: pd.DataFrame, mmap: bool):
+    """Opens a classic NetCDF file and checks it against the namelist (get_data, preprocessing.py:35-146;
+    validate_variable_match / validate_required_coordinates, validation.py:247-356)."""
     from scipy.io import netcdf_file
 
     if not os.path.exists(path):
@@ -149,33 +161,52 @@ def open_dataset(path: str, variable_list_df: pd.DataFrame) -> LECDataset:
     if magic[:3] != b"CDF":
         raise ValueError(f"{path}: not a classic NetCDF-3 file (magic {magic!r}); NetCDF-4/HDF5 input needs an HDF5 "
                          "reader that is not available in this environment (convert with `nccopy -k classic`)")
-    nc = netcdf_file(path, mmap=False)
+    nc = netcdf_file(path, mmap=mmap)
     var = lambda role: str(variable_list_df.loc[role]["Variable"])
     names = {r: var(r) for r in REQUIRED_ROLES}
     geo_role = "Geopotential" if "Geopotential" in variable_list_df.index else "Geopotential Height"
     names[geo_role] = var(geo_role)
     missing = [f"{r} -> {n}" for r, n in names.items() if n not in nc.variables]
     if missing:
+        nc.close()
         raise KeyError(f"namelist variables not found in {path}: {missing}; file has {list(nc.variables)}")
     native = lambda n: np.array(nc.variables[n].data).astype(nc.variables[n].data.dtype.newbyteorder("="))
     lat, lon, lev = native(names["Latitude"]), native(names["Longitude"]), native(names["Vertical Level"])
-    tv = nc.variables[names["Time"]]
-    time = _decode_time(native(names["Time"]), tv.units.decode() if isinstance(tv.units, bytes) else str(tv.units))
-    lv = nc.variables[names["Vertical Level"]]
-    level_units = getattr(lv, "units", None)
-    if isinstance(level_units, bytes):
-        level_units = level_units.decode()
+    time = _decode_time(native(names["Time"]), _attr(nc.variables[names["Time"]], "units"))
+    level_units = _attr(nc.variables[names["Vertical Level"]], "units")
     want = (names["Time"], names["Vertical Level"], names["Latitude"], names["Longitude"])
+    return nc, names, geo_role, lat, lon, lev, time, level_units, want
+
+
+def _packing(v):
+    """CF packing attributes of a variable: (scale_factor, add_offset, fill value) with None for absent ones."""
+    scale, offset = _attr(v, "scale_factor"), _attr(v, "add_offset")
+    fill = _attr(v, "_FillValue")
+    if fill is None:
+        fill = _attr(v, "missing_value")
+    return (None if scale is None else float(scale), None if offset is None else float(offset),
+            None if fill is None else float(fill))
+
+
+def open_dataset(path: str, variable_list_df: pd.DataFrame) -> LECDataset:
+    """Host-side decode of the whole file: raw values equal to the fill value become NaN, CF-packed variables
+    decode to float64 as ``raw * scale_factor + add_offset`` (xarray 2024.2 decodes int16 data that has an
+    add_offset to float64), other variables keep the file's dtype."""
+    nc, names, geo_role, lat, lon, lev, time, level_units, want = _open_nc(path, variable_list_df, mmap=False)
     variables = {}
-    for role in ("Air Temperature", "Omega Velocity", "Eastward Wind Component", "Northward Wind Component", geo_role):
+    for role in FIELD_ROLES + (geo_role,):
         v = nc.variables[names[role]]
-        a = native(names[role])
-        scale, offset = getattr(v, "scale_factor", None), getattr(v, "add_offset", None)
-        if scale is not None or offset is not None:       # CF packing decodes to float64 (xarray 2024.2)
-            a = a.astype(np.float64) * (1.0 if scale is None else float(scale)) + (0.0 if offset is None else float(offset))
-        fill = getattr(v, "_FillValue", None)
+        raw = np.array(v.data).astype(v.data.dtype.newbyteorder("="))
+        scale, offset, fill = _packing(v)
+        a = raw
+        if scale is not None or offset is not None:
+            a = raw.astype(np.float64)
+            if scale is not None:
+                a *= scale
+            if offset is not None:
+                a += offset
         if fill is not None and np.issubdtype(a.dtype, np.floating):
-            a = np.where(a == fill, np.nan, a)
+            a = np.where(raw == fill, np.nan, a)
         if set(v.dimensions) != set(want):
             raise ValueError(f"{names[role]} has dimensions {v.dimensions}, expected {want}")
         variables[names[role]] = np.transpose(a, [v.dimensions.index(d) for d in want])
@@ -183,13 +214,75 @@ def open_dataset(path: str, variable_list_df: pd.DataFrame) -> LECDataset:
     return LECDataset(variables, lat, lon, lev, time, names, level_units)
 
 
+@dataclass
+class RawVariable:
+    """One file variable as stored: memory-mapped, file byte order, possibly CF-packed."""
+    data: np.ndarray                  # [time, level, lat, lon] in FILE order of each axis
+    scale_factor: Optional[float]
+    add_offset: Optional[float]
+    fill_value: Optional[float]
+
+
+@dataclass
+class RawDataset:
+    """The undecoded file: what the device ingest (ingest.py) streams to the GPU."""
+    variables: Dict[str, RawVariable]
+    lat: np.ndarray
+    lon: np.ndarray
+    level: np.ndarray
+    time: np.ndarray
+    names: Dict[str, str]
+    level_units: Optional[str]
+    geo_role: str
+    _nc: object = None                # keeps the memory map alive
+
+    def close(self):
+        if self._nc is not None:
+            self.variables.clear()
+            try:
+                self._nc.close()
+            except Exception:       # scipy refuses to close while views of the map are alive; the map goes with them
+                pass
+            self._nc = None
+
+
+def open_raw(path: str, variable_list_df: pd.DataFrame) -> RawDataset:
+    """Like open_dataset, but nothing is decoded or copied: the variables stay memory-mapped file bytes."""
+    nc, names, geo_role, lat, lon, lev, time, level_units, want = _open_nc(path, variable_list_df, mmap=True)
+    variables = {}
+    for role in FIELD_ROLES + (geo_role,):
+        v = nc.variables[names[role]]
+        if tuple(v.dimensions) != want:
+            nc.close()
+            raise ValueError(f"{names[role]} has dimensions {v.dimensions}; the device ingest needs {want} order")
+        if v.data.dtype.kind not in "if" or v.data.dtype.itemsize not in (2, 4, 8) or (v.data.dtype.kind == "i" and v.data.dtype.itemsize != 2):
+            nc.close()
+            raise ValueError(f"{names[role]}: the device ingest reads int16, float32 and float64 variables, not {v.data.dtype}")
+        scale, offset, fill = _packing(v)
+        variables[names[role]] = RawVariable(v.data, scale, offset, fill)
+    return RawDataset(variables, lat, lon, lev, time, names, level_units, geo_role, nc)
+
+
 # --------------------------------------------------------------------------------------------
 # process_data / slice_domain
 # --------------------------------------------------------------------------------------------
-def process_data(data: LECDataset, args, variable_list_df: pd.DataFrame, app_logger=None) -> LECDataset:
-    """process_data (preprocessing.py:149-371): track-time selection, 0..360 -> -180..180 longitudes,
-    level -> Pa, sort lon / level / lat ascending, drop levels above 10 hPa."""
-    v, lat, lon, lev, time = dict(data.variables), data.lat, data.lon, data.level, data.time
+@dataclass
+class ProcessIndex:
+    """What process_data does to the axes, as index maps (sorted axis -> file axis)."""
+    tpos: Optional[np.ndarray]        # selected time steps (track times) or None for all
+    ik: np.ndarray                    # kept levels, ascending in Pa
+    ij: np.ndarray                    # latitudes S -> N
+    io: np.ndarray                    # longitudes W -> E after the wrap to -180..180
+    lat: np.ndarray
+    lon: np.ndarray
+    level: np.ndarray                 # Pa
+    time: np.ndarray
+
+
+def process_index(lat, lon, lev, time, level_units, names, args, app_logger=None) -> ProcessIndex:
+    """process_data (preprocessing.py:149-371) on the coordinates only: track-time selection, 0..360 -> -180..180
+    longitudes, level -> Pa, sort lon / level / lat ascending, drop levels above 10 hPa."""
+    tpos = None
     if getattr(args, "track", False):
         track = read_track(args.trackfile, app_logger)
         data_dt = int((time[1] - time[0]) / np.timedelta64(1, "h"))
@@ -204,38 +297,45 @@ def process_data(data: LECDataset, args, variable_list_df: pd.DataFrame, app_log
         if track.index[-1] > time[-1]:
             raise ValueError(f"Track final timestamp ({track.index[-1]}) is later than data final timestamp "
                              f"({time[-1]}). Please adjust the track file or re-download the data.")
-        pos = pd.Index(time).get_indexer(track.index.values)
-        if np.any(pos < 0):
-            raise KeyError(f"track times not found in the data: {list(track.index[pos < 0])}")
-        v = {k: a[pos] for k, a in v.items()}
-        time = time[pos]
+        tpos = pd.Index(time).get_indexer(track.index.values)
+        if np.any(tpos < 0):
+            raise KeyError(f"track times not found in the data: {list(track.index[tpos < 0])}")
+        time = time[tpos]
     if lon.min() < -180 or lon.max() > 180:
         lon = (lon + 180) % 360 - 180                                   # tools.py:76-92
-    key = (data.level_units or "hPa").strip().lower()
-    if data.level_units is None and app_logger:
+    key = (level_units or "hPa").strip().lower()
+    if level_units is None and app_logger:
         app_logger.warning(f"Vertical level coordinate has no units attribute. Assuming hPa (hectopascals).")
     if key not in _LEVEL_SCALE:
-        raise ValueError(f"Cannot convert vertical level units to Pa. Check if '{data.names.get('Vertical Level')}' "
+        raise ValueError(f"Cannot convert vertical level units to Pa. Check if '{names.get('Vertical Level')}' "
                          "has valid pressure units.")
     lev = lev.astype(np.float64) * _LEVEL_SCALE[key]
     io, ik, ij = np.argsort(lon, kind="stable"), np.argsort(lev, kind="stable"), np.argsort(lat, kind="stable")
-    lon, lev, lat = lon[io], lev[ik], lat[ij]
-    keep = lev >= 1000.0                                                # preprocessing.py:364-365
-    v = {k: np.ascontiguousarray(a[:, ik][:, keep][:, :, ij][:, :, :, io]) for k, a in v.items()}
-    return LECDataset(v, lat, lon, lev[keep], time, dict(data.names), "Pa")
+    keep = lev[ik] >= 1000.0                                            # preprocessing.py:364-365
+    return ProcessIndex(tpos, ik[keep], ij, io, lat[ij], lon[io], lev[ik][keep], time)
 
 
-def slice_domain(data: LECDataset, args, variable_list_df: pd.DataFrame) -> LECDataset:
-    """slice_domain (select_area.py:254-338): fixed -> nearest-point crop from the hard-coded
-    inputs/box_limits; track -> label slice of the track extent +- (half the largest box + one grid step)."""
+def process_data(data: LECDataset, args, variable_list_df: pd.DataFrame, app_logger=None) -> LECDataset:
+    """process_data (preprocessing.py:149-371): track-time selection, 0..360 -> -180..180 longitudes,
+    level -> Pa, sort lon / level / lat ascending, drop levels above 10 hPa."""
+    px = process_index(data.lat, data.lon, data.level, data.time, data.level_units, data.names, args, app_logger)
+    v = data.variables if px.tpos is None else {k: a[px.tpos] for k, a in data.variables.items()}
+    v = {k: np.ascontiguousarray(a[:, px.ik][:, :, px.ij][:, :, :, px.io]) for k, a in v.items()}
+    return LECDataset(v, px.lat, px.lon, px.level, px.time, dict(data.names), "Pa")
+
+
+def domain_slices(lat: np.ndarray, lon: np.ndarray, args):
+    """slice_domain (select_area.py:254-338) on sorted coordinates: (lat slice, lon slice).  Fixed -> nearest-point
+    crop from the hard-coded inputs/box_limits; track -> label slice of the track extent +- (half the largest
+    box + one grid step)."""
     from .tables import nearest_index
     if getattr(args, "fixed", False):
         w, e, s, n = read_box_limits("inputs/box_limits")
-        iw, ie = nearest_index(data.lon, w), nearest_index(data.lon, e)
-        js, jn = nearest_index(data.lat, s), nearest_index(data.lat, n)
-        return data.isel(j=slice(js, jn + 1), i=slice(iw, ie + 1))
+        iw, ie = nearest_index(lon, w), nearest_index(lon, e)
+        js, jn = nearest_index(lat, s), nearest_index(lat, n)
+        return slice(js, jn + 1), slice(iw, ie + 1)
     if getattr(args, "track", False):
-        dx, dy = data.lon[1] - data.lon[0], data.lat[1] - data.lat[0]
+        dx, dy = lon[1] - lon[0], lat[1] - lat[0]
         track = read_track(args.trackfile or "inputs/track")
         if "width" in track.columns:
             mw, ml = track["width"].max(), track["length"].max()
@@ -243,12 +343,18 @@ def slice_domain(data: LECDataset, args, variable_list_df: pd.DataFrame) -> LECD
             mw, ml = 15, 15
         w, e = track["Lon"].min() - mw / 2 - dx, track["Lon"].max() + mw / 2 + dx
         s, n = track["Lat"].min() - ml / 2 - dy, track["Lat"].max() + ml / 2 + dy
-        ii = np.flatnonzero((data.lon >= w) & (data.lon <= e))
-        jj = np.flatnonzero((data.lat >= s) & (data.lat <= n))
+        ii = np.flatnonzero((lon >= w) & (lon <= e))
+        jj = np.flatnonzero((lat >= s) & (lat <= n))
         if ii.size < 2 or jj.size < 2:
             raise ValueError("track extent selects fewer than 2 grid points of the data")
-        return data.isel(j=slice(jj[0], jj[-1] + 1), i=slice(ii[0], ii[-1] + 1))
+        return slice(jj[0], jj[-1] + 1), slice(ii[0], ii[-1] + 1)
     raise NotImplementedError("the interactive -c/--choose domain selection needs a GUI and is out of scope")
+
+
+def slice_domain(data: LECDataset, args, variable_list_df: pd.DataFrame) -> LECDataset:
+    """slice_domain (select_area.py:254-338), see domain_slices."""
+    js, is_ = domain_slices(data.lat, data.lon, args)
+    return data.isel(j=js, i=is_)
 
 
 def field_scale(variable_list_df: pd.DataFrame, role: str) -> float:

@@ -10,7 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 from dataclasses import dataclass
-from typing import Dict, Optional, Sequence
+from typing import Callable, Dict, Optional, Sequence
 
 import numpy as np
 import torch
@@ -95,8 +95,9 @@ class LECEngine:
                 time_s=None, dTdt: Optional[torch.Tensor] = None, t_begin: int = 0,
                 t_count: Optional[int] = None, with_q: bool = True, phi_scale: float = 1.0,
                 keep_rows: bool = False, timing: Optional[list] = None,
-                drop_any_time: Optional[bool] = None) -> LECResult:
-        """All LEC terms for time steps [t_begin, t_begin + t_count) of the cubes.
+                drop_any_time: Optional[bool] = None,
+                merge_dropmask: Optional[Callable[[torch.Tensor], None]] = None) -> LECResult:
+        """All LEC terms for time steps [t_begin, t_begin + t_count) of the cubes: ``rowstats`` then ``reduce``.
 
         ``boxes``: one (iw, ie, js, jn) quadruple (fixed framework) or one per processed time step
         (moving framework).  ``time_s`` (seconds, length nt) gives dT/dt by np.gradient over the
@@ -104,9 +105,21 @@ class LECEngine:
         ``drop_any_time``: _handle_nans' dropna semantics -- True drops a level that stays NaN at any processed
         time step from every time step's integrals (what the fixed framework's [time, level] arrays do); default:
         True for one fixed box, False for per-time-step boxes (the moving framework builds one BoxData per step).
+        ``merge_dropmask``: see ``reduce`` (time-sharded runs).
         ``timing``: a list that receives one (start, end) pair of HIP events recorded on the launch
         stream around the stage-1 kernel (bench.py's roofline figure).
         """
+        rows = self.rowstats(tair, u, v, omega, geopt, boxes, time_s=time_s, dTdt=dTdt, t_begin=t_begin, t_count=t_count,
+                             with_q=with_q, timing=timing)
+        return self.reduce(rows, boxes, phi_scale=phi_scale, drop_any_time=drop_any_time, merge_dropmask=merge_dropmask,
+                           keep_rows=keep_rows)
+
+    def rowstats(self, tair: torch.Tensor, u: torch.Tensor, v: torch.Tensor, omega: torch.Tensor,
+                 geopt: Optional[torch.Tensor], boxes: Sequence[Sequence[int]], *,
+                 time_s=None, dTdt: Optional[torch.Tensor] = None, t_begin: int = 0,
+                 t_count: Optional[int] = None, with_q: bool = True, timing: Optional[list] = None,
+                 rows_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Stage 1 (``lec_rowstats``): row records [t_count, nl, nyb_max, 32] of time steps [t_begin, t_begin + t_count)."""
         if tair.dim() != 4:
             raise ValueError("fields must be [time, level, lat, lon]")
         nt, nl, ny, nx = tair.shape
@@ -140,17 +153,13 @@ class LECEngine:
             tcoef = self._up(tables.time_coefs(time_s))
 
         f64 = dict(dtype=torch.float64, device=tair.device)
-        rows = torch.empty((t_count, nl, bt.nyb_max, _lib.LEC_NSTAT), **f64)
-        am = torch.empty((t_count, nl, 8), **f64)
-        levraw = torch.empty((t_count, nl, _lib.LEC_NLEVRAW), **f64)
-        scalars = torch.empty((t_count, _lib.LEC_NSCALAR), **f64)
-        levels = torch.empty((t_count, _lib.LEC_NLEVTAB, nl), **f64)
-        nanflag = torch.empty((t_count,), dtype=torch.int32, device=tair.device)
-        if drop_any_time is None:
-            drop_any_time = len(boxes) == 1
-        dropmask = torch.empty((_lib.LEC_NLEVFUN, nl), dtype=torch.int32, device=tair.device) if drop_any_time else None
+        if rows_out is None:
+            rows = torch.empty((t_count, nl, bt.nyb_max, _lib.LEC_NSTAT), **f64)
+        else:       # a slice of a longer series' record buffer (chunked ingest): stage 2 runs once over all of it
+            rows = rows_out
+            if rows.shape != (t_count, nl, bt.nyb_max, _lib.LEC_NSTAT) or rows.dtype != torch.float64 or not rows.is_contiguous():
+                raise ValueError("rows_out must be a contiguous fp64 [t_count, nl, nyb_max, 32] tensor")
         stream = C.c_void_p(torch.cuda.current_stream(tair.device).cuda_stream)
-
         ra = _lib.RowstatsArgs(
             tair_d=_ptr(tair), u_d=_ptr(u), v_d=_ptr(v), omega_d=_ptr(omega), geopt_d=_ptr(geopt), dTdt_d=_ptr(dTdt),
             dtype=_lib.LEC_F64 if tair.dtype == torch.float64 else _lib.LEC_F32, with_q=int(bool(with_q)),
@@ -167,14 +176,47 @@ class LECEngine:
             if timing is not None:
                 ev1.record()
                 timing.append((ev0, ev1))
-            rd = _lib.ReduceArgs(
-                rows_d=_ptr(rows), t_count=t_count, nl=nl, n_box=len(boxes), nyb_max=bt.nyb_max,
-                box_d=_ptr(dev["box"]), boxtab2_d=_ptr(dev["boxtab2"]), lattab2_d=_ptr(dev["lattab2"]),
-                levtab2_d=_ptr(self._levtab2), phi_scale=float(phi_scale),
-                drop_any_time=int(bool(drop_any_time)), reserved0=0, dropmask_d=_ptr(dropmask),
-                am_d=_ptr(am), levraw_d=_ptr(levraw), scalars_d=_ptr(scalars), levels_d=_ptr(levels),
-                nanflag_d=_ptr(nanflag), stream=stream)
+        # tcoef is released to torch's caching allocator only after the stream work is enqueued; the allocator
+        # is stream-ordered, so reuse on this stream is safe.
+        return rows
+
+    def reduce(self, rows: torch.Tensor, boxes: Sequence[Sequence[int]], *, phi_scale: float = 1.0,
+               drop_any_time: Optional[bool] = None, merge_dropmask: Optional[Callable[[torch.Tensor], None]] = None,
+               keep_rows: bool = False) -> LECResult:
+        """Stage 2 on row records [t_count, nl, nyb_max, 32] (``lec_reduce``).
+
+        ``merge_dropmask``: for a series processed in shards -- called with this shard's any-time NaN-level mask
+        (int32 [28, nl], non-zero = drop) and must merge it in place with the other shards' masks (element-wise
+        max, e.g. an all_reduce); the merged mask then applies to every shard, as xarray's dropna(dim=level) on the
+        whole [time, level] array does in the reference (energy_contents.py:203-207)."""
+        boxes = [tuple(int(x) for x in b) for b in (boxes if isinstance(boxes[0], (tuple, list, np.ndarray)) else [boxes])]
+        t_count, nl = int(rows.shape[0]), int(rows.shape[1])
+        if len(boxes) not in (1, t_count):
+            raise ValueError("boxes: give one box, or one per processed time step")
+        bt, dev = self._box_tables(boxes)
+        if rows.shape != (t_count, self.level.size, bt.nyb_max, _lib.LEC_NSTAT) or rows.dtype != torch.float64 or not rows.is_contiguous():
+            raise ValueError("rows must be a contiguous fp64 [t_count, nl, nyb_max, 32] tensor")
+        f64 = dict(dtype=torch.float64, device=rows.device)
+        am = torch.empty((t_count, nl, 8), **f64)
+        levraw = torch.empty((t_count, nl, _lib.LEC_NLEVRAW), **f64)
+        scalars = torch.empty((t_count, _lib.LEC_NSCALAR), **f64)
+        levels = torch.empty((t_count, _lib.LEC_NLEVTAB, nl), **f64)
+        nanflag = torch.empty((t_count,), dtype=torch.int32, device=rows.device)
+        if drop_any_time is None:
+            drop_any_time = len(boxes) == 1
+        dropmask = torch.empty((_lib.LEC_NLEVFUN, nl), dtype=torch.int32, device=rows.device) if drop_any_time else None
+        stream = C.c_void_p(torch.cuda.current_stream(rows.device).cuda_stream)
+        mode = 0 if not drop_any_time else (2 if merge_dropmask is not None else 1)
+        rd = _lib.ReduceArgs(
+            rows_d=_ptr(rows), t_count=t_count, nl=nl, n_box=len(boxes), nyb_max=bt.nyb_max,
+            box_d=_ptr(dev["box"]), boxtab2_d=_ptr(dev["boxtab2"]), lattab2_d=_ptr(dev["lattab2"]),
+            levtab2_d=_ptr(self._levtab2), phi_scale=float(phi_scale),
+            drop_any_time=mode, reserved0=0, dropmask_d=_ptr(dropmask),
+            am_d=_ptr(am), levraw_d=_ptr(levraw), scalars_d=_ptr(scalars), levels_d=_ptr(levels),
+            nanflag_d=_ptr(nanflag), stream=stream)
+        with torch.cuda.device(rows.device):
+            if mode == 2:
+                _lib.check(self.lib.lec_dropmask(C.byref(rd)), "lec_dropmask")
+                merge_dropmask(dropmask)
             _lib.check(self.lib.lec_reduce(C.byref(rd)), "lec_reduce")
-        # tcoef / workspaces are released to torch's caching allocator only after the stream work is
-        # enqueued; the allocator is stream-ordered, so reuse on this stream is safe.
         return LECResult(scalars=scalars, levels=levels, nanflag=nanflag, rows=rows if keep_rows else None)

@@ -1,0 +1,192 @@
+"""Device ingest: file bytes -> GPU -> LEC terms, without a host pass over the data.
+
+The reference decodes the whole file with xarray, then copies it four more times on the host
+(longitude wrap + sorts, level filter, domain crop, unit conversion; src/utils/preprocessing.py:35-371,
+src/utils/select_area.py:254-338, src/utils/box_data.py:297-310) before any term is computed.  Here the
+memory-mapped file bytes of a chunk of time steps go over PCIe as they are (int16-packed ERA5 data is a
+quarter of its fp64 size), ``lec_ingest`` decodes / sorts / crops / converts them in one gather pass on the
+GPU, ``lec_rowstats`` turns the chunk into row records, and ``lec_reduce`` runs once over the records of
+the whole series.  Chunks are double-buffered: the copy of chunk c+1 (copy stream) overlaps the kernels of
+chunk c (compute stream).  Results are bit-identical to the resident path (``LECEngine.compute`` on the
+host-prepared cubes): stage 1 is per row, and every chunk carries the one-step halo of T that dT/dt needs.
+
+Fixed (Eulerian) framework only: a moving box reads a small crop per step, which the resident path handles.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import sys
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import dataset as ds
+from .engine import LECEngine, LECResult
+
+_ROLE_KEYS = {"Air Temperature": "tair", "Eastward Wind Component": "u", "Northward Wind Component": "v",
+              "Omega Velocity": "omega"}
+
+
+@dataclass
+class IngestPlan:
+    """Index maps from the analysis domain (sorted, cropped) to file positions, plus the domain's coordinates."""
+    tsel: np.ndarray        # file time index of every processed time step
+    kmap: np.ndarray        # int32 [nl]
+    jmap: np.ndarray        # int32 [ny]
+    imap: np.ndarray        # int32 [nx]
+    lat: np.ndarray
+    lon: np.ndarray
+    level: np.ndarray       # Pa
+    time: np.ndarray        # datetime64[ns]
+
+    @property
+    def time_s(self) -> np.ndarray:
+        return (self.time - self.time.min()) / np.timedelta64(1, "s")
+
+
+def make_plan(raw: ds.RawDataset, args, app_logger=None) -> IngestPlan:
+    """process_data + slice_domain (preprocessing.py:149-371, select_area.py:254-338) as index maps."""
+    px = ds.process_index(raw.lat, raw.lon, raw.level, raw.time, raw.level_units, raw.names, args, app_logger)
+    js, is_ = ds.domain_slices(px.lat, px.lon, args)
+    tsel = np.arange(raw.time.size) if px.tpos is None else np.asarray(px.tpos)
+    i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+    return IngestPlan(tsel, i32(px.ik), i32(px.ij[js]), i32(px.io[is_]), px.lat[js], px.lon[is_], px.level, px.time)
+
+
+def _src_code(dtype: np.dtype) -> int:
+    if dtype.kind == "i" and dtype.itemsize == 2:
+        return _lib.LEC_I16
+    if dtype.kind == "f" and dtype.itemsize == 4:
+        return _lib.LEC_F32
+    if dtype.kind == "f" and dtype.itemsize == 8:
+        return _lib.LEC_F64
+    raise ValueError(f"the device ingest reads int16, float32 and float64 variables, not {dtype}")
+
+
+def _swapped(dtype: np.dtype) -> bool:
+    return dtype.byteorder == (">" if sys.byteorder == "little" else "<")
+
+
+class _Stager:
+    """One variable's path to the GPU: a pinned host buffer and a raw device buffer per pipeline slot."""
+
+    def __init__(self, var: ds.RawVariable, steps: int, device, slots: int = 2):
+        self.var = var
+        self.step_elems = int(np.prod(var.data.shape[1:]))
+        self.itemsize = var.data.dtype.itemsize
+        carrier = {2: torch.int16, 4: torch.int32, 8: torch.int64}[self.itemsize]      # bytes only; never interpreted
+        self.pinned = [torch.empty((steps, self.step_elems), dtype=carrier).pin_memory() for _ in range(slots)]
+        self.raw_dev = [torch.empty((steps, self.step_elems), dtype=carrier, device=device) for _ in range(slots)]
+        self._carrier_np = {2: np.int16, 4: np.int32, 8: np.int64}[self.itemsize]
+
+    def stage(self, slot: int, file_steps: np.ndarray, at: int):
+        """File time steps -> pinned rows [at, at + len): the only host touch of the data (page cache -> pinned)."""
+        dst = self.pinned[slot].numpy()
+        n = len(file_steps)
+        if n == 0:
+            return
+        flat = self.var.data.reshape(self.var.data.shape[0], -1)
+        as_bytes = lambda a: a.view(a.dtype.newbyteorder("=")).view(self._carrier_np)     # reinterpret, never convert
+        if n == 1 or np.all(np.diff(file_steps) == 1):
+            np.copyto(dst[at: at + n], as_bytes(flat[file_steps[0]: file_steps[0] + n]))
+        else:
+            for r, ft in enumerate(file_steps):
+                np.copyto(dst[at + r], as_bytes(flat[ft]))
+
+    def upload(self, slot: int, n: int):
+        self.raw_dev[slot][:n].copy_(self.pinned[slot][:n], non_blocking=True)
+
+
+def lec_fixed_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, box_limits, *, device="cuda:0",
+                       chunk_steps: int = 8, with_q: bool = True, stats: Optional[dict] = None) -> LECResult:
+    """All LEC terms of the fixed framework for the whole series, streamed from the memory-mapped file.
+
+    ``box_limits``: (west, east, south, north) in degrees, as inputs/box_limits.  ``chunk_steps`` time steps are
+    resident per pipeline slot (two slots).  ``stats`` receives counters: bytes moved, chunks, dtype.
+    """
+    lib = _lib.load()
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise _lib.LecLibraryError("the device ingest needs a GPU: there is no CPU path")
+    engine = LECEngine(plan.lat, plan.lon, plan.level, device=dev)
+    box = engine.box_from_limits(*box_limits)
+    nt, nl, ny, nx = len(plan.tsel), plan.level.size, plan.lat.size, plan.lon.size
+    if with_q and nt < 2:
+        raise ValueError("dT/dt by finite differences needs at least 2 time steps")
+    chunk_steps = max(1, min(int(chunk_steps), nt))
+    geo_role = raw.geo_role
+    roles = list(_ROLE_KEYS) + [geo_role]
+    keys = {**_ROLE_KEYS, geo_role: "geopt"}
+    rvars = {r: raw.variables[raw.names[r]] for r in roles}
+    packed_any = any(v.scale_factor is not None or v.add_offset is not None for v in rvars.values())
+    all_f32 = all(v.data.dtype.kind == "f" and v.data.dtype.itemsize == 4 for v in rvars.values())
+    out_dtype = torch.float32 if (all_f32 and not packed_any) else torch.float64      # the file's precision, fp64 for packed data
+    slots = 2
+    span = chunk_steps + 2                                                # own steps + the one-step halo of T either side
+    nl_in, ny_in, nx_in = (int(x) for x in rvars["Air Temperature"].data.shape[1:])
+    stagers = {r: _Stager(rvars[r], span, dev, slots) for r in roles}
+    cubes = [{keys[r]: torch.empty((span, nl, ny, nx), dtype=out_dtype, device=dev) for r in roles} for _ in range(slots)]
+    up = lambda a: torch.as_tensor(a, dtype=torch.int32).to(dev)
+    kmap, jmap, imap = up(plan.kmap), up(plan.jmap), up(plan.imap)
+    bt, _ = engine._box_tables([box])
+    rows = torch.empty((nt, nl, bt.nyb_max, _lib.LEC_NSTAT), dtype=torch.float64, device=dev)
+    time_s = plan.time_s
+    phi_scale = ds.field_scale(variable_list_df, geo_role)
+
+    compute = torch.cuda.current_stream(dev)
+    copier = torch.cuda.Stream(device=dev)
+    copied = [torch.cuda.Event() for _ in range(slots)]        # uploads of the slot have landed
+    consumed = [torch.cuda.Event() for _ in range(slots)]      # the slot's raw buffers have been decoded
+    used = [False] * slots
+    moved = 0
+    n_chunks = (nt + chunk_steps - 1) // chunk_steps
+    for c in range(n_chunks):
+        slot = c % slots
+        c0, c1 = c * chunk_steps, min((c + 1) * chunk_steps, nt)
+        h0, h1 = (max(c0 - 1, 0), min(c1 + 1, nt)) if with_q else (c0, c1)
+        if used[slot]:
+            copied[slot].synchronize()          # the pinned buffers of this slot may be overwritten now
+        for r in roles:                          # only T carries the halo; the others start at their own first step
+            if r == "Air Temperature":
+                stagers[r].stage(slot, plan.tsel[h0:h1], 0)
+            else:
+                stagers[r].stage(slot, plan.tsel[c0:c1], c0 - h0)
+        with torch.cuda.stream(copier):
+            if used[slot]:
+                copier.wait_event(consumed[slot])   # the raw device buffers of this slot have been decoded
+            for r in roles:
+                stagers[r].upload(slot, h1 - h0)
+                moved += (h1 - h0) * stagers[r].step_elems * stagers[r].itemsize
+            copied[slot].record(copier)
+        compute.wait_event(copied[slot])
+        with torch.cuda.device(dev):
+            for r in roles:
+                v, st = rvars[r], stagers[r]
+                unit = 1.0 if r == geo_role else ds.field_scale(variable_list_df, r)
+                ga = _lib.IngestArgs(
+                    src_d=C.c_void_p(st.raw_dev[slot].data_ptr()), src_dtype=_src_code(v.data.dtype),
+                    swap_bytes=int(_swapped(v.data.dtype)), nt=h1 - h0, nl_in=nl_in, ny_in=ny_in, nx_in=nx_in,
+                    nl=nl, ny=ny, nx=nx, kmap_d=C.c_void_p(kmap.data_ptr()), jmap_d=C.c_void_p(jmap.data_ptr()),
+                    imap_d=C.c_void_p(imap.data_ptr()),
+                    has_packing=int(v.scale_factor is not None or v.add_offset is not None),
+                    has_fill=int(v.fill_value is not None),
+                    scale_factor=1.0 if v.scale_factor is None else v.scale_factor,
+                    add_offset=0.0 if v.add_offset is None else v.add_offset,
+                    fill_value=0.0 if v.fill_value is None else v.fill_value, unit_scale=float(unit),
+                    out_dtype=_lib.LEC_F64 if out_dtype == torch.float64 else _lib.LEC_F32, reserved0=0,
+                    out_d=C.c_void_p(cubes[slot][keys[r]].data_ptr()), stream=C.c_void_p(compute.cuda_stream))
+                _lib.check(lib.lec_ingest(C.byref(ga)), "lec_ingest")
+            consumed[slot].record(compute)
+        f = {k: t[: h1 - h0] for k, t in cubes[slot].items()}
+        engine.rowstats(f["tair"], f["u"], f["v"], f["omega"], f["geopt"], [box],
+                        time_s=time_s[h0:h1] if with_q else None, t_begin=c0 - h0, t_count=c1 - c0, with_q=with_q,
+                        rows_out=rows[c0:c1])
+        used[slot] = True
+    res = engine.reduce(rows, [box], phi_scale=phi_scale)
+    if stats is not None:
+        stats.update(bytes_moved=moved, chunks=n_chunks, chunk_steps=chunk_steps, storage=str(out_dtype).replace("torch.", ""),
+                     box=tuple(int(x) for x in box), domain=(nt, nl, ny, nx))
+    return res

@@ -2,7 +2,8 @@
 
 The LEC path shards embarrassingly: every time step is independent except dT/dt, which needs the
 neighbouring time steps of T (thermodynamics.py:109-110 of the reference) -- a one-step halo that
-each rank loads/generates itself, so the data path has no collective.  The only exchange is one
+each rank loads/generates itself, so the data path has no collective.  The exchanges are one tiny all_reduce
+of the NaN-level mask ([28, L] int32; it only matters for fields with below-ground NaNs) and one
 all_gather of the per-time-step results ([T_local, 16 + 21 L] fp64, a few KB per step) over
 RCCL/xGMI (backend "nccl"; "gloo" in the CPU tests); budgets and residuals are then O(T) host work
 on the gathered series (calc_budget_and_residual.py:32-56,131-154).
@@ -52,8 +53,22 @@ def gather_timeseries(local: torch.Tensor, n_steps: int, group=None) -> torch.Te
     return torch.cat(parts, dim=0)
 
 
+def merge_dropmask(mask: torch.Tensor, group=None) -> None:
+    """Element-wise max of every rank's any-time NaN-level mask, in place (a [28, nl] int32 all_reduce): a level
+    that stays NaN at any time step of ANY shard is dropped from the pressure integrals of every time step, as
+    the reference's dropna(dim=level) on the whole [time, level] array does (energy_contents.py:203-207)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    if dist.get_backend(group) == "gloo" and mask.is_cuda:      # CPU rehearsal: stage through host memory
+        host = mask.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.MAX, group=group)
+        mask.copy_(host)
+    else:
+        dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=group)
+
+
 def compute_shard(engine, fields, time_s_global, n_steps: int, world: int, rank: int, box, *, with_q=True,
-                  phi_scale=1.0, timing=None):
+                  phi_scale=1.0, timing=None, group=None):
     """Runs the engine on this rank's contiguous block of time steps.
 
     ``fields``: dict with this rank's cubes (tair, u, v, omega, geopt) covering the HALO range
@@ -66,7 +81,8 @@ def compute_shard(engine, fields, time_s_global, n_steps: int, world: int, rank:
         raise ValueError(f"rank {rank}: cube must hold time steps [{h0}, {h1}) (own steps plus halo)")
     return engine.compute(fields["tair"], fields["u"], fields["v"], fields["omega"], fields.get("geopt"), [box],
                           time_s=time_s_global[h0:h1] if with_q else None, t_begin=t0 - h0, t_count=t1 - t0,
-                          with_q=with_q, phi_scale=phi_scale, timing=timing)
+                          with_q=with_q, phi_scale=phi_scale, timing=timing,
+                          merge_dropmask=(lambda m: merge_dropmask(m, group)) if world > 1 else None)
 
 
 def gather_result(res, n_steps: int, group=None):

@@ -1,0 +1,111 @@
+"""Device ingest: memory-mapped file bytes -> lec_ingest -> lec_rowstats per chunk -> one lec_reduce must
+give the very same numbers as the host-prepared, fully resident path (open_dataset + process_data + slice_domain +
+BoxData), for the reference's own float32 sample and for an ERA5-style int16-packed file whose axes need the
+longitude wrap, every sort, the 10 hPa filter and a fill value."""
+import argparse
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+pytestmark = pytest.mark.gpu
+
+from lorenzcycletoolkit_amd import dataset as ds
+from lorenzcycletoolkit_amd import ingest
+from lorenzcycletoolkit_amd.frameworks import BoxData
+
+
+@pytest.fixture
+def workdir(tmp_path, golden_dir, monkeypatch):
+    os.makedirs(tmp_path / "inputs")
+    shutil.copy(os.path.join(golden_dir, "inputs", "namelist_NCEP-R2"), tmp_path / "inputs" / "namelist")
+    monkeypatch.chdir(tmp_path)
+    return tmp_path
+
+
+def _both_paths(infile, namelist, limits, chunk_steps):
+    args = argparse.Namespace(fixed=True, track=False, trackfile=None, residuals=True)
+    df = ds.read_namelist(namelist)
+    host = ds.slice_domain(ds.process_data(ds.open_dataset(infile, df), args, df), args, df)
+    box = BoxData(host, df, *limits, args=args)
+    raw = ds.open_raw(infile, df)
+    plan = ingest.make_plan(raw, args)
+    stats = {}
+    res = ingest.lec_fixed_streamed(raw, plan, df, limits, chunk_steps=chunk_steps, stats=stats)
+    torch.cuda.synchronize()
+    raw.close()
+    assert np.array_equal(plan.lat, host.lat) and np.array_equal(plan.lon, host.lon) and np.array_equal(plan.level, host.level)
+    assert np.array_equal(plan.time, host.time)
+    return box.result, res, stats
+
+
+@pytest.mark.parametrize("chunk_steps", [5, 36, 1])
+def test_catarina_streamed_equals_resident(workdir, golden_dir, chunk_steps):
+    limits = (-55.0, -36.0, -35.0, -20.0)
+    (workdir / "inputs" / "box_limits").write_text("min_lon;-55\nmax_lon;-36\nmin_lat;-35\nmax_lat;-20\n")
+    a, b, stats = _both_paths(os.path.join(golden_dir, "Catarina_NCEP-R2.nc"), "inputs/namelist", limits, chunk_steps)
+    assert stats["storage"] == "float32" and stats["chunks"] == -(-36 // chunk_steps)
+    assert torch.equal(a.scalars, b.scalars)
+    assert torch.equal(a.levels, b.levels)
+    assert torch.equal(a.nanflag, b.nanflag)
+
+
+def _write_packed(path, nt=7):
+    """ERA5-style file: int16 with scale_factor / add_offset / _FillValue, lon 0..357.5, lat N -> S, levels in hPa
+    from the surface up including 5 hPa (dropped by the >= 10 hPa filter)."""
+    from scipy.io import netcdf_file
+    rng = np.random.default_rng(4)
+    lon = np.arange(0.0, 360.0, 2.5)
+    lat = np.arange(60.0, -62.5, -2.5)
+    lev = np.array([1000, 850, 700, 500, 300, 200, 100, 50, 5], dtype=np.int32)
+    nl, ny, nx = lev.size, lat.size, lon.size
+    f = netcdf_file(path, "w", version=2)
+    for n, s in (("time", nt), ("level", nl), ("latitude", ny), ("longitude", nx)):
+        f.createDimension(n, s)
+    tv = f.createVariable("time", "i", ("time",)); tv[:] = 6 * np.arange(nt); tv.units = "hours since 2020-01-01 00:00:00"
+    lv = f.createVariable("level", "i", ("level",)); lv[:] = lev; lv.units = "millibars"
+    la = f.createVariable("latitude", "f", ("latitude",)); la[:] = lat
+    lo = f.createVariable("longitude", "f", ("longitude",)); lo[:] = lon
+    p = (lev[None, :, None, None] * 100.0) / 1e5
+    fields = {
+        "t": 288.0 * p ** 0.19 + 8.0 * np.cos(np.deg2rad(2 * lat))[None, None, :, None] * p + rng.standard_normal((nt, nl, ny, nx)),
+        "u": 20.0 * np.cos(np.deg2rad(lat))[None, None, :, None] * (1 - p / 1.2) + 5 * rng.standard_normal((nt, nl, ny, nx)),
+        "v": 3.0 * rng.standard_normal((nt, nl, ny, nx)),
+        "w": 0.1 * rng.standard_normal((nt, nl, ny, nx)),
+        "z": 9.80665 * 7000.0 * np.log(1.0 / p) + 100.0 * rng.standard_normal((nt, nl, ny, nx)),
+    }
+    for name, a in fields.items():
+        lo_, hi_ = a.min(), a.max()
+        scale = (hi_ - lo_) / 65000.0
+        offset = 0.5 * (hi_ + lo_)
+        q = np.clip(np.round((a - offset) / scale), -32000, 32000).astype(np.int16)
+        if name == "v":
+            q[2, 7, :, :] = -32767          # 50 hPa = the top kept level, one time step: dropped for the whole series
+            q[4, 3, 10, 20] = -32767        # an interior point: that level is repaired by interpolation at that step
+        v = f.createVariable(name, "h", ("time", "level", "latitude", "longitude"))
+        v[:] = q
+        v.scale_factor = float(scale); v.add_offset = float(offset); v._FillValue = np.int16(-32767)
+    f.close()
+
+
+@pytest.mark.parametrize("chunk_steps", [3, 7])
+def test_packed_int16_file_streamed_equals_resident(workdir, chunk_steps):
+    path = str(workdir / "packed.nc")
+    _write_packed(path)
+    (workdir / "inputs" / "namelist").write_text(
+        ";Variable;Units\nAir Temperature;t;K\nGeopotential;z;m**2/s**2\nOmega Velocity;w;Pa/s\n"
+        "Eastward Wind Component;u;m/s\nNorthward Wind Component;v;m/s\nLongitude;longitude\nLatitude;latitude\n"
+        "Time;time\nVertical Level;level\n")
+    limits = (-60.0, 20.0, -45.0, 30.0)      # crosses the Greenwich meridian: needs the longitude wrap + sort
+    (workdir / "inputs" / "box_limits").write_text("min_lon;-60\nmax_lon;20\nmin_lat;-45\nmax_lat;30\n")
+    a, b, stats = _both_paths(path, "inputs/namelist", limits, chunk_steps)
+    assert stats["storage"] == "float64" and stats["domain"][1] == 8          # 5 hPa dropped
+    assert int(a.nanflag.max()) > 0                                            # the fill values reached _handle_nans
+    assert torch.equal(a.scalars, b.scalars)
+    assert np.array_equal(a.levels.cpu().numpy(), b.levels.cpu().numpy(), equal_nan=True)     # NaN levels stay NaN in the tables
+    assert torch.isfinite(a.scalars[:, :4]).all()
+    full_bytes = 5 * 7 * 9 * 49 * 144 * 2
+    assert stats["bytes_moved"] <= 1.6 * full_bytes                            # int16 over PCIe (+ T halo), not fp64

@@ -19,8 +19,12 @@ from tests.helpers import synthetic_domain
 N_STEPS = 7
 
 
-def _dom():
-    return synthetic_domain(N_STEPS, 5, 12, 128, seed=21)
+def _dom(nan_case=False):
+    dom = synthetic_domain(N_STEPS, 5, 12, 128, seed=21)
+    if nan_case:        # a top level that is NaN at ONE time step (of the first shard): dropped for EVERY step of every shard
+        dom.v[1, 0, :, :] = np.nan
+        dom.tair[5, 2, 4, 9] = np.nan      # an interior level in the last shard: repaired by interpolation there only
+    return dom
 
 
 def _free_port():
@@ -29,14 +33,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, nan_case):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from lorenzcycletoolkit_amd.engine import LECEngine
         from lorenzcycletoolkit_amd.parallel import compute_shard, gather_result, halo_range, shard_range
-        dom = _dom()
+        dom = _dom(nan_case)
         t0, t1 = shard_range(N_STEPS, world, rank)
         h0, h1 = halo_range(t0, t1, N_STEPS)
         dev = lambda a: torch.as_tensor(np.ascontiguousarray(a[h0:h1])).to("cuda:0")
@@ -50,17 +54,21 @@ def _worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_series_equals_single_process(tmp_path, world):
+@pytest.mark.parametrize("world,nan_case", [(2, False), (3, False), (2, True), (3, True)])
+def test_sharded_series_equals_single_process(tmp_path, world, nan_case):
+    """nan_case: the any-time NaN-level mask must be merged across shards (one [28, L] all_reduce), otherwise
+    only the shard that holds the NaN time step would drop the level."""
     from lorenzcycletoolkit_amd.engine import LECEngine
-    dom = _dom()
+    dom = _dom(nan_case)
     dev = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to("cuda:0")
     eng = LECEngine(dom.lat, dom.lon, dom.level, device="cuda:0")
     box = eng.box_from_limits(dom.lon[2], dom.lon[-3], dom.lat[1], dom.lat[-2])
     res = eng.compute(dev(dom.tair), dev(dom.u), dev(dom.v), dev(dom.omega), dev(dom.geopt), [box], time_s=dom.time_s)
     want = torch.cat([res.scalars, res.levels.reshape(N_STEPS, -1)], dim=1).cpu().numpy()
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), nan_case), nprocs=world, join=True)
     for r in range(world):
         got = np.load(tmp_path / f"full_{r}.npy")
         assert got.shape == want.shape
-        assert np.array_equal(got, want), f"rank {r}: sharded series differs from the single-process one"
+        assert np.array_equal(got, want, equal_nan=True), f"rank {r}: sharded series differs from the single-process one"
+    if nan_case:
+        assert np.isfinite(want[:, :4]).all()      # the energy terms survive: the level was dropped / repaired, not propagated

@@ -97,6 +97,8 @@ def test_struct_sizes_match_header_layout():
     # 6 pointers + 12 int32 + 7 pointers + 2 pointers ; 1 pointer + 4 int32 + 4 pointers + double + 2 int32 + 7 pointers
     assert ctypes.sizeof(_lib.RowstatsArgs) == 6 * 8 + 12 * 4 + 9 * 8
     assert ctypes.sizeof(_lib.ReduceArgs) == 8 + 4 * 4 + 4 * 8 + 8 + 2 * 4 + 8 + 6 * 8
+    # lec_ingest_args: pointer + 2 int32 + 4 int32 + 3 int32 (+4 padding) + 3 pointers + 2 int32 + 4 doubles + 2 int32 + 2 pointers
+    assert ctypes.sizeof(_lib.IngestArgs) == 8 + 9 * 4 + 4 + 3 * 8 + 2 * 4 + 4 * 8 + 2 * 4 + 2 * 8
 
 
 def test_argument_errors_without_gpu():
@@ -110,3 +112,7 @@ def test_argument_errors_without_gpu():
     r = _lib.ReduceArgs()
     assert lib.lec_reduce(ctypes.byref(r)) == 1
     assert lib.lec_rowstats(None) == 1
+    assert lib.lec_dropmask(ctypes.byref(r)) == 1
+    g = _lib.IngestArgs()
+    assert lib.lec_ingest(ctypes.byref(g)) == 1 and b"null" in lib.lec_last_error()
+    assert lib.lec_ingest(None) == 1
