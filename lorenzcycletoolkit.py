@@ -36,6 +36,7 @@ def create_arg_parser():
     parser.add_argument("--time-resolution", type=int, default=3, help="Temporal resolution in hours for CDS API data download (default: 3).")
     parser.add_argument("--trackfile", type=str, default="inputs/track", help="Specify a custom track file. Default is 'inputs/track'.")
     parser.add_argument("--box_limits", type=str, default="inputs/box_limits", help="Specify a custom box limits file. Default is 'inputs/box_limits'.")
+    parser.add_argument("--device-ingest", action="store_true", help="(MI355X engine, with -f) stream the file bytes to the GPU and decode / sort / crop them there instead of preparing the data on the host.")
     parser.add_argument("-o", "--outname", type=str, help="Specify an output name for the results.")
     return parser
 
@@ -91,7 +92,11 @@ def main(argv=None):
     app_logger.info("Starting LEC analysis")
     app_logger.info(f"Command line arguments: {args}")
     try:
-        data = prepare_data(args, "inputs/namelist", app_logger)
+        if args.device_ingest:
+            from lorenzcycletoolkit_amd.ingest import prepare_streamed
+            data = prepare_streamed(args, "inputs/namelist", app_logger)
+        else:
+            data = prepare_data(args, "inputs/namelist", app_logger)
         run_lec_analysis(data, args, results_subdirectory, figures_directory, results_subdirectory_vertical_levels, app_logger)
     except Exception:
         app_logger.exception("LEC analysis failed")

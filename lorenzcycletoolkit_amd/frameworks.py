@@ -69,6 +69,23 @@ class BoxData:
         self.western_limit, self.eastern_limit = float(data.lon[iw]), float(data.lon[ie])
         self.southern_limit, self.northern_limit = float(data.lat[js]), float(data.lat[jn])
 
+        from .ingest import StreamedDataset, lec_fixed_streamed
+        if isinstance(data, StreamedDataset):
+            # device ingest: the file bytes are streamed, decoded, sorted and cropped on the GPU (ingest.py)
+            if boxes_limits is not None or dTdt is not None:
+                raise NotImplementedError("the device ingest serves the fixed framework")
+            self.ingest_stats = {}
+            self.result: LECResult = lec_fixed_streamed(data.raw, data.plan, variable_list_df, limits[0], device=dev,
+                                                        chunk_steps=data.chunk_steps, stats=self.ingest_stats)
+        else:
+            self.result = self._compute_resident(data, variable_list_df, dev, dTdt)
+        torch.cuda.synchronize(dev)
+        self.scalars = self.result.scalars_dict()
+        self.levels = self.result.levels_dict()
+        self.nanflag = self.result.nanflag.cpu().numpy()
+
+    def _compute_resident(self, data: ds.LECDataset, variable_list_df: pd.DataFrame, dev, dTdt) -> LECResult:
+        """Host-prepared cubes, uploaded whole."""
         geo_role = "Geopotential" if "Geopotential" in variable_list_df.index else "Geopotential Height"
         roles = ["Air Temperature", "Eastward Wind Component", "Northward Wind Component", "Omega Velocity", geo_role]
         cubes = []
@@ -80,13 +97,8 @@ class BoxData:
             cubes.append(torch.as_tensor(np.ascontiguousarray(a)).to(dev))
         phi_scale = ds.field_scale(variable_list_df, geo_role)
         dTdt_dev = None if dTdt is None else torch.as_tensor(np.ascontiguousarray(dTdt, dtype=cubes[0].cpu().numpy().dtype)).to(dev)
-        self.result: LECResult = self.engine.compute(cubes[0], cubes[1], cubes[2], cubes[3], cubes[4], self.boxes,
-                                                     time_s=data.time_s if dTdt is None else None, dTdt=dTdt_dev,
-                                                     phi_scale=phi_scale)
-        torch.cuda.synchronize(dev)
-        self.scalars = self.result.scalars_dict()
-        self.levels = self.result.levels_dict()
-        self.nanflag = self.result.nanflag.cpu().numpy()
+        return self.engine.compute(cubes[0], cubes[1], cubes[2], cubes[3], cubes[4], self.boxes,
+                                   time_s=data.time_s if dTdt is None else None, dTdt=dTdt_dev, phi_scale=phi_scale)
 
 
 class _Terms:

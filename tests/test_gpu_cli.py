@@ -95,3 +95,15 @@ def test_non_residual_mode_fails_like_the_reference(workdir, golden_dir):
     (workdir / "inputs" / "box_limits").write_text("min_lon;-55\nmax_lon;-36\nmin_lat;-35\nmax_lat;-20\n")
     with pytest.raises(KeyError, match="Friction Velocity"):       # SURVEY B-8: only -r works in the reference
         _main([os.path.join(golden_dir, "Catarina_NCEP-R2.nc"), "-f"])
+
+
+def test_device_ingest_flag_writes_identical_csvs(workdir, golden_dir):
+    """--device-ingest streams the file bytes to the GPU instead of preparing the data on the host: same CSVs, byte for byte."""
+    (workdir / "inputs" / "box_limits").write_text("min_lon;-55\nmax_lon;-36\nmin_lat;-35\nmax_lat;-20\n")
+    infile = os.path.join(golden_dir, "Catarina_NCEP-R2.nc")
+    _main([infile, "-r", "-f", "-o", "host"])
+    _main([infile, "-r", "-f", "--device-ingest", "-o", "device"])
+    out = workdir / "LEC_Results" / "Catarina_NCEP-R2_fixed"
+    assert (out / "host.csv").read_bytes() == (out / "device.csv").read_bytes()
+    a = pd.read_csv(out / "device.csv", index_col=0)
+    assert len(a) == 36 and np.isfinite(a.values).all()

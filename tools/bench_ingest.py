@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive rate of the device ingest at the headline grid (37 x 721 x 1440): host memory -> pinned ->
+GPU -> lec_ingest -> lec_rowstats per chunk -> one lec_reduce.  Not the bench.py metric (that one has the
+inputs resident in HBM); DESIGN.md quotes this number next to it.
+
+  python tools/bench_ingest.py --src i16 --timesteps 16 --chunk 4
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--src", choices=["i16", "f32", "f64"], default="i16", help="dtype of the 'file' variables in host memory")
+    ap.add_argument("--timesteps", type=int, default=16)
+    ap.add_argument("--chunk", type=int, default=4)
+    ap.add_argument("--repeat", type=int, default=3)
+    ap.add_argument("--ny", type=int, default=721)
+    ap.add_argument("--nx", type=int, default=1440)
+    args = ap.parse_args()
+    import pandas as pd
+    import torch
+    from lorenzcycletoolkit_amd import dataset as ds
+    from lorenzcycletoolkit_amd import ingest
+    from lorenzcycletoolkit_amd.synthetic import era5_like_levels, synthetic_cube
+
+    dev = torch.device("cuda:0")
+    level = era5_like_levels()
+    lat = np.linspace(-90.0, 90.0, args.ny)
+    lon = np.linspace(-180.0, 180.0 - 360.0 / args.nx, args.nx)
+    T = args.timesteps
+    # the "file": ERA5 axis conventions (lat N -> S, lon 0..360, levels in hPa from the top down), big-endian
+    file_lat, file_lon = lat[::-1].copy(), np.where(lon < 0, lon + 360.0, lon)
+    lon_order = np.argsort(file_lon, kind="stable")
+    file_lon = file_lon[lon_order]
+    file_lev = (level / 100.0)
+    names = {"Air Temperature": "t", "Eastward Wind Component": "u", "Northward Wind Component": "v",
+             "Omega Velocity": "w", "Geopotential": "z", "Longitude": "longitude", "Latitude": "latitude",
+             "Time": "time", "Vertical Level": "level"}
+    variables = {}
+    keys = {"t": "tair", "u": "u", "v": "v", "w": "omega", "z": "geopt"}
+    lon_idx = torch.as_tensor(lon_order, device=dev)
+    for t0 in range(0, T, 4):
+        n = min(4, T - t0)
+        f = synthetic_cube(n, level, lat, lon, device=dev, dtype=torch.float64, seed=1234, t0_global=t0)
+        for name, key in keys.items():
+            a = f[key].flip(2).index_select(3, lon_idx)          # file order of lat / lon
+            if args.src == "i16":
+                if t0 == 0:
+                    lo, hi = float(a.min()) - 1.0, float(a.max()) + 1.0
+                    variables[name] = dict(scale=(hi - lo) / 64000.0, offset=0.5 * (hi + lo), parts=[])
+                v = variables[name]
+                q = torch.clamp(torch.round((a - v["offset"]) / v["scale"]), -32000, 32000).to(torch.int16)
+                v["parts"].append(q.cpu().numpy())
+            else:
+                variables.setdefault(name, dict(scale=None, offset=None, parts=[]))["parts"].append(
+                    a.to(torch.float32 if args.src == "f32" else torch.float64).cpu().numpy())
+        del f
+    torch.cuda.empty_cache()
+    raw_vars = {}
+    for name, v in variables.items():
+        a = np.concatenate(v["parts"], axis=0)
+        be = a.astype(a.dtype.newbyteorder(">"))                   # classic NetCDF stores big-endian
+        raw_vars[name] = ds.RawVariable(be, v["scale"], v["offset"], -32767.0 if args.src == "i16" else None)
+    time = np.datetime64("2020-01-01T00", "ns") + (np.arange(T) * 3600 * 10 ** 9).astype("timedelta64[ns]")
+    raw = ds.RawDataset(raw_vars, file_lat, file_lon, file_lev, time, names, "hPa", "Geopotential")
+    px = ds.process_index(raw.lat, raw.lon, raw.level, raw.time, raw.level_units, raw.names, argparse.Namespace(track=False))
+    i32 = lambda x: np.ascontiguousarray(x, dtype=np.int32)
+    plan = ingest.IngestPlan(np.arange(T), i32(px.ik), i32(px.ij), i32(px.io), px.lat, px.lon, px.level, px.time)
+    assert np.allclose(plan.lat, lat) and np.allclose(plan.lon, lon)
+    df = pd.DataFrame({"Variable": list(names.values()), "Units": ["K", "m/s", "m/s", "Pa/s", "m**2/s**2", "", "", "", ""]},
+                      index=list(names.keys()))
+    limits = (lon[0], lon[-1], lat[0], lat[-1])
+    best, stats = None, {}
+    for r in range(args.repeat + 1):                               # first pass = warm-up (pinned allocations, page faults)
+        torch.cuda.synchronize()
+        t0 = time_now()
+        res = ingest.lec_fixed_streamed(raw, plan, df, limits, chunk_steps=args.chunk, stats=stats)
+        torch.cuda.synchronize()
+        dt = time_now() - t0
+        if r > 0:
+            best = dt if best is None else min(best, dt)
+    finite = bool(torch.isfinite(res.scalars).all())
+    print(json.dumps({
+        "metric": "LEC timesteps/sec from HOST memory (PCIe-inclusive device ingest), all terms, 37x%dx%d" % (args.ny, args.nx),
+        "value": T / best, "unit": "timesteps/s", "source_dtype": args.src, "timesteps": T, "chunk_steps": args.chunk,
+        "seconds": best, "bytes_moved": stats["bytes_moved"], "host_to_device_GBs": stats["bytes_moved"] / best / 1e9,
+        "storage_on_device": stats["storage"], "host_staging_seconds": stats["host_staging_seconds"], "results_finite": finite}))
+
+
+def time_now():
+    return time.perf_counter()
+
+
+if __name__ == "__main__":
+    main()
