@@ -19,10 +19,6 @@
 #ifndef LEC_MINW_SINGLE
 #define LEC_MINW_SINGLE 4
 #endif
-// waves per SIMD requested for the 384-thread row kernel
-#ifndef LEC_MINW_BIG
-#define LEC_MINW_BIG 3
-#endif
 
 // records an error message (thread-local) and returns `code`
 int lec_set_error(int code, const char* msg);

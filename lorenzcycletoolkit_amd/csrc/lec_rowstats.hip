@@ -38,7 +38,7 @@ constexpr int lec_min_waves() {
 #if LEC_MINW > 0
     return LEC_MINW;
 #else
-    return (NTHR > 256) ? LEC_MINW_BIG : ((ITERS > 3) ? 1 : (sizeof(TIN) == 4 ? 3 : (MODE == 0 ? 4 : 1)));
+    return (ITERS > 3) ? 1 : (sizeof(TIN) == 4 ? 3 : (MODE == 0 ? 4 : 1));
 #endif
 }
 
@@ -288,13 +288,10 @@ template <typename TIN, int VEC>
 int launch_vec(const RowParams& p, bool uniform, int mode, int nblocks, hipStream_t st) {
     // vectors needed to cover the longest row, plus one for the alignment shift
     const int nvec = (p.nxb_max + VEC - 1) / VEC + (VEC > 1 ? 1 : 0);
-    const char* eb = getenv("LEC_BLOCK");          // experiments: 384-thread workgroups, 2 vectors per lane
-    const int big = eb ? atoi(eb) : 0;
     if (nvec <= 64) launch_cfg<TIN, VEC, 64, 1>(p, uniform, mode, nblocks, st);
     else if (nvec <= 128) launch_cfg<TIN, VEC, 128, 1>(p, uniform, mode, nblocks, st);
     else if (nvec <= 256) launch_cfg<TIN, VEC, 256, 1>(p, uniform, mode, nblocks, st);
     else if (nvec <= 512) launch_cfg<TIN, VEC, 256, 2>(p, uniform, mode, nblocks, st);
-    else if (nvec <= 768 && big == 384) launch_cfg<TIN, VEC, 384, 2>(p, uniform, mode, nblocks, st);
     else if (nvec <= 768) launch_cfg<TIN, VEC, 256, 3>(p, uniform, mode, nblocks, st);
     else if (nvec <= 1024) launch_cfg<TIN, VEC, 256, 4>(p, uniform, mode, nblocks, st);
     else if (nvec <= 1536) launch_cfg<TIN, VEC, 256, 6>(p, uniform, mode, nblocks, st);
