@@ -11,7 +11,7 @@ namespace lec {
 constexpr double kCp = LEC_CP_D;
 
 // ---------------------------------------------------------------------------------------------
-// vector loads: VEC elements of TIN -> double[VEC]
+// vector loads: VEC elements of TIN -> TO[VEC] (TO = double, or TIN itself to keep the raw values and convert at use)
 // ---------------------------------------------------------------------------------------------
 template <typename TIN, int VEC>
 struct VecLoad;
@@ -22,8 +22,8 @@ typedef float flt4_t __attribute__((ext_vector_type(4)));
 // NT = nontemporal (streaming) load: the line is not kept in L2 ahead of re-used rows
 template <>
 struct VecLoad<double, 2> {
-    template <bool NT>
-    static __device__ __forceinline__ void load(const double* p, double (&o)[2]) {
+    template <bool NT, typename TO>
+    static __device__ __forceinline__ void load(const double* p, TO (&o)[2]) {
         const dbl2_t* q = reinterpret_cast<const dbl2_t*>(p);
         const dbl2_t v = NT ? __builtin_nontemporal_load(q) : *q;
         o[0] = v.x; o[1] = v.y;
@@ -31,13 +31,13 @@ struct VecLoad<double, 2> {
 };
 template <>
 struct VecLoad<double, 1> {
-    template <bool NT>
-    static __device__ __forceinline__ void load(const double* p, double (&o)[1]) { o[0] = NT ? __builtin_nontemporal_load(p) : *p; }
+    template <bool NT, typename TO>
+    static __device__ __forceinline__ void load(const double* p, TO (&o)[1]) { o[0] = (TO)(NT ? __builtin_nontemporal_load(p) : *p); }
 };
 template <>
 struct VecLoad<float, 4> {
-    template <bool NT>
-    static __device__ __forceinline__ void load(const float* p, double (&o)[4]) {
+    template <bool NT, typename TO>
+    static __device__ __forceinline__ void load(const float* p, TO (&o)[4]) {
         const flt4_t* q = reinterpret_cast<const flt4_t*>(p);
         const flt4_t v = NT ? __builtin_nontemporal_load(q) : *q;
         o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
@@ -46,8 +46,8 @@ struct VecLoad<float, 4> {
 typedef float flt2_t __attribute__((ext_vector_type(2)));
 template <>
 struct VecLoad<float, 2> {
-    template <bool NT>
-    static __device__ __forceinline__ void load(const float* p, double (&o)[2]) {
+    template <bool NT, typename TO>
+    static __device__ __forceinline__ void load(const float* p, TO (&o)[2]) {
         const flt2_t* q = reinterpret_cast<const flt2_t*>(p);
         const flt2_t v = NT ? __builtin_nontemporal_load(q) : *q;
         o[0] = v.x; o[1] = v.y;
@@ -55,8 +55,8 @@ struct VecLoad<float, 2> {
 };
 template <>
 struct VecLoad<float, 1> {
-    template <bool NT>
-    static __device__ __forceinline__ void load(const float* p, double (&o)[1]) { o[0] = (double)(NT ? __builtin_nontemporal_load(p) : *p); }
+    template <bool NT, typename TO>
+    static __device__ __forceinline__ void load(const float* p, TO (&o)[1]) { o[0] = (TO)(NT ? __builtin_nontemporal_load(p) : *p); }
 };
 
 // Branch-free row loads.  `e0c` is the lane's first element index clamped so that the 16-byte vector
@@ -68,10 +68,10 @@ struct VecLoad<float, 1> {
 // `rowa` = row pointer moved back to its 16-byte boundary (wave-uniform, lives in SGPRs), `off` = the
 // lane's non-negative element offset from it: the loads become `global_load ... v_off, s[base]` with a
 // 32-bit VGPR offset instead of a 64-bit per-lane address (saves two VGPRs and a 64-bit add per load).
-template <typename TIN, int VEC, bool NT>
-__device__ __forceinline__ void load_vec(const TIN* __restrict__ rowa, unsigned off, double (&o)[VEC]) {
+template <typename TIN, int VEC, bool NT, typename TO>
+__device__ __forceinline__ void load_vec(const TIN* __restrict__ rowa, unsigned off, TO (&o)[VEC]) {
     const unsigned boff = off * (unsigned)sizeof(TIN);     // 32-bit byte offset: rows are far shorter than 4 GiB
-    VecLoad<TIN, VEC>::template load<NT>(reinterpret_cast<const TIN*>(reinterpret_cast<const char*>(rowa) + boff), o);
+    VecLoad<TIN, VEC>::template load<NT, TO>(reinterpret_cast<const TIN*>(reinterpret_cast<const char*>(rowa) + boff), o);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -232,12 +232,12 @@ int launch_vec(RowParams& p, bool uniform, int mode, int nblocks, hipStream_t st
 }  // namespace
 
 // `aligned` = every cube base is 16-byte aligned and nx is a multiple of the 16-byte vector;
-// `aligned8` (fp32 only) = 8-byte aligned bases and even nx.  fp32 storage uses float2 vectors: the
-// same two elements per lane and trip as fp64, which is what keeps the kernel at 4 waves/SIMD
-// (float4 needs 163 VGPRs and measured 10 % slower).
+// `aligned8` (fp32 only) = 8-byte aligned bases and even nx.  fp32 storage uses float4 vectors when it can
+// (four elements per lane and trip, operands kept as floats and converted at use: 149 VGPRs, 3 waves/SIMD,
+// 10.7 ms per 64 steps) and float2 otherwise (11.6 ms; LEC_F32VEC=2 forces it).
 int lec_launch_rowsweep(lec::RowParams& p, int dtype, bool aligned, bool aligned8, bool uniform, int mode, int nblocks, hipStream_t st) {
     if (dtype == LEC_F64) return aligned ? launch_vec<double, 2>(p, uniform, mode, nblocks, st) : launch_vec<double, 1>(p, uniform, mode, nblocks, st);
     const char* ev = getenv("LEC_F32VEC");
-    if (aligned && ev && atoi(ev) == 4) return launch_vec<float, 4>(p, uniform, mode, nblocks, st);
+    if (aligned && !(ev && atoi(ev) == 2)) return launch_vec<float, 4>(p, uniform, mode, nblocks, st);
     return aligned8 ? launch_vec<float, 2>(p, uniform, mode, nblocks, st) : launch_vec<float, 1>(p, uniform, mode, nblocks, st);
 }

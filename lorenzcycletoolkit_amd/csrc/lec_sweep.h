@@ -19,7 +19,7 @@ constexpr int sweep_min_waves() {
 #if LEC_MINW > 0
     return LEC_MINW;
 #else
-    return (sizeof(TIN) == 4 && MODE != 0 && VEC == 4) ? LEC_MINW_SINGLE - 1 : LEC_MINW_SINGLE;
+    return (sizeof(TIN) == 4 && MODE != 0 && VEC == 4) ? LEC_MINW_SINGLE - 1 : LEC_MINW_SINGLE;   // float4 all-terms: 149 VGPRs, 3 waves (a 128 cap spills: 13.4 vs 10.7 ms)
 #endif
 }
 
@@ -123,6 +123,9 @@ __device__ __forceinline__ void sweep_elems(double (&acc)[kNA], const SweepRow& 
             if (EDGE) f = inside ? f : 0.0;
         }
         accum20<UNIFORM && !EDGE>(acc, w, Tv - r.cT, Uv - r.cU, Vv - r.cV, Wv - r.cW, Pv - r.cP, f);
+        // four-element vectors: finish one element before starting the next, or the scheduler interleaves all four and
+        // their temporaries push the kernel past 128 VGPRs
+        if (VEC > 2) __builtin_amdgcn_sched_barrier(0);
     }
 }
 
