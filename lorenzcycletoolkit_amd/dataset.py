@@ -238,11 +238,14 @@ class RawDataset:
 
     def close(self):
         if self._nc is not None:
+            import warnings
             self.variables.clear()
-            try:
-                self._nc.close()
-            except Exception:       # scipy refuses to close while views of the map are alive; the map goes with them
-                pass
+            with warnings.catch_warnings():     # scipy warns when views of the map are still alive; the map goes with them
+                warnings.simplefilter("ignore", RuntimeWarning)
+                try:
+                    self._nc.close()
+                except Exception:
+                    pass
             self._nc = None
 
 

@@ -130,12 +130,16 @@ class _Stager:
         n = len(file_steps)
         if n == 0:
             return
-        flat = self.var.data.reshape(self.var.data.shape[0], -1)
+        # one time step of a variable is contiguous in the file even when the time axis is the record dimension
+        # (record variables are interleaved per record): never reshape across time, that would copy the variable
         as_bytes = lambda a: a.view(a.dtype.newbyteorder("=")).view(self._carrier_np)     # reinterpret, never convert
         jobs = []
         piece = max(1, (8 << 20) // self.itemsize)                  # ~8 MiB per copy job: memcpy releases the GIL
         for r, ft in enumerate(file_steps):
-            src, out = as_bytes(flat[ft]), dst[at + r]
+            block = self.var.data[int(ft)]
+            if not block.flags["C_CONTIGUOUS"]:
+                raise ValueError("the device ingest needs each time step of a variable to be contiguous in the file")
+            src, out = as_bytes(block.reshape(-1)), dst[at + r]
             for a in range(0, self.step_elems, piece):
                 jobs.append((out[a: a + piece], src[a: a + piece]))
         if len(jobs) == 1:
