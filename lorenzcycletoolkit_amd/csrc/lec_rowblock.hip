@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(64 * BT * BK * BJ, LEC_MINW_SINGLE) lec_rowblo
     constexpr int NW = BT * BK * BJ;
     __shared__ double red[NW][kHalf * red_stride(64)];
     __shared__ double tot[NW][24];
-    __shared__ __attribute__((aligned(16))) double xch[2][NW][64 * VEC];
+    __shared__ __attribute__((aligned(16))) TIN xch[2][NW][64 * VEC];
 
     // wave-uniform: everything derived from the wave index stays in SGPRs
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -127,22 +127,24 @@ __global__ void __launch_bounds__(64 * BT * BK * BJ, LEC_MINW_SINGLE) lec_rowblo
 #pragma unroll
     for (int s = 0; s < kNA; ++s) acc[s] = 0.0;
 
+    QCoef qc;
+    qc.t0 = cT0; qc.t1 = cT1; qc.tm = tb; qc.k0 = cK0; qc.k1 = cK1; qc.km = be; qc.j0 = cJ0; qc.j1 = cJ1; qc.jm = gb;
+
     auto trip = [&](auto edge_tag, const int it) {
         constexpr bool EDGE = decltype(edge_tag)::value;
         const int el = it * 64 * VEC - shift;                // box element of lane 0 (wave-uniform)
         const int e0 = el + tid * VEC;
         const bool lane_in = !EDGE || (e0 <= e0_last);
         const unsigned eo = (unsigned)((EDGE ? min(e0, e0_last) : e0) + shift);
-        double fT[VEC], fU[VEC], fV[VEC], fW[VEC], fP[VEC];
-        double xt0[VEC], xk0[VEC], xj0[VEC], xt1[VEC], xk1[VEC], xj1[VEC];
-        double sT[VEC], sP[VEC], sS[VEC];
+        TIN fT[VEC], fU[VEC], fV[VEC], fW[VEC], fP[VEC];
+        QRaw<TIN, VEC> qr;                                    // x0 = the outer (global) neighbour, x1 = the other side
         load_vec<TIN, VEC, false>(rT - shift, eo, fT);       // first: the block mates wait for it
-        load_vec<TIN, VEC, false>(gT0 - shift, eo, xt0);
-        load_vec<TIN, VEC, false>(gK0 - shift, eo, xk0);
-        load_vec<TIN, VEC, false>(gJ0 - shift, eo, xj0);
-        if (BT == 1) load_vec<TIN, VEC, false>(rTtp - shift, eo, xt1);
-        if (BK == 1) load_vec<TIN, VEC, false>(rTkp - shift, eo, xk1);
-        if (BJ == 1) load_vec<TIN, VEC, false>(rTjp - shift, eo, xj1);
+        load_vec<TIN, VEC, false>(gT0 - shift, eo, qr.t0);
+        load_vec<TIN, VEC, false>(gK0 - shift, eo, qr.k0);
+        load_vec<TIN, VEC, false>(gJ0 - shift, eo, qr.j0);
+        if (BT == 1) load_vec<TIN, VEC, false>(rTtp - shift, eo, qr.t1);
+        if (BK == 1) load_vec<TIN, VEC, false>(rTkp - shift, eo, qr.k1);
+        if (BJ == 1) load_vec<TIN, VEC, false>(rTjp - shift, eo, qr.j1);
         load_vec<TIN, VEC, true>(rU - shift, eo, fU);
         load_vec<TIN, VEC, true>(rV - shift, eo, fV);
         load_vec<TIN, VEC, true>(rW - shift, eo, fW);
@@ -152,31 +154,25 @@ __global__ void __launch_bounds__(64 * BT * BK * BJ, LEC_MINW_SINGLE) lec_rowblo
         const int ir = EDGE ? min(max(el + 64 * VEC, 0), nxb - 1) : el + 64 * VEC;
         const double tl0 = (double)rT[il], tr0 = (double)rT[ir];
 
-        // publish the own T vector, read the block mates'
+        // publish the own T vector (storage type), read the block mates'
         if (NW > 1) {
-            double* mine = &xch[it & 1][wave][tid * VEC];
+            TIN* mine = &xch[it & 1][wave][tid * VEC];
 #pragma unroll
             for (int q2 = 0; q2 < VEC; ++q2) mine[q2] = fT[q2];
             lds_barrier();
-            const double* mt = &xch[it & 1][mateT][tid * VEC];
-            const double* mk = &xch[it & 1][mateK][tid * VEC];
-            const double* mj = &xch[it & 1][mateJ][tid * VEC];
+            const TIN* mt = &xch[it & 1][mateT][tid * VEC];
+            const TIN* mk = &xch[it & 1][mateK][tid * VEC];
+            const TIN* mj = &xch[it & 1][mateJ][tid * VEC];
 #pragma unroll
             for (int q2 = 0; q2 < VEC; ++q2) {
-                if (BT == 2) xt1[q2] = mt[q2];
-                if (BK == 2) xk1[q2] = mk[q2];
-                if (BJ == 2) xj1[q2] = mj[q2];
+                if (BT == 2) qr.t1[q2] = mt[q2];
+                if (BK == 2) qr.k1[q2] = mk[q2];
+                if (BJ == 2) qr.j1[q2] = mj[q2];
             }
         }
-        const double tl_edge = from_prev_lane(fT[VEC - 1], tl0);
-        const double tr_edge = from_next_lane(fT[0], tr0);
-#pragma unroll
-        for (int q2 = 0; q2 < VEC; ++q2) {
-            sT[q2] = stencil3(cT0, xt0[q2], cT1, xt1[q2], tb, fT[q2]);
-            sP[q2] = stencil3(cJ0, xj0[q2], cJ1, xj1[q2], gb, fT[q2]);
-            sS[q2] = stencil3(cK0, xk0[q2], cK1, xk1[q2], be, fT[q2]);
-        }
-        sweep_elems<VEC, UNIFORM, EDGE, true>(acc, r, e0, lane_in, fT, fU, fV, fW, fP, tl_edge, tr_edge, sT, sP, sS);
+        const double tl_edge = from_prev_lane((double)fT[VEC - 1], tl0);
+        const double tr_edge = from_next_lane((double)fT[0], tr0);
+        sweep_elems<VEC, UNIFORM, EDGE, 1>(acc, r, e0, lane_in, fT, fU, fV, fW, fP, tl_edge, tr_edge, qr, qc);
     };
 
     // every wave of the block runs the same trips (same box row geometry): the LDS barriers stay matched

@@ -95,7 +95,6 @@ __global__ void __launch_bounds__(kThreads, (sweep_min_waves<TIN, VEC, MODE>()))
     const TIN* __restrict__ rV = (const TIN*)p.V + rowoff;
     const TIN* __restrict__ rW = (const TIN*)p.W + rowoff;
     const TIN* __restrict__ rP = (const TIN*)(p.P ? p.P : p.T) + rowoff;
-    const double phimul = p.P ? 1.0 : 0.0;
     const bool has_p = (MODE != 0) || (p.P != nullptr);
 
     const double inv_xlen = p.boxtab[4 * bi + 0];
@@ -129,7 +128,7 @@ __global__ void __launch_bounds__(kThreads, (sweep_min_waves<TIN, VEC, MODE>()))
     SweepRow r;
     r.nxb = nxb;
     r.cT = (double)rT[0]; r.cU = (double)rU[0]; r.cV = (double)rV[0]; r.cW = (double)rW[0];
-    r.cP = has_p ? (double)rP[0] * phimul : 0.0;
+    r.cP = (has_p && p.P) ? (double)rP[0] : 0.0;
     r.cx = 0.5 * inv_hdeg * inv_dx; r.inv_dx = inv_dx; r.wl = wl; r.gl = gl;
     // T, u, v at the east box column (boundary terms), fetched now so that the row does not end on a load
     const double eT = (double)rT[nxb - 1], eU = (double)rU[nxb - 1], eV = (double)rV[nxb - 1];
@@ -138,58 +137,49 @@ __global__ void __launch_bounds__(kThreads, (sweep_min_waves<TIN, VEC, MODE>()))
 #pragma unroll
     for (int s = 0; s < kNA; ++s) acc[s] = 0.0;
 
-    // one trip = one vector of every row operand per lane; EDGE trips hold a row end or lanes past it
+    QCoef qc;
+    qc.t0 = ta; qc.t1 = tc; qc.tm = tb; qc.k0 = al; qc.k1 = gm; qc.km = be; qc.j0 = ga; qc.j1 = gc; qc.jm = gb;
+
+    // one trip = one vector of every row operand per lane; EDGE trips hold a row end or lanes past it.
+    // Operands stay in their storage type (TIN) and are converted where they are used.
     auto trip = [&](auto edge_tag, const int it) {
         constexpr bool EDGE = decltype(edge_tag)::value;
         const int el = it * nthr * VEC - shift;              // box element of lane 0 (wave-uniform)
         const int e0 = el + tid * VEC;
         const bool lane_in = !EDGE || (e0 <= e0_last);
         const unsigned eo = (unsigned)((EDGE ? min(e0, e0_last) : e0) + shift);
-        double fT[VEC], fU[VEC], fV[VEC], fW[VEC], fP[VEC];
-        double tjm[VEC], tjp[VEC], tkm[VEC], tkp[VEC], tm[VEC], tp[VEC];
-        double sT[VEC], sP[VEC], sS[VEC];
+        TIN fT[VEC], fU[VEC], fV[VEC], fW[VEC], fP[VEC];
+        QRaw<TIN, VEC> qr;
         double tl_edge = 0.0, tr_edge = 0.0;
         load_vec<TIN, VEC, MODE == 0>(rT - shift, eo, fT);
         load_vec<TIN, VEC, true>(rU - shift, eo, fU);
         load_vec<TIN, VEC, true>(rV - shift, eo, fV);
         load_vec<TIN, VEC, true>(rW - shift, eo, fW);
-        if (has_p) {
-            load_vec<TIN, VEC, true>(rP - shift, eo, fP);
+        if (has_p) load_vec<TIN, VEC, true>(rP - shift, eo, fP);
+        if (!has_p || !p.P) {                                // no geopotential cube: its statistics are written as 0
 #pragma unroll
-            for (int q = 0; q < VEC; ++q) fP[q] *= phimul;
-        } else {
-#pragma unroll
-            for (int q = 0; q < VEC; ++q) fP[q] = 0.0;
+            for (int q = 0; q < VEC; ++q) fP[q] = (TIN)0;
         }
         if (WITH_Q) {
-            load_vec<TIN, VEC, false>(rTjm - shift, eo, tjm);
-            load_vec<TIN, VEC, false>(rTjp - shift, eo, tjp);
-            load_vec<TIN, VEC, false>(rTkm - shift, eo, tkm);
-            load_vec<TIN, VEC, false>(rTkp - shift, eo, tkp);
+            load_vec<TIN, VEC, false>(rTjm - shift, eo, qr.j0);
+            load_vec<TIN, VEC, false>(rTjp - shift, eo, qr.j1);
+            load_vec<TIN, VEC, false>(rTkm - shift, eo, qr.k0);
+            load_vec<TIN, VEC, false>(rTkp - shift, eo, qr.k1);
             if (p.order == 7) {      // tiled order: the T[t+-1] rows are own rows of sibling workgroups -> keep them cacheable
-                load_vec<TIN, VEC, false>(rTtm - shift, eo, tm);
-                if (MODE == 1) load_vec<TIN, VEC, false>(rTtp - shift, eo, tp);
+                load_vec<TIN, VEC, false>(rTtm - shift, eo, qr.t0);
+                if (MODE == 1) load_vec<TIN, VEC, false>(rTtp - shift, eo, qr.t1);
             } else {
-                load_vec<TIN, VEC, true>(rTtm - shift, eo, tm);
-                if (MODE == 1) load_vec<TIN, VEC, true>(rTtp - shift, eo, tp);
+                load_vec<TIN, VEC, true>(rTtm - shift, eo, qr.t0);
+                if (MODE == 1) load_vec<TIN, VEC, true>(rTtp - shift, eo, qr.t1);
             }
             // in-row neighbours T[i-1], T[i+1]: from the adjacent lanes' registers (DPP); the elements beyond the
             // wave's two end lanes are at wave-uniform addresses: scalar loads
             const int il = EDGE ? min(max(el - 1, 0), nxb - 1) : el - 1;
             const int ir = EDGE ? min(max(el + nthr * VEC, 0), nxb - 1) : el + nthr * VEC;
-            tl_edge = from_prev_lane(fT[VEC - 1], (double)rT[il]);
-            tr_edge = from_next_lane(fT[0], (double)rT[ir]);
-#pragma unroll
-            for (int q = 0; q < VEC; ++q) {
-                sT[q] = (MODE == 1) ? stencil3(ta, tm[q], tc, tp[q], tb, fT[q]) : tm[q];
-                sP[q] = stencil3(ga, tjm[q], gc, tjp[q], gb, fT[q]);
-                sS[q] = stencil3(al, tkm[q], gm, tkp[q], be, fT[q]);
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < VEC; ++q) sT[q] = sP[q] = sS[q] = 0.0;
+            tl_edge = from_prev_lane((double)fT[VEC - 1], (double)rT[il]);
+            tr_edge = from_next_lane((double)fT[0], (double)rT[ir]);
         }
-        sweep_elems<VEC, UNIFORM, EDGE, WITH_Q>(acc, r, e0, lane_in, fT, fU, fV, fW, fP, tl_edge, tr_edge, sT, sP, sS);
+        sweep_elems<VEC, UNIFORM, EDGE, MODE>(acc, r, e0, lane_in, fT, fU, fV, fW, fP, tl_edge, tr_edge, qr, qc);
     };
 
     // a real loop (not unrolled): the live state stays at the 20 accumulators plus one vector's worth of
@@ -233,8 +223,8 @@ int launch_vec(RowParams& p, bool uniform, int mode, int nblocks, hipStream_t st
 
 // `aligned` = every cube base is 16-byte aligned and nx is a multiple of the 16-byte vector;
 // `aligned8` (fp32 only) = 8-byte aligned bases and even nx.  fp32 storage uses float4 vectors when it can
-// (four elements per lane and trip, operands kept as floats and converted at use: 149 VGPRs, 3 waves/SIMD,
-// 10.7 ms per 64 steps) and float2 otherwise (11.6 ms; LEC_F32VEC=2 forces it).
+// (four elements per lane and trip, operands kept as floats and converted at use, one element finished before the
+// next starts: 141 VGPRs, 3 waves/SIMD, 10.5 ms per 64 steps) and float2 otherwise (11.0 ms; LEC_F32VEC=2 forces it).
 int lec_launch_rowsweep(lec::RowParams& p, int dtype, bool aligned, bool aligned8, bool uniform, int mode, int nblocks, hipStream_t st) {
     if (dtype == LEC_F64) return aligned ? launch_vec<double, 2>(p, uniform, mode, nblocks, st) : launch_vec<double, 1>(p, uniform, mode, nblocks, st);
     const char* ev = getenv("LEC_F32VEC");

@@ -81,17 +81,25 @@ struct SweepRow {
     const double* gl;               // table longitudes: d/dlon coefficients
 };
 
+// T neighbours of the diabatic-heating stencils as loaded (raw storage type, converted at use), and their
+// wave-uniform coefficients: per dimension x0 / x1 are the two neighbours in whatever order the kernel fetched
+// them, cm multiplies the centre value
+template <typename OP, int VEC>
+struct QRaw { OP t0[VEC], t1[VEC], k0[VEC], k1[VEC], j0[VEC], j1[VEC]; };
+struct QCoef { double t0, t1, tm, k0, k1, km, j0, j1, jm; };
+
 // One vector (VEC consecutive longitudes starting at box element e0) of every operand -> the 20 sums.
 //   EDGE = false: every element of the trip lies strictly inside the row (1 <= e <= nxb - 2): no selects,
 //                 and with uniform longitudes the weight is the constant 1 (the row epilogue multiplies by h).
 //   EDGE = true : the first / last trips: half weights at the row ends, lanes outside the row contribute 0.
+//   QMODE: 0 no Q; 1 dT/dt = tm T + t0 T[t0] + t1 T[t1] (time stencil); 2 dT/dt read from a cube (in qr.t0).
 // With uniform longitudes the sums carry RELATIVE trapezoid weights (1, 1/2, 0); Q is accumulated without
-// the factor cp (applied in the epilogue).  sT, sP, sS: dT/dt, dT/dy and the static-stability stencil.
-template <int VEC, bool UNIFORM, bool EDGE, bool WITH_Q>
+// the factor cp (applied in the epilogue).  Operands arrive in their storage type OP and are converted here.
+template <int VEC, bool UNIFORM, bool EDGE, int QMODE, typename OP>
 __device__ __forceinline__ void sweep_elems(double (&acc)[kNA], const SweepRow& r, int e0, bool lane_in,
-                                            const double (&fT)[VEC], const double (&fU)[VEC], const double (&fV)[VEC],
-                                            const double (&fW)[VEC], const double (&fP)[VEC], double tl_edge, double tr_edge,
-                                            const double (&sT)[VEC], const double (&sP)[VEC], const double (&sS)[VEC]) {
+                                            const OP (&fT)[VEC], const OP (&fU)[VEC], const OP (&fV)[VEC],
+                                            const OP (&fW)[VEC], const OP (&fP)[VEC], double tl_edge, double tr_edge,
+                                            const QRaw<OP, VEC>& qr, const QCoef& qc) {
 #pragma clang fp contract(off)
 #pragma unroll
     for (int q = 0; q < VEC; ++q) {
@@ -101,15 +109,16 @@ __device__ __forceinline__ void sweep_elems(double (&acc)[kNA], const SweepRow& 
         double w = 1.0;
         if (UNIFORM) { if (EDGE) w = inside ? ((first || last) ? 0.5 : 1.0) : 0.0; }
         else w = EDGE ? (inside ? r.wl[min(max(e, 0), r.nxb - 1)] : 0.0) : r.wl[e];
-        const double Tv = inside ? fT[q] : r.cT;
-        const double Uv = inside ? fU[q] : r.cU;
-        const double Vv = inside ? fV[q] : r.cV;
-        const double Wv = inside ? fW[q] : r.cW;
-        const double Pv = inside ? fP[q] : r.cP;
+        const double Tc = (double)fT[q];
+        const double Tv = inside ? Tc : r.cT;
+        const double Uv = inside ? (double)fU[q] : r.cU;
+        const double Vv = inside ? (double)fV[q] : r.cV;
+        const double Wv = inside ? (double)fW[q] : r.cW;
+        const double Pv = inside ? (double)fP[q] : r.cP;
         double f = 0.0;
-        if (WITH_Q) {
-            const double Tl = (q == 0) ? tl_edge : fT[q > 0 ? q - 1 : 0];
-            const double Tr = (q == VEC - 1) ? tr_edge : fT[q < VEC - 1 ? q + 1 : q];
+        if (QMODE != 0) {
+            const double Tl = (q == 0) ? tl_edge : (double)fT[q > 0 ? q - 1 : 0];
+            const double Tr = (q == VEC - 1) ? tr_edge : (double)fT[q < VEC - 1 ? q + 1 : q];
             double adv;                                     // u dT/dx
             if (UNIFORM) {
                 double d = Tr - Tl;
@@ -119,7 +128,10 @@ __device__ __forceinline__ void sweep_elems(double (&acc)[kNA], const SweepRow& 
                 const int ec = EDGE ? min(max(e, 0), r.nxb - 1) : e;
                 adv = Uv * fma(r.gl[3 * ec + 2], Tr, fma(r.gl[3 * ec + 1], Tv, r.gl[3 * ec + 0] * Tl)) * r.inv_dx;
             }
-            f = fma(-Wv, sS[q], fma(Vv, sP[q], sT[q] + adv));
+            const double sT = (QMODE == 1) ? stencil3(qc.t0, (double)qr.t0[q], qc.t1, (double)qr.t1[q], qc.tm, Tc) : (double)qr.t0[q];
+            const double sP = stencil3(qc.j0, (double)qr.j0[q], qc.j1, (double)qr.j1[q], qc.jm, Tc);
+            const double sS = stencil3(qc.k0, (double)qr.k0[q], qc.k1, (double)qr.k1[q], qc.km, Tc);
+            f = fma(-Wv, sS, fma(Vv, sP, sT + adv));
             if (EDGE) f = inside ? f : 0.0;
         }
         accum20<UNIFORM && !EDGE>(acc, w, Tv - r.cT, Uv - r.cU, Vv - r.cV, Wv - r.cW, Pv - r.cP, f);
