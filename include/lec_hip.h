@@ -68,7 +68,7 @@ enum lec_stat {
     LEC_S_WU = 12, LEC_S_WV, LEC_S_WP, LEC_S_QT,                         /* [w'u'] [w'v'] [w'Phi'] [Q'T'] */
     LEC_S_VTT = 16, LEC_S_WTT, LEC_S_KV, LEC_S_KW, LEC_S_EV, LEC_S_EW,   /* [vT'T'] [wT'T'] [Kv] [Kw] [Ev] [Ew] */
     LEC_S_TW = 22, LEC_S_TE, LEC_S_UW, LEC_S_UE, LEC_S_VW, LEC_S_VE,     /* T,u,v at the west / east box column */
-    LEC_S_SPARE = 28
+    LEC_S_SPARE = 28    /* 28..31: scratch of lec_rowstats (cross-time covariance pieces), not an interface */
 };
 
 /*

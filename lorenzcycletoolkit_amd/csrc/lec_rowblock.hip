@@ -10,7 +10,8 @@
 // what limits this configuration (profiles/r01_notes.md).
 //
 // The stencils are linear, so which side comes from LDS only swaps coefficients (wave-uniform, hoisted
-// out of the loop); no per-lane selects.  Waves whose row lies outside the processed range still walk
+// out of the loop); no per-lane selects.  In time only T(t+1) is needed (cross-time covariance, see
+// sweep_elems): the earlier wave of a time pair reads it from its mate, the later one loads it.  Waves whose row lies outside the processed range still walk
 // a real neighbouring row (the halo time step of a shard, the next XCD's first latitude) so that their
 // block mates read correct data; they just do not store.
 #include <hip/hip_runtime.h>
@@ -94,22 +95,18 @@ __global__ void __launch_bounds__(64 * BT * BK * BJ, LEC_MINW_SINGLE) lec_rowblo
     const double ga = lt[0], gb = lt[1], gc = lt[2], inv_dx = lt[3];
     const double* lv = p.levtab + (size_t)k * 3;
     const double al = lv[0], be = lv[1], gm = lv[2];
-    const double* tcf = p.tcoef + (size_t)t * 3;
-    const double ta = tcf[0], tb = tcf[1], tc = tcf[2];
     const TIN* rTjm = (jb > 0) ? rT - p.nx : rT;
     const TIN* rTjp = (jb < nyb - 1) ? rT + p.nx : rT;
     const TIN* rTkm = (k > 0) ? rT - plane : rT;
     const TIN* rTkp = (k < p.nl - 1) ? rT + plane : rT;
-    const TIN* rTtm = (t > 0) ? rT - cube : rT;
     const TIN* rTtp = (t < p.nt - 1) ? rT + cube : rT;
 
     // per dimension: B == 1 -> both neighbours global (g0 = minus, g1 = plus);
     // B == 2 -> g0 = the outer neighbour (global), the inner one is the block mate's row in LDS
-    const TIN* gT0 = (BT == 1 || wt == 0) ? rTtm : rTtp;  const double cT0 = (BT == 1 || wt == 0) ? ta : tc;
+    const bool fwd_global = (BT == 1) || (wt == BT - 1);      // T(t+1): a global load, or the time mate's row in LDS
     const TIN* gK0 = (BK == 1 || wk == 0) ? rTkm : rTkp;  const double cK0 = (BK == 1 || wk == 0) ? al : gm;
     const TIN* gJ0 = (BJ == 1 || wj == 0) ? rTjm : rTjp;  const double cJ0 = (BJ == 1 || wj == 0) ? ga : gc;
-    const double cT1 = (BT == 1 || wt == 0) ? tc : ta;    // coefficient of the other side (global if B == 1, LDS if B == 2)
-    const double cK1 = (BK == 1 || wk == 0) ? gm : al;
+    const double cK1 = (BK == 1 || wk == 0) ? gm : al;    // coefficient of the other side (global if B == 1, LDS if B == 2)
     const double cJ1 = (BJ == 1 || wj == 0) ? gc : ga;
     const int mateT = (BT == 2) ? (wt == 0 ? wave + 1 : wave - 1) : wave;
     const int mateK = (BK == 2) ? (wk == 0 ? wave + BT : wave - BT) : wave;
@@ -120,15 +117,18 @@ __global__ void __launch_bounds__(64 * BT * BK * BJ, LEC_MINW_SINGLE) lec_rowblo
     r.nxb = nxb;
     r.cT = (double)rT[0]; r.cU = (double)rU[0]; r.cV = (double)rV[0]; r.cW = (double)rW[0]; r.cP = (double)rP[0];
     r.cx = 0.5 * inv_hdeg * inv_dx; r.inv_dx = inv_dx; r.wl = wl; r.gl = gl;
+    r.cTf = (double)rTtp[0]; r.cTb = 0.0;
     // T, u, v at the east box column (boundary terms), fetched now so that the row does not end on a load
     const double eT = (double)rT[nxb - 1], eU = (double)rU[nxb - 1], eV = (double)rV[nxb - 1];
 
-    double acc[kNA];
+    double acc[kNA], xacc[kNX];
 #pragma unroll
     for (int s = 0; s < kNA; ++s) acc[s] = 0.0;
+#pragma unroll
+    for (int s = 0; s < kNX; ++s) xacc[s] = 0.0;
 
     QCoef qc;
-    qc.t0 = cT0; qc.t1 = cT1; qc.tm = tb; qc.k0 = cK0; qc.k1 = cK1; qc.km = be; qc.j0 = cJ0; qc.j1 = cJ1; qc.jm = gb;
+    qc.k0 = cK0; qc.k1 = cK1; qc.km = be; qc.j0 = cJ0; qc.j1 = cJ1; qc.jm = gb;
 
     auto trip = [&](auto edge_tag, const int it) {
         constexpr bool EDGE = decltype(edge_tag)::value;
@@ -139,10 +139,9 @@ __global__ void __launch_bounds__(64 * BT * BK * BJ, LEC_MINW_SINGLE) lec_rowblo
         TIN fT[VEC], fU[VEC], fV[VEC], fW[VEC], fP[VEC];
         QRaw<TIN, VEC> qr;                                    // x0 = the outer (global) neighbour, x1 = the other side
         load_vec<TIN, VEC, false>(rT - shift, eo, fT);       // first: the block mates wait for it
-        load_vec<TIN, VEC, false>(gT0 - shift, eo, qr.t0);
+        if (fwd_global) load_vec<TIN, VEC, false>(rTtp - shift, eo, qr.tf);
         load_vec<TIN, VEC, false>(gK0 - shift, eo, qr.k0);
         load_vec<TIN, VEC, false>(gJ0 - shift, eo, qr.j0);
-        if (BT == 1) load_vec<TIN, VEC, false>(rTtp - shift, eo, qr.t1);
         if (BK == 1) load_vec<TIN, VEC, false>(rTkp - shift, eo, qr.k1);
         if (BJ == 1) load_vec<TIN, VEC, false>(rTjp - shift, eo, qr.j1);
         load_vec<TIN, VEC, true>(rU - shift, eo, fU);
@@ -165,14 +164,14 @@ __global__ void __launch_bounds__(64 * BT * BK * BJ, LEC_MINW_SINGLE) lec_rowblo
             const TIN* mj = &xch[it & 1][mateJ][tid * VEC];
 #pragma unroll
             for (int q2 = 0; q2 < VEC; ++q2) {
-                if (BT == 2) qr.t1[q2] = mt[q2];
+                if (BT == 2 && !fwd_global) qr.tf[q2] = mt[q2];
                 if (BK == 2) qr.k1[q2] = mk[q2];
                 if (BJ == 2) qr.j1[q2] = mj[q2];
             }
         }
         const double tl_edge = from_prev_lane((double)fT[VEC - 1], tl0);
         const double tr_edge = from_next_lane((double)fT[0], tr0);
-        sweep_elems<VEC, UNIFORM, EDGE, 1>(acc, r, e0, lane_in, fT, fU, fV, fW, fP, tl_edge, tr_edge, qr, qc);
+        sweep_elems<VEC, UNIFORM, EDGE, 3, false>(acc, xacc, r, e0, lane_in, fT, fU, fV, fW, fP, tl_edge, tr_edge, qr, qc);
     };
 
     // every wave of the block runs the same trips (same box row geometry): the LDS barriers stay matched
@@ -184,7 +183,7 @@ __global__ void __launch_bounds__(64 * BT * BK * BJ, LEC_MINW_SINGLE) lec_rowblo
 #pragma unroll 1
     for (int it = max(mid_end, 1); it < ntrips; ++it) trip(std::true_type{}, it);
 
-    finish_row<64, kHalf>(acc, red[wave], tot[wave], tid, UNIFORM ? h_rad * inv_xlen : inv_xlen, r.cT, r.cU, r.cV, r.cW, r.cP, out, store);
+    finish_row<64, kHalf, true>(acc, xacc, red[wave], tot[wave], tid, UNIFORM ? h_rad * inv_xlen : inv_xlen, r, out, store);
     if (store && tid == 0) {
         out[LEC_S_TW] = r.cT; out[LEC_S_UW] = r.cU; out[LEC_S_VW] = r.cV;
         out[LEC_S_TE] = eT; out[LEC_S_UE] = eU; out[LEC_S_VE] = eV;
@@ -225,7 +224,7 @@ int launch_block(RowParams& p, int bt, int bk, int bj, hipStream_t st) {
 
 // all terms, dT/dt from the cube, ONE fixed box, Phi present, fp64 or fp32 storage; p.tgroup / p.jgroup are the
 // tile extents in cells (blocks of bt time steps / bj latitudes)
-int lec_launch_rowblock(lec::RowParams& p, int dtype, bool aligned, bool aligned8, bool uniform, int bt, int bk, int bj, hipStream_t st) {
+int lec_launch_rowblock(lec::RowParams p, int dtype, bool aligned, bool aligned8, bool uniform, int bt, int bk, int bj, hipStream_t st) {
     if (dtype == LEC_F64) {
         if (aligned) return uniform ? launch_block<double, 2, true>(p, bt, bk, bj, st) : launch_block<double, 2, false>(p, bt, bk, bj, st);
         return uniform ? launch_block<double, 1, true>(p, bt, bk, bj, st) : launch_block<double, 1, false>(p, bt, bk, bj, st);

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/lec_hip.h"
 #include "lec_internal.h"
 
 namespace lec {
@@ -145,6 +146,14 @@ struct RowParams {
     int cpx;     // sweep kernel: latitude chunks per XCD
 };
 
+
+// the same launch without its first time step (fixed box only: per-step box tables are indexed by the local step)
+inline RowParams later_steps(const RowParams& p) {
+    RowParams q = p;
+    q.t_begin += 1; q.t_count -= 1;
+    q.rows += (size_t)p.nl * p.nyb_max * LEC_NSTAT;
+    return q;
+}
 
 }  // namespace lec
 #endif

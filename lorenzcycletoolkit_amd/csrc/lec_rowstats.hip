@@ -304,8 +304,9 @@ int launch_vec(const RowParams& p, bool uniform, int mode, int nblocks, hipStrea
 
 static bool kernel_is_two_sweep() { const char* ek = getenv("LEC_KERNEL"); return ek && atoi(ek) == 0; }
 
-int lec_launch_rowsweep(lec::RowParams& p, int dtype, bool aligned, bool aligned8, bool uniform, int mode, int nblocks, hipStream_t st);
-int lec_launch_rowblock(lec::RowParams& p, int dtype, bool aligned, bool aligned8, bool uniform, int bt, int bk, int bj, hipStream_t st);
+int lec_launch_rowsweep(const lec::RowParams& p, int dtype, bool aligned, bool aligned8, bool uniform, int mode, bool first_only, hipStream_t st);
+int lec_launch_rowblock(lec::RowParams p, int dtype, bool aligned, bool aligned8, bool uniform, int bt, int bk, int bj, hipStream_t st);
+int lec_launch_qtime(const lec::RowParams& p, hipStream_t st);
 
 extern "C" int lec_max_row(int dtype, int aligned) {
     (void)dtype;
@@ -387,16 +388,26 @@ extern "C" int lec_rowstats(const lec_rowstats_args* a) {
     // an independent formulation (deviation from the zonal mean, then products) for cross-checks
     const char* ek = getenv("LEC_KERNEL");
     const int kernel = ek ? atoi(ek) : 1;
-    // all terms with dT/dt from the cube on one fixed box (the headline configuration): row-block kernel, 2 time steps x
-    // 2 latitudes per workgroup (lec_rowblock.hip; measured 17.6-17.9 vs 18.4 ms per 64 steps for one wave per row).
-    // LEC_BLK=<bt><bk><bj> picks another block shape, LEC_BLK=0 the one-wave-per-row kernel (bit-identical results).
+    // Single-sweep kernels (default).  All terms with dT/dt from the cube on one fixed box (the headline configuration):
+    // a row reads T(t+1) only and the time-derivative parts of [Q], [Q'T'] are completed from the records afterwards
+    // (lec_qtime_kernel); the first time step goes to the one-wave-per-row kernel and the rest to the
+    // row-block kernel, 2 time steps x 2 latitudes per workgroup (lec_rowblock.hip; fp64 storage: 17.6-17.9 vs 18.4 ms
+    // per 64 steps).  LEC_BLK=<bt><bk><bj> picks another block shape, LEC_BLK=0 the one-wave-per-row kernel everywhere
+    // (bit-identical results).
     const char* eblk = getenv("LEC_BLK");
-    const int blk = eblk ? atoi(eblk) : (a->dtype == LEC_F64 ? 212 : 0);     // fp32 storage: no gain measured (11.9 vs 11.7 ms)
-    if (kernel == 1 && blk > 0 && wq == 1 && a->n_box == 1 && a->geopt_d && a->t_count >= 2 && !getenv("LEC_ORDER")) {
-        const char* etg = getenv("LEC_TG"); const char* ejg = getenv("LEC_JG");
-        p.order = 8; p.tgroup = etg ? atoi(etg) : 2; p.jgroup = ejg ? atoi(ejg) : 4;      // tile: 2 x 4 blocks at one level, levels next
-        rc = lec_launch_rowblock(p, a->dtype, aligned, aligned8, uni, blk / 100, (blk / 10) % 10, blk % 10, st);
-    } else if (kernel == 1) rc = lec_launch_rowsweep(p, a->dtype, aligned, aligned8, uni, wq, (int)nblocks, st);
+    const int blk = eblk ? atoi(eblk) : (a->dtype == LEC_F64 ? 212 : 0);     // fp32 storage: no gain measured
+    if (kernel == 1) {
+        const int mode = (wq == 1 && a->n_box == 1) ? 3 : wq;       // time stencil on one fixed box: through cross-time covariances
+        const bool block_ok = blk > 0 && mode == 3 && a->geopt_d && a->t_count >= 2 && !getenv("LEC_ORDER");
+        rc = lec_launch_rowsweep(p, a->dtype, aligned, aligned8, uni, mode, block_ok, st);
+        if (rc == LEC_OK && block_ok) {
+            RowParams pb = later_steps(p);
+            const char* etg = getenv("LEC_TG"); const char* ejg = getenv("LEC_JG");
+            pb.order = 8; pb.tgroup = etg ? atoi(etg) : 2; pb.jgroup = ejg ? atoi(ejg) : 4;      // tile: 2 x 4 blocks at one level, levels next
+            rc = lec_launch_rowblock(pb, a->dtype, aligned, aligned8, uni, blk / 100, (blk / 10) % 10, blk % 10, st);
+        }
+        if (rc == LEC_OK && mode == 3) rc = lec_launch_qtime(p, st);
+    }
     else if (a->dtype == LEC_F64) rc = aligned ? launch_vec<double, 2>(p, uni, wq, (int)nblocks, st) : launch_vec<double, 1>(p, uni, wq, (int)nblocks, st);
     else                     rc = aligned ? launch_vec<float, 4>(p, uni, wq, (int)nblocks, st) : launch_vec<float, 1>(p, uni, wq, (int)nblocks, st);
     if (rc != LEC_OK) return lec_set_error(rc, "lec_rowstats: row too long for the compiled kernels");

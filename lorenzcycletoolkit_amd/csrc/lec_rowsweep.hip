@@ -31,10 +31,14 @@ namespace {
 
 constexpr int kThreads = 64; // one wave per row: measured best (64 / 128 / 256 threads: 19.0 / 19.1 / 20.1 ms per 64 steps)
 // one workgroup per (time, level, box-latitude) row, ONE sweep over the row (see the header comment)
-template <typename TIN, int VEC, bool UNIFORM, int MODE, bool ONE_TRIP>
+// MODE: 0 no Q; 1 dT/dt from the cube's time neighbours per point; 2 dT/dt cube; 3 as 1 on one fixed box, through
+// cross-time covariances (sweep_elems).  BOTH (MODE 3 only): the row also forms the covariance with T(t-1) -- the first
+// processed time step of a launch
+template <typename TIN, int VEC, bool UNIFORM, int MODE, bool ONE_TRIP, bool BOTH>
 __global__ void __launch_bounds__(kThreads, (sweep_min_waves<TIN, VEC, MODE>())) lec_rowsweep_kernel(const RowParams p) {
     constexpr int NTHR = kThreads;
     constexpr bool WITH_Q = MODE != 0;
+    constexpr bool TIME_NB = (MODE == 1 || MODE == 3);      // reads T at t+1 (and t-1)
     constexpr int nthr = NTHR;
     __shared__ double red[kHalf * red_stride(NTHR)];
     __shared__ double tot[24];
@@ -119,8 +123,10 @@ __global__ void __launch_bounds__(kThreads, (sweep_min_waves<TIN, VEC, MODE>()))
         } else {
             if (t > 0) rTtm = rT - cube;
             if (t < p.nt - 1) rTtp = rT + cube;
-            const double* tcf = p.tcoef + (size_t)t * 3;
-            ta = tcf[0]; tb = tcf[1]; tc = tcf[2];
+            if (MODE == 1) {
+                const double* tcf = p.tcoef + (size_t)t * 3;
+                ta = tcf[0]; tb = tcf[1]; tc = tcf[2];
+            }
         }
     }
 
@@ -130,15 +136,19 @@ __global__ void __launch_bounds__(kThreads, (sweep_min_waves<TIN, VEC, MODE>()))
     r.cT = (double)rT[0]; r.cU = (double)rU[0]; r.cV = (double)rV[0]; r.cW = (double)rW[0];
     r.cP = (has_p && p.P) ? (double)rP[0] : 0.0;
     r.cx = 0.5 * inv_hdeg * inv_dx; r.inv_dx = inv_dx; r.wl = wl; r.gl = gl;
+    r.cTf = (MODE == 3) ? (double)rTtp[0] : 0.0;
+    r.cTb = (MODE == 3 && BOTH) ? (double)rTtm[0] : 0.0;
     // T, u, v at the east box column (boundary terms), fetched now so that the row does not end on a load
     const double eT = (double)rT[nxb - 1], eU = (double)rU[nxb - 1], eV = (double)rV[nxb - 1];
 
-    double acc[kNA];
+    double acc[kNA], xacc[kNX];
 #pragma unroll
     for (int s = 0; s < kNA; ++s) acc[s] = 0.0;
+#pragma unroll
+    for (int s = 0; s < kNX; ++s) xacc[s] = 0.0;
 
     QCoef qc;
-    qc.t0 = ta; qc.t1 = tc; qc.tm = tb; qc.k0 = al; qc.k1 = gm; qc.km = be; qc.j0 = ga; qc.j1 = gc; qc.jm = gb;
+    qc.tb_ = ta; qc.tf_ = tc; qc.tm = tb; qc.k0 = al; qc.k1 = gm; qc.km = be; qc.j0 = ga; qc.j1 = gc; qc.jm = gb;
 
     // one trip = one vector of every row operand per lane; EDGE trips hold a row end or lanes past it.
     // Operands stay in their storage type (TIN) and are converted where they are used.
@@ -165,12 +175,14 @@ __global__ void __launch_bounds__(kThreads, (sweep_min_waves<TIN, VEC, MODE>()))
             load_vec<TIN, VEC, false>(rTjp - shift, eo, qr.j1);
             load_vec<TIN, VEC, false>(rTkm - shift, eo, qr.k0);
             load_vec<TIN, VEC, false>(rTkp - shift, eo, qr.k1);
-            if (p.order == 7) {      // tiled order: the T[t+-1] rows are own rows of sibling workgroups -> keep them cacheable
-                load_vec<TIN, VEC, false>(rTtm - shift, eo, qr.t0);
-                if (MODE == 1) load_vec<TIN, VEC, false>(rTtp - shift, eo, qr.t1);
+            // MODE 3: T(t+1) for the cross-time covariance (T(t-1) too when BOTH); MODE 1: both; MODE 2: the dT/dt cube (rTtm points into it).
+            // Tiled order: the T(t+1) row is the own row of a sibling workgroup -> keep it cacheable
+            if (TIME_NB) {
+                if (p.order == 7) load_vec<TIN, VEC, false>(rTtp - shift, eo, qr.tf);
+                else load_vec<TIN, VEC, true>(rTtp - shift, eo, qr.tf);
+                if (MODE == 1 || BOTH) load_vec<TIN, VEC, true>(rTtm - shift, eo, qr.tb);
             } else {
-                load_vec<TIN, VEC, true>(rTtm - shift, eo, qr.t0);
-                if (MODE == 1) load_vec<TIN, VEC, true>(rTtp - shift, eo, qr.t1);
+                load_vec<TIN, VEC, true>(rTtm - shift, eo, qr.tf);
             }
             // in-row neighbours T[i-1], T[i+1]: from the adjacent lanes' registers (DPP); the elements beyond the
             // wave's two end lanes are at wave-uniform addresses: scalar loads
@@ -179,7 +191,7 @@ __global__ void __launch_bounds__(kThreads, (sweep_min_waves<TIN, VEC, MODE>()))
             tl_edge = from_prev_lane((double)fT[VEC - 1], (double)rT[il]);
             tr_edge = from_next_lane((double)fT[0], (double)rT[ir]);
         }
-        sweep_elems<VEC, UNIFORM, EDGE, MODE>(acc, r, e0, lane_in, fT, fU, fV, fW, fP, tl_edge, tr_edge, qr, qc);
+        sweep_elems<VEC, UNIFORM, EDGE, MODE, BOTH>(acc, xacc, r, e0, lane_in, fT, fU, fV, fW, fP, tl_edge, tr_edge, qr, qc);
     };
 
     // a real loop (not unrolled): the live state stays at the 20 accumulators plus one vector's worth of
@@ -194,7 +206,7 @@ __global__ void __launch_bounds__(kThreads, (sweep_min_waves<TIN, VEC, MODE>()))
         for (int it = max(mid_end, 1); it < ntrips; ++it) trip(std::true_type{}, it);
     }
 
-    finish_row<NTHR, kHalf>(acc, red, tot, tid, UNIFORM ? h_rad * inv_xlen : inv_xlen, r.cT, r.cU, r.cV, r.cW, r.cP, out);
+    finish_row<NTHR, kHalf, MODE == 3>(acc, xacc, red, tot, tid, UNIFORM ? h_rad * inv_xlen : inv_xlen, r, out);
     // T, u, v at the west / east box columns (boundary terms): wave-uniform scalar loads
     if (tid == 0) {
         out[LEC_S_TW] = r.cT; out[LEC_S_UW] = r.cU; out[LEC_S_VW] = r.cV;
@@ -202,21 +214,69 @@ __global__ void __launch_bounds__(kThreads, (sweep_min_waves<TIN, VEC, MODE>()))
     }
 }
 
-template <typename TIN, int VEC>
-int launch_vec(RowParams& p, bool uniform, int mode, int nblocks, hipStream_t st) {
+// Completes [Q] and [Q'T'] of the time-stencil mode from the row records: the time-derivative part of Q is linear in
+// T(t-1), T(t), T(t+1), so  [Q] += cp (ta [T](t-1) + tb [T](t) + tc [T](t+1))  and
+// [Q'T'] += cp (ta [T'(t)T'(t-1)] + tb [T'T'] + tc [T'(t)T'(t+1)]).  The backward pieces are the previous row's
+// forward ones when that row was processed in this launch, else the row's own (slots 30, 31).  One fixed box only.
+__global__ void __launch_bounds__(256) lec_qtime_kernel(const RowParams p) {
+#pragma clang fp contract(off)
+    const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long per_t = (long long)p.nl * p.nyb_max;
+    if (row >= per_t * p.t_count) return;
+    const int tl = (int)(row / per_t);
+    double* __restrict__ rec = p.rows + (size_t)row * LEC_NSTAT;
+    const bool from_prev = tl > 0;
+    const double* __restrict__ prev = rec - (size_t)per_t * LEC_NSTAT;
+    const double mtb = from_prev ? prev[LEC_S_MT] : rec[LEC_S_SPARE + 3];
+    const double cb = from_prev ? prev[LEC_S_SPARE + 0] : rec[LEC_S_SPARE + 2];
+    const double* tcf = p.tcoef + (size_t)(p.t_begin + tl) * 3;
+    const double ta = tcf[0], tb = tcf[1], tc = tcf[2];
+    const double dm = (ta * mtb + tc * rec[LEC_S_SPARE + 1]) + tb * rec[LEC_S_MT];
+    const double dc = (ta * cb + tc * rec[LEC_S_SPARE + 0]) + tb * rec[LEC_S_TT];
+    rec[LEC_S_MQ] = rec[LEC_S_MQ] + kCp * dm;
+    rec[LEC_S_QT] = rec[LEC_S_QT] + kCp * dc;
+}
+
+// workgroups (= rows, rounded up to whole XCD chunks / tiles) of a launch over p.t_count time steps; 0 = too many
+long long grid_blocks(const RowParams& p) {
+    long long n;
+    if (p.order == 0) n = (long long)p.t_count * p.nl * p.nyb_max;
+    else if (p.order == 7) {
+        const long long tgc = (p.t_count + p.tgroup - 1) / p.tgroup, jgc = (p.jchunk + p.jgroup - 1) / p.jgroup;
+        n = 8LL * jgc * tgc * p.nl * p.tgroup * p.jgroup;
+    } else n = (long long)p.t_count * 8 * p.jchunk * p.nl;
+    return n > 0x7fffffffLL ? 0 : n;
+}
+
+template <typename TIN, int VEC, bool BOTH>
+int launch_one(RowParams p, bool uniform, int mode, hipStream_t st) {
     // vectors needed to cover the longest row, plus one for the alignment shift; one wave walks them in trips of 64
     const int nvec = (p.nxb_max + VEC - 1) / VEC + (VEC > 1 ? 1 : 0);
     p.ntrips = (nvec + kThreads - 1) / kThreads;
-    dim3 grid(nblocks), block(kThreads);
-#define LEC_LAUNCH(U, M) do { if (p.ntrips == 1) hipLaunchKernelGGL((lec_rowsweep_kernel<TIN, VEC, U, M, true>), grid, block, 0, st, p); \
-                              else hipLaunchKernelGGL((lec_rowsweep_kernel<TIN, VEC, U, M, false>), grid, block, 0, st, p); } while (0)
-    if (uniform) {
-        if (mode == 0) LEC_LAUNCH(true, 0); else if (mode == 1) LEC_LAUNCH(true, 1); else LEC_LAUNCH(true, 2);
-    } else {
-        if (mode == 0) LEC_LAUNCH(false, 0); else if (mode == 1) LEC_LAUNCH(false, 1); else LEC_LAUNCH(false, 2);
-    }
+    if (p.order == 7 && p.t_count < 2) p.order = 2;
+    long long nblocks = grid_blocks(p);
+    if (nblocks == 0) { p.order = 0; nblocks = grid_blocks(p); }
+    if (nblocks == 0) return LEC_ERR_UNSUPPORTED;
+    dim3 grid((unsigned)nblocks), block(kThreads);
+#define LEC_LAUNCH(U, M) do { if (p.ntrips == 1) hipLaunchKernelGGL((lec_rowsweep_kernel<TIN, VEC, U, M, true, BOTH && M == 3>), grid, block, 0, st, p); \
+                              else hipLaunchKernelGGL((lec_rowsweep_kernel<TIN, VEC, U, M, false, BOTH && M == 3>), grid, block, 0, st, p); } while (0)
+#define LEC_MODES(U) do { if (mode == 0) LEC_LAUNCH(U, 0); else if (mode == 1) LEC_LAUNCH(U, 1); else if (mode == 2) LEC_LAUNCH(U, 2); else LEC_LAUNCH(U, 3); } while (0)
+    if (uniform) LEC_MODES(true); else LEC_MODES(false);
+#undef LEC_MODES
 #undef LEC_LAUNCH
     return LEC_OK;
+}
+
+// mode 3 (time stencil on one fixed box): the first time step of the launch forms both cross-time covariances, the
+// others only the forward one (`first_only`: the row-block kernel takes the rest)
+template <typename TIN, int VEC>
+int launch_vec(const RowParams& p, bool uniform, int mode, bool first_only, hipStream_t st) {
+    if (mode != 3) return launch_one<TIN, VEC, false>(p, uniform, mode, st);
+    RowParams p0 = p;
+    p0.t_count = 1;
+    int rc = launch_one<TIN, VEC, true>(p0, uniform, mode, st);
+    if (rc != LEC_OK || first_only || p.t_count < 2) return rc;
+    return launch_one<TIN, VEC, false>(later_steps(p), uniform, mode, st);
 }
 
 }  // namespace
@@ -225,9 +285,15 @@ int launch_vec(RowParams& p, bool uniform, int mode, int nblocks, hipStream_t st
 // `aligned8` (fp32 only) = 8-byte aligned bases and even nx.  fp32 storage uses float4 vectors when it can
 // (four elements per lane and trip, operands kept as floats and converted at use, one element finished before the
 // next starts: 141 VGPRs, 3 waves/SIMD, 10.5 ms per 64 steps) and float2 otherwise (11.0 ms; LEC_F32VEC=2 forces it).
-int lec_launch_rowsweep(lec::RowParams& p, int dtype, bool aligned, bool aligned8, bool uniform, int mode, int nblocks, hipStream_t st) {
-    if (dtype == LEC_F64) return aligned ? launch_vec<double, 2>(p, uniform, mode, nblocks, st) : launch_vec<double, 1>(p, uniform, mode, nblocks, st);
+int lec_launch_rowsweep(const lec::RowParams& p, int dtype, bool aligned, bool aligned8, bool uniform, int mode, bool first_only, hipStream_t st) {
+    if (dtype == LEC_F64) return aligned ? launch_vec<double, 2>(p, uniform, mode, first_only, st) : launch_vec<double, 1>(p, uniform, mode, first_only, st);
     const char* ev = getenv("LEC_F32VEC");
-    if (aligned && !(ev && atoi(ev) == 2)) return launch_vec<float, 4>(p, uniform, mode, nblocks, st);
-    return aligned8 ? launch_vec<float, 2>(p, uniform, mode, nblocks, st) : launch_vec<float, 1>(p, uniform, mode, nblocks, st);
+    if (aligned && !(ev && atoi(ev) == 2)) return launch_vec<float, 4>(p, uniform, mode, first_only, st);
+    return aligned8 ? launch_vec<float, 2>(p, uniform, mode, first_only, st) : launch_vec<float, 1>(p, uniform, mode, first_only, st);
+}
+
+int lec_launch_qtime(const lec::RowParams& p, hipStream_t st) {
+    const long long rows = (long long)p.t_count * p.nl * p.nyb_max;
+    hipLaunchKernelGGL(lec_qtime_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, p);
+    return LEC_OK;
 }

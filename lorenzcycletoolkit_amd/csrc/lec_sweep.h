@@ -75,6 +75,7 @@ __device__ __forceinline__ void accum20(double (&acc)[kNA], double w, double a, 
 struct SweepRow {
     int nxb;                        // box points in the row
     double cT, cU, cV, cW, cP;      // shifts: the row's first box element
+    double cTf, cTb;                // the same for the T rows one time step ahead / back (cross-time covariances)
     double cx;                      // uniform longitudes: 0.5 / h_deg / dx_j  (centred d/dlon -> d/dx)
     double inv_dx;                  // table longitudes: 1 / dx_j
     const double* wl;               // table longitudes: trapezoid weights
@@ -83,20 +84,29 @@ struct SweepRow {
 
 // T neighbours of the diabatic-heating stencils as loaded (raw storage type, converted at use), and their
 // wave-uniform coefficients: per dimension x0 / x1 are the two neighbours in whatever order the kernel fetched
-// them, cm multiplies the centre value
+// them, cm multiplies the centre value.  tf / tb: the T row one time step ahead / back.
 template <typename OP, int VEC>
-struct QRaw { OP t0[VEC], t1[VEC], k0[VEC], k1[VEC], j0[VEC], j1[VEC]; };
-struct QCoef { double t0, t1, tm, k0, k1, km, j0, j1, jm; };
+struct QRaw { OP tf[VEC], tb[VEC], k0[VEC], k1[VEC], j0[VEC], j1[VEC]; };
+struct QCoef { double tb_, tf_, tm, k0, k1, km, j0, j1, jm; };      // tb_ / tf_ multiply T(t-1) / T(t+1) (QMODE 1)
+
+constexpr int kNX = 4;      // cross-time sums: <a a+>, <a+>, <a a->, <a->
 
 // One vector (VEC consecutive longitudes starting at box element e0) of every operand -> the 20 sums.
 //   EDGE = false: every element of the trip lies strictly inside the row (1 <= e <= nxb - 2): no selects,
 //                 and with uniform longitudes the weight is the constant 1 (the row epilogue multiplies by h).
 //   EDGE = true : the first / last trips: half weights at the row ends, lanes outside the row contribute 0.
-//   QMODE: 0 no Q; 1 dT/dt = tm T + t0 T[t0] + t1 T[t1] (time stencil); 2 dT/dt read from a cube (in qr.t0).
+//   QMODE: 0 no Q;
+//          1 dT/dt = ta T(t-1) + tb T(t) + tc T(t+1) per point (moving boxes: the neighbours in time sum over other boxes);
+//          2 dT/dt read from a cube (in qr.tf): f = Q / cp complete;
+//          3 (one fixed box) the same dT/dt as 1, but NOT formed per point: f holds only the
+//            advective and static-stability parts; the time-derivative parts of [Q] and [Q'T'] are linear in T(t+-1),
+//            so they follow from the zonal means and the cross-time covariances [T'(t) T'(t+1)], [T'(t) T'(t-1)]
+//            (lec_qtime_kernel).  A row therefore reads T(t+1) only -- the covariance with T(t-1) is the previous
+//            row's forward covariance; BOTH: the row has no processed predecessor and forms the backward one too.
 // With uniform longitudes the sums carry RELATIVE trapezoid weights (1, 1/2, 0); Q is accumulated without
 // the factor cp (applied in the epilogue).  Operands arrive in their storage type OP and are converted here.
-template <int VEC, bool UNIFORM, bool EDGE, int QMODE, typename OP>
-__device__ __forceinline__ void sweep_elems(double (&acc)[kNA], const SweepRow& r, int e0, bool lane_in,
+template <int VEC, bool UNIFORM, bool EDGE, int QMODE, bool BOTH, typename OP>
+__device__ __forceinline__ void sweep_elems(double (&acc)[kNA], double (&xacc)[kNX], const SweepRow& r, int e0, bool lane_in,
                                             const OP (&fT)[VEC], const OP (&fU)[VEC], const OP (&fV)[VEC],
                                             const OP (&fW)[VEC], const OP (&fP)[VEC], double tl_edge, double tr_edge,
                                             const QRaw<OP, VEC>& qr, const QCoef& qc) {
@@ -115,6 +125,7 @@ __device__ __forceinline__ void sweep_elems(double (&acc)[kNA], const SweepRow& 
         const double Vv = inside ? (double)fV[q] : r.cV;
         const double Wv = inside ? (double)fW[q] : r.cW;
         const double Pv = inside ? (double)fP[q] : r.cP;
+        const double a = Tv - r.cT;
         double f = 0.0;
         if (QMODE != 0) {
             const double Tl = (q == 0) ? tl_edge : (double)fT[q > 0 ? q - 1 : 0];
@@ -128,28 +139,46 @@ __device__ __forceinline__ void sweep_elems(double (&acc)[kNA], const SweepRow& 
                 const int ec = EDGE ? min(max(e, 0), r.nxb - 1) : e;
                 adv = Uv * fma(r.gl[3 * ec + 2], Tr, fma(r.gl[3 * ec + 1], Tv, r.gl[3 * ec + 0] * Tl)) * r.inv_dx;
             }
-            const double sT = (QMODE == 1) ? stencil3(qc.t0, (double)qr.t0[q], qc.t1, (double)qr.t1[q], qc.tm, Tc) : (double)qr.t0[q];
             const double sP = stencil3(qc.j0, (double)qr.j0[q], qc.j1, (double)qr.j1[q], qc.jm, Tc);
             const double sS = stencil3(qc.k0, (double)qr.k0[q], qc.k1, (double)qr.k1[q], qc.km, Tc);
-            f = fma(-Wv, sS, fma(Vv, sP, sT + adv));
+            double rest = adv;
+            if (QMODE == 1) rest = stencil3(qc.tb_, (double)qr.tb[q], qc.tf_, (double)qr.tf[q], qc.tm, Tc) + adv;
+            if (QMODE == 2) rest = (double)qr.tf[q] + adv;
+            f = fma(-Wv, sS, fma(Vv, sP, rest));
             if (EDGE) f = inside ? f : 0.0;
+            if (QMODE == 3) {
+                // the product a * a+ is rounded before it is weighted, so the row at t and the row at t+1 (as its backward
+                // covariance) form bit-identical sums: results do not depend on where a shard or a chunk starts
+                const double af = inside ? (double)qr.tf[q] - r.cTf : 0.0;
+                const double pf = a * af;
+                if (UNIFORM && !EDGE) { xacc[0] += pf; xacc[1] += af; }
+                else { xacc[0] = fma(w, pf, xacc[0]); xacc[1] = fma(w, af, xacc[1]); }
+                if (BOTH) {
+                    const double ab = inside ? (double)qr.tb[q] - r.cTb : 0.0;
+                    const double pb = a * ab;
+                    if (UNIFORM && !EDGE) { xacc[2] += pb; xacc[3] += ab; }
+                    else { xacc[2] = fma(w, pb, xacc[2]); xacc[3] = fma(w, ab, xacc[3]); }
+                }
+            }
         }
-        accum20<UNIFORM && !EDGE>(acc, w, Tv - r.cT, Uv - r.cU, Vv - r.cV, Wv - r.cW, Pv - r.cP, f);
+        accum20<UNIFORM && !EDGE>(acc, w, a, Uv - r.cU, Vv - r.cV, Wv - r.cW, Pv - r.cP, f);
         // four-element vectors: finish one element before starting the next, or the scheduler interleaves all four and
         // their temporaries push the kernel past 128 VGPRs
         if (VEC > 2) __builtin_amdgcn_sched_barrier(0);
     }
 }
 
-// block sums of the accumulators (two rounds through the same LDS tile), scaled by `scale` (1 / xlength,
+// block sums of the accumulators (rounds through the same LDS tile), scaled by `scale` (1 / xlength,
 // times the longitude step when the sums carry relative weights), then the centred
-// statistics from the shifted sums (lanes 0..21) written to the row record.  Ends with every read of
-// `red` / `tot` complete only after the caller's next barrier.
-template <int NTHR, int NR = kHalf>
-__device__ __forceinline__ void finish_row(const double (&acc)[kNA], double* red, double* tot, int tid, double scale,
-                                           double cT, double cU, double cV, double cW, double cP, double* __restrict__ out,
-                                           bool store = true) {
+// statistics from the shifted sums (lanes 0..21) written to the row record.  XCOV: the cross-time sums go to the
+// record's scratch slots 28..31 as [T'(t)T'(t+1)], [T](t+1), [T'(t)T'(t-1)], [T](t-1) for lec_qtime_kernel.
+// Contraction is off: the epilogue must give the same bits in every kernel instantiation.
+template <int NTHR, int NR = kHalf, bool XCOV = false>
+__device__ __forceinline__ void finish_row(const double (&acc)[kNA], const double (&xacc)[kNX], double* red, double* tot, int tid,
+                                           double scale, const SweepRow& r, double* __restrict__ out, bool store = true) {
+#pragma clang fp contract(off)
     constexpr int rshift = red_rshift(NTHR);
+    const double cT = r.cT, cU = r.cU, cV = r.cV, cW = r.cW, cP = r.cP;
 #pragma unroll
     for (int r0 = 0; r0 < kNA; r0 += NR) {      // rounds of NR statistics through the same LDS tile
         double h[NR];
@@ -158,6 +187,11 @@ __device__ __forceinline__ void finish_row(const double (&acc)[kNA], double* red
         const double t0 = block_sums<NR, NTHR>(h, red, tid);
         if ((tid & ((1 << rshift) - 1)) == 0 && (tid >> rshift) < NR && r0 + (tid >> rshift) < kNA)
             tot[r0 + (tid >> rshift)] = t0 * ((r0 + (tid >> rshift) == 5 || r0 + (tid >> rshift) == 15) ? scale * kCp : scale);   // <f>, <fa>: Q = cp f
+        __syncthreads();
+    }
+    if (XCOV) {
+        const double t0 = block_sums<kNX, NTHR>(xacc, red, tid);
+        if ((tid & ((1 << rshift) - 1)) == 0 && (tid >> rshift) < kNX) tot[kNA + (tid >> rshift)] = t0 * scale;
         __syncthreads();
     }
     if (tid < 22) {
@@ -194,7 +228,15 @@ __device__ __forceinline__ void finish_row(const double (&acc)[kNA], double* red
         }
         if (store) out[tid] = o;
     }
-    if (store && tid < 4) out[LEC_S_SPARE + tid] = 0.0;
+    if (store && tid < 4) {
+        double o = 0.0;
+        if (XCOV) {
+            const double da = tot[0];
+            const double x = tot[kNA + (tid & 2)], y = tot[kNA + (tid & 2) + 1];     // forward pair (tid 0, 1), backward pair (tid 2, 3)
+            o = (tid & 1) ? ((tid & 2) ? r.cTb : r.cTf) + y : x - da * y;           // [T] of the neighbour row : centred covariance
+        }
+        out[LEC_S_SPARE + tid] = o;
+    }
 }
 
 }  // namespace lec

@@ -10,6 +10,7 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -24,16 +25,26 @@ rows = list(csv.DictReader(open(stats)))
 with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
     w = csv.DictWriter(f, fieldnames=rows[0].keys())
     w.writeheader()
-    for r in rows[:12]:
-        w.writerow(r)
-row_k = [r for r in rows if "lec_row" in r["Name"]][0]
+    for i, r in enumerate(rows):
+        if i < 12 or "lec_" in r["Name"]:
+            w.writerow(r)
+# stage 1 (one lec_rowstats call) may be several kernels: the first time step on lec_rowsweep_kernel, the rest on
+# lec_rowblock_kernel, then lec_qtime_kernel; the dominant one is reported by name, the call by the sum
+stage1 = [r for r in rows if "lec_row" in r["Name"] or "lec_qtime" in r["Name"]]
+row_k = max(stage1, key=lambda r: float(r["TotalDurationNs"]))
+calls = int(row_k["Calls"])
+stage1_ms = sum(float(r["TotalDurationNs"]) for r in stage1) / calls / 1e6
 
 
 def counter(sub, name):
+    """Counter summed over the stage-1 kernels of one lec_rowstats call (averaged over the calls of the run)."""
     f = glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv"))[0]
-    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
-            if "lec_row" in r["Kernel_Name"] and r["Counter_Name"] == name]
-    return sum(vals) / len(vals), len(vals)
+    per_kernel = {}
+    for r in csv.DictReader(open(f)):
+        if ("lec_row" in r["Kernel_Name"] or "lec_qtime" in r["Kernel_Name"]) and r["Counter_Name"] == name:
+            per_kernel.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
+    n = max(len(v) for v in per_kernel.values())
+    return sum(sum(v) / len(v) for v in per_kernel.values()), n
 
 
 fetch_kb, n = counter("pmc_fetch", "FETCH_SIZE")
@@ -51,6 +62,9 @@ summary = {
     "tag": tag, "storage": storage, "terms": terms,
     "kernel": row_k["Name"],
     "rocprof_avg_launch_ms": float(row_k["AverageNs"]) / 1e6, "rocprof_calls": int(row_k["Calls"]),
+    "stage1_kernels_ms_per_call": {re.search(r"(lec_\w+)", r["Name"]).group(1) + re.sub(r"^[^<]*", "", r["Name"].split("(lec::")[0]):
+                                   float(r["TotalDurationNs"]) / calls / 1e6 for r in stage1},
+    "rocprof_stage1_ms_per_call": stage1_ms,
     "timesteps_per_launch_stats_run": t_stats,
     "bench_event_avg_launch_ms": bench_stats["roofline"]["avg_launch_ms"],
     "pmc_run_timesteps_per_launch": t_pmc, "pmc_dispatches": n,
