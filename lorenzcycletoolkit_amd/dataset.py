@@ -238,15 +238,20 @@ class RawDataset:
 
     def close(self):
         if self._nc is not None:
-            import warnings
             self.variables.clear()
-            with warnings.catch_warnings():     # scipy warns when views of the map are still alive; the map goes with them
-                warnings.simplefilter("ignore", RuntimeWarning)
-                try:
-                    self._nc.close()
-                except Exception:
-                    pass
+            _close_mapped(self._nc)
             self._nc = None
+
+
+def _close_mapped(nc):
+    """Closes a memory-mapped netcdf_file; scipy warns when views of the map are still alive (the map goes with them)."""
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        try:
+            nc.close()
+        except Exception:
+            pass
 
 
 def open_raw(path: str, variable_list_df: pd.DataFrame) -> RawDataset:
@@ -256,10 +261,10 @@ def open_raw(path: str, variable_list_df: pd.DataFrame) -> RawDataset:
     for role in FIELD_ROLES + (geo_role,):
         v = nc.variables[names[role]]
         if tuple(v.dimensions) != want:
-            nc.close()
+            _close_mapped(nc)
             raise ValueError(f"{names[role]} has dimensions {v.dimensions}; the device ingest needs {want} order")
         if v.data.dtype.kind not in "if" or v.data.dtype.itemsize not in (2, 4, 8) or (v.data.dtype.kind == "i" and v.data.dtype.itemsize != 2):
-            nc.close()
+            _close_mapped(nc)
             raise ValueError(f"{names[role]}: the device ingest reads int16, float32 and float64 variables, not {v.data.dtype}")
         scale, offset, fill = _packing(v)
         variables[names[role]] = RawVariable(v.data, scale, offset, fill)

@@ -16,6 +16,7 @@ pytestmark = pytest.mark.gpu
 from lorenzcycletoolkit_amd import dataset as ds
 from lorenzcycletoolkit_amd import ingest
 from lorenzcycletoolkit_amd.frameworks import BoxData
+from tests.helpers import write_packed_era5_style as _write_packed
 
 
 @pytest.fixture
@@ -51,44 +52,6 @@ def test_catarina_streamed_equals_resident(workdir, golden_dir, chunk_steps):
     assert torch.equal(a.scalars, b.scalars)
     assert torch.equal(a.levels, b.levels)
     assert torch.equal(a.nanflag, b.nanflag)
-
-
-def _write_packed(path, nt=7):
-    """ERA5-style file: int16 with scale_factor / add_offset / _FillValue, lon 0..357.5, lat N -> S, levels in hPa
-    from the surface up including 5 hPa (dropped by the >= 10 hPa filter)."""
-    from scipy.io import netcdf_file
-    rng = np.random.default_rng(4)
-    lon = np.arange(0.0, 360.0, 2.5)
-    lat = np.arange(60.0, -62.5, -2.5)
-    lev = np.array([1000, 850, 700, 500, 300, 200, 100, 50, 5], dtype=np.int32)
-    nl, ny, nx = lev.size, lat.size, lon.size
-    f = netcdf_file(path, "w", version=2)
-    for n, s in (("time", nt), ("level", nl), ("latitude", ny), ("longitude", nx)):
-        f.createDimension(n, s)
-    tv = f.createVariable("time", "i", ("time",)); tv[:] = 6 * np.arange(nt); tv.units = "hours since 2020-01-01 00:00:00"
-    lv = f.createVariable("level", "i", ("level",)); lv[:] = lev; lv.units = "millibars"
-    la = f.createVariable("latitude", "f", ("latitude",)); la[:] = lat
-    lo = f.createVariable("longitude", "f", ("longitude",)); lo[:] = lon
-    p = (lev[None, :, None, None] * 100.0) / 1e5
-    fields = {
-        "t": 288.0 * p ** 0.19 + 8.0 * np.cos(np.deg2rad(2 * lat))[None, None, :, None] * p + rng.standard_normal((nt, nl, ny, nx)),
-        "u": 20.0 * np.cos(np.deg2rad(lat))[None, None, :, None] * (1 - p / 1.2) + 5 * rng.standard_normal((nt, nl, ny, nx)),
-        "v": 3.0 * rng.standard_normal((nt, nl, ny, nx)),
-        "w": 0.1 * rng.standard_normal((nt, nl, ny, nx)),
-        "z": 9.80665 * 7000.0 * np.log(1.0 / p) + 100.0 * rng.standard_normal((nt, nl, ny, nx)),
-    }
-    for name, a in fields.items():
-        lo_, hi_ = a.min(), a.max()
-        scale = (hi_ - lo_) / 65000.0
-        offset = 0.5 * (hi_ + lo_)
-        q = np.clip(np.round((a - offset) / scale), -32000, 32000).astype(np.int16)
-        if name == "v":
-            q[2, 7, :, :] = -32767          # 50 hPa = the top kept level, one time step: dropped for the whole series
-            q[4, 3, 10, 20] = -32767        # an interior point: that level is repaired by interpolation at that step
-        v = f.createVariable(name, "h", ("time", "level", "latitude", "longitude"))
-        v[:] = q
-        v.scale_factor = float(scale); v.add_offset = float(offset); v._FillValue = np.int16(-32767)
-    f.close()
 
 
 @pytest.mark.parametrize("chunk_steps", [3, 7])

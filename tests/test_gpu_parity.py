@@ -106,16 +106,16 @@ def test_testdata_moving(golden_dir):
 # synthetic shapes: every kernel configuration
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("nx,dtype,nonuni", [
-    (48, np.float64, False),     # 1 vector per lane, 64-thread blocks
-    (200, np.float64, False),    # 128-thread blocks
-    (300, np.float64, False),    # 256-thread blocks, 1 vector per lane
-    (1000, np.float64, False),   # 256-thread blocks, 2-3 vectors per lane
+    (48, np.float64, False),     # one trip per row (the moving-box instantiation)
+    (200, np.float64, False),    # two trips: an edge trip at either end, no middle trip
+    (300, np.float64, False),    # three trips: one middle trip
+    (1000, np.float64, False),   # 8 trips
     (1001, np.float64, False),   # odd row length -> scalar-load kernel
-    (1800, np.float64, False),   # 4 vectors per lane
-    (2400, np.float64, False),   # 6 vectors per lane
-    (3500, np.float64, False),   # 8 vectors per lane
+    (1800, np.float64, False),
+    (2400, np.float64, False),
+    (3500, np.float64, False),   # 28 trips (beyond the two-sweep kernel's row limit)
     (3500, np.float32, False),
-    (300, np.float32, False),    # float4 loads
+    (300, np.float32, False),    # float4 trips
     (1000, np.float32, False),
     (303, np.float32, False),    # float, unaligned
     (300, np.float64, True),     # non-uniform longitudes: table path

@@ -1,0 +1,101 @@
+"""The host side of the device ingest, without a GPU: the index maps of ingest.make_plan applied with NumPy to the raw
+(memory-mapped, big-endian, possibly packed) file variables must reproduce what the host preparation path
+(open_dataset + process_data + slice_domain) produces, element for element."""
+import argparse
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+from lorenzcycletoolkit_amd import dataset as ds
+from lorenzcycletoolkit_amd import ingest
+
+
+@pytest.fixture
+def workdir(tmp_path, golden_dir, monkeypatch):
+    os.makedirs(tmp_path / "inputs")
+    shutil.copy(os.path.join(golden_dir, "inputs", "namelist_NCEP-R2"), tmp_path / "inputs" / "namelist")
+    monkeypatch.chdir(tmp_path)
+    return tmp_path
+
+
+def _emulate_lec_ingest(var: ds.RawVariable, plan: ingest.IngestPlan) -> np.ndarray:
+    """What lec_ingest_kernel computes (include/lec_hip.h), in NumPy."""
+    raw = np.asarray(var.data)[plan.tsel][:, plan.kmap][:, :, plan.jmap][:, :, :, plan.imap]
+    raw = raw.astype(raw.dtype.newbyteorder("="))
+    out = raw
+    if var.scale_factor is not None or var.add_offset is not None:
+        out = raw.astype(np.float64)
+        out = out * (1.0 if var.scale_factor is None else var.scale_factor)
+        out = out + (0.0 if var.add_offset is None else var.add_offset)
+    if var.fill_value is not None:
+        out = np.where(raw == var.fill_value, np.nan, out.astype(np.float64) if out.dtype.kind == "i" else out)
+    return out
+
+
+def _compare(infile, args):
+    df = ds.read_namelist("inputs/namelist")
+    host = ds.slice_domain(ds.process_data(ds.open_dataset(infile, df), args, df), args, df)
+    raw = ds.open_raw(infile, df)
+    plan = ingest.make_plan(raw, args)
+    assert np.array_equal(plan.lat, host.lat) and np.array_equal(plan.lon, host.lon)
+    assert np.array_equal(plan.level, host.level) and np.array_equal(plan.time, host.time)
+    assert np.all(np.diff(plan.lat) > 0) and np.all(np.diff(plan.lon) > 0) and np.all(np.diff(plan.level) > 0)
+    for name, var in raw.variables.items():
+        got = _emulate_lec_ingest(var, plan)
+        want = host.variables[name]
+        assert got.shape == want.shape and got.dtype == want.dtype, name
+        assert np.array_equal(got, want, equal_nan=True), name
+    raw.close()
+    return plan, host
+
+
+def test_catarina_fixed_plan(workdir, golden_dir):
+    (workdir / "inputs" / "box_limits").write_text("min_lon;-55\nmax_lon;-36\nmin_lat;-35\nmax_lat;-20\n")
+    args = argparse.Namespace(fixed=True, track=False, trackfile=None)
+    plan, host = _compare(os.path.join(golden_dir, "Catarina_NCEP-R2.nc"), args)
+    assert plan.tsel.tolist() == list(range(36))
+
+
+def test_testdata_track_plan(workdir, golden_dir):
+    """Track mode: time steps selected from the track, domain = track extent +- (half box + one grid step)."""
+    shutil.copy(os.path.join(golden_dir, "inputs", "track_testdata_NCEP-R2"), workdir / "inputs" / "track")
+    args = argparse.Namespace(fixed=False, track=True, trackfile="inputs/track")
+    plan, host = _compare(os.path.join(golden_dir, "testdata_NCEP-R2.nc"), args)
+    assert len(plan.tsel) == len(host.time)
+
+
+def test_packed_file_plan(workdir):
+    from tests.helpers import write_packed_era5_style
+    path = str(workdir / "packed.nc")
+    write_packed_era5_style(path, nt=5)
+    (workdir / "inputs" / "namelist").write_text(
+        ";Variable;Units\nAir Temperature;t;K\nGeopotential;z;m**2/s**2\nOmega Velocity;w;Pa/s\n"
+        "Eastward Wind Component;u;m/s\nNorthward Wind Component;v;m/s\nLongitude;longitude\nLatitude;latitude\n"
+        "Time;time\nVertical Level;level\n")
+    (workdir / "inputs" / "box_limits").write_text("min_lon;-60\nmax_lon;20\nmin_lat;-45\nmax_lat;30\n")
+    args = argparse.Namespace(fixed=True, track=False, trackfile=None)
+    plan, host = _compare(path, args)
+    assert plan.level.size == 8 and plan.level[0] == 5000.0          # 5 hPa dropped, 50 hPa first
+    assert plan.lon[0] == -60.0 and plan.lon[-1] == 20.0 and plan.lat[0] == -45.0 and plan.lat[-1] == 30.0
+    assert np.isnan(host.variables["v"]).any()                         # the fill values became NaN on both paths
+
+
+def test_open_raw_rejects_what_the_kernel_cannot_read(workdir, golden_dir):
+    from scipy.io import netcdf_file
+    path = str(workdir / "bad.nc")
+    f = netcdf_file(path, "w")
+    for n, s in (("time", 2), ("level", 2), ("lat", 3), ("lon", 3)):
+        f.createDimension(n, s)
+        v = f.createVariable(n, "f", (n,)); v[:] = np.arange(s)
+    f.variables["time"].units = "hours since 2000-01-01"
+    for n in ("t", "u", "v", "w", "z"):
+        v = f.createVariable(n, "f", ("time", "lat", "level", "lon")); v[:] = 0        # wrong axis order
+    f.close()
+    (workdir / "inputs" / "namelist").write_text(
+        ";Variable;Units\nAir Temperature;t;K\nGeopotential;z;m**2/s**2\nOmega Velocity;w;Pa/s\n"
+        "Eastward Wind Component;u;m/s\nNorthward Wind Component;v;m/s\nLongitude;lon\nLatitude;lat\nTime;time\nVertical Level;level\n")
+    df = ds.read_namelist("inputs/namelist")
+    with pytest.raises(ValueError, match="order"):
+        ds.open_raw(path, df)
