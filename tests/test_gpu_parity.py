@@ -127,6 +127,24 @@ def test_synthetic_fixed(nx, dtype, nonuni):
     check_fixed(dom, limits, what=f"synthetic nx={nx} {np.dtype(dtype).name} nonuni={nonuni}")
 
 
+@pytest.mark.parametrize("nt,nl,ny,nx,box", [
+    (2, 2, 3, 4, (1, 2, 0, 1)),        # the smallest everything: two time steps, two levels, a 2 x 2 box
+    (2, 3, 5, 9, (0, 8, 0, 4)),        # two time steps: the first-step kernel plus a one-step row-block launch
+    (3, 2, 4, 6, (2, 5, 1, 3)),
+    (5, 4, 6, 130, (1, 128, 2, 3)),    # two latitudes only, rows that start on an odd element
+])
+def test_minimal_extents(nt, nl, ny, nx, box):
+    dom = synthetic_domain(nt, nl, ny, nx, seed=100 + nx)
+    iw, ie, js, jn = box
+    limits = (dom.lon[iw], dom.lon[ie], dom.lat[js], dom.lat[jn])
+    check_fixed(dom, limits, what=f"minimal nt={nt} nl={nl} ny={ny} nx={nx}")
+    # every single-step shard equals the whole-series result bit for bit
+    full = run_fixed(dom, limits)
+    for t in range(nt):
+        part = run_fixed(dom, limits, t_begin=t, t_count=1)
+        assert torch.equal(full.scalars[t:t + 1], part.scalars), f"single-step shard {t}"
+
+
 def test_synthetic_full_domain_box():
     dom = synthetic_domain(3, 6, 9, 64, seed=5)
     limits = (dom.lon[0], dom.lon[-1], dom.lat[0], dom.lat[-1])
