@@ -195,7 +195,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "one lec_rowstats call = lec_rowblock_kernel (time steps 2..T) + lec_rowsweep_kernel (first step) + lec_qtime_kernel; lec_rowstats_kernel with LEC_KERNEL=0", "avg_launch_ms": avg_launch_ms,
+                "kernel": "one lec_rowstats call = lec_rowblock_kernel + lec_qtime_kernel (lec_rowsweep_kernel for other configurations; lec_rowstats_kernel with LEC_KERNEL=0)", "avg_launch_ms": avg_launch_ms,
                 "algorithmic_bytes_per_launch": bytes_per_step_t * T_local,
             },
         }

@@ -100,6 +100,9 @@ __global__ void __launch_bounds__(64 * BT * BK * BJ, LEC_MINW_SINGLE) lec_rowblo
     const TIN* rTkm = (k > 0) ? rT - plane : rT;
     const TIN* rTkp = (k < p.nl - 1) ? rT + plane : rT;
     const TIN* rTtp = (t < p.nt - 1) ? rT + cube : rT;
+    const TIN* rTtm = (t > 0) ? rT - cube : rT;
+    // the first time step of the launch has no processed predecessor: it forms the backward cross-time covariance too
+    const bool both = (tl0 == 0);
 
     // per dimension: B == 1 -> both neighbours global (g0 = minus, g1 = plus);
     // B == 2 -> g0 = the outer neighbour (global), the inner one is the block mate's row in LDS
@@ -117,7 +120,7 @@ __global__ void __launch_bounds__(64 * BT * BK * BJ, LEC_MINW_SINGLE) lec_rowblo
     r.nxb = nxb;
     r.cT = (double)rT[0]; r.cU = (double)rU[0]; r.cV = (double)rV[0]; r.cW = (double)rW[0]; r.cP = (double)rP[0];
     r.cx = 0.5 * inv_hdeg * inv_dx; r.inv_dx = inv_dx; r.wl = wl; r.gl = gl;
-    r.cTf = (double)rTtp[0]; r.cTb = 0.0;
+    r.cTf = (double)rTtp[0]; r.cTb = both ? (double)rTtm[0] : 0.0;
     // T, u, v at the east box column (boundary terms), fetched now so that the row does not end on a load
     const double eT = (double)rT[nxb - 1], eU = (double)rU[nxb - 1], eV = (double)rV[nxb - 1];
 
@@ -130,8 +133,9 @@ __global__ void __launch_bounds__(64 * BT * BK * BJ, LEC_MINW_SINGLE) lec_rowblo
     QCoef qc;
     qc.k0 = cK0; qc.k1 = cK1; qc.km = be; qc.j0 = cJ0; qc.j1 = cJ1; qc.jm = gb;
 
-    auto trip = [&](auto edge_tag, const int it) {
+    auto trip = [&](auto edge_tag, auto both_tag, const int it) {
         constexpr bool EDGE = decltype(edge_tag)::value;
+        constexpr bool BOTH = decltype(both_tag)::value;
         const int el = it * 64 * VEC - shift;                // box element of lane 0 (wave-uniform)
         const int e0 = el + tid * VEC;
         const bool lane_in = !EDGE || (e0 <= e0_last);
@@ -140,6 +144,7 @@ __global__ void __launch_bounds__(64 * BT * BK * BJ, LEC_MINW_SINGLE) lec_rowblo
         QRaw<TIN, VEC> qr;                                    // x0 = the outer (global) neighbour, x1 = the other side
         load_vec<TIN, VEC, false>(rT - shift, eo, fT);       // first: the block mates wait for it
         if (fwd_global) load_vec<TIN, VEC, false>(rTtp - shift, eo, qr.tf);
+        if (BOTH) load_vec<TIN, VEC, true>(rTtm - shift, eo, qr.tb);
         load_vec<TIN, VEC, false>(gK0 - shift, eo, qr.k0);
         load_vec<TIN, VEC, false>(gJ0 - shift, eo, qr.j0);
         if (BK == 1) load_vec<TIN, VEC, false>(rTkp - shift, eo, qr.k1);
@@ -171,17 +176,21 @@ __global__ void __launch_bounds__(64 * BT * BK * BJ, LEC_MINW_SINGLE) lec_rowblo
         }
         const double tl_edge = from_prev_lane((double)fT[VEC - 1], tl0);
         const double tr_edge = from_next_lane((double)fT[0], tr0);
-        sweep_elems<VEC, UNIFORM, EDGE, 3, false>(acc, xacc, r, e0, lane_in, fT, fU, fV, fW, fP, tl_edge, tr_edge, qr, qc);
+        sweep_elems<VEC, UNIFORM, EDGE, 3, BOTH>(acc, xacc, r, e0, lane_in, fT, fU, fV, fW, fP, tl_edge, tr_edge, qr, qc);
     };
 
-    // every wave of the block runs the same trips (same box row geometry): the LDS barriers stay matched
+    // every wave of the block runs the same trips (same box row geometry, one barrier per trip in either variant): the
+    // LDS barriers stay matched
     const int ntrips = p.ntrips;
     const int mid_end = min((nxb - 1 + shift) / (64 * VEC), ntrips);
-    trip(std::true_type{}, 0);
+    auto sweep = [&](auto both_tag) {
+        trip(std::true_type{}, both_tag, 0);
 #pragma unroll 1
-    for (int it = 1; it < mid_end; ++it) trip(std::false_type{}, it);
+        for (int it = 1; it < mid_end; ++it) trip(std::false_type{}, both_tag, it);
 #pragma unroll 1
-    for (int it = max(mid_end, 1); it < ntrips; ++it) trip(std::true_type{}, it);
+        for (int it = max(mid_end, 1); it < ntrips; ++it) trip(std::true_type{}, both_tag, it);
+    };
+    if (both) sweep(std::true_type{}); else sweep(std::false_type{});
 
     finish_row<64, kHalf, true>(acc, xacc, red[wave], tot[wave], tid, UNIFORM ? h_rad * inv_xlen : inv_xlen, r, out, store);
     if (store && tid == 0) {

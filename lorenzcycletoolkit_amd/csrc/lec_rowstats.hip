@@ -304,7 +304,7 @@ int launch_vec(const RowParams& p, bool uniform, int mode, int nblocks, hipStrea
 
 static bool kernel_is_two_sweep() { const char* ek = getenv("LEC_KERNEL"); return ek && atoi(ek) == 0; }
 
-int lec_launch_rowsweep(const lec::RowParams& p, int dtype, bool aligned, bool aligned8, bool uniform, int mode, bool first_only, hipStream_t st);
+int lec_launch_rowsweep(const lec::RowParams& p, int dtype, bool aligned, bool aligned8, bool uniform, int mode, hipStream_t st);
 int lec_launch_rowblock(lec::RowParams p, int dtype, bool aligned, bool aligned8, bool uniform, int bt, int bk, int bj, hipStream_t st);
 int lec_launch_qtime(const lec::RowParams& p, hipStream_t st);
 
@@ -390,7 +390,7 @@ extern "C" int lec_rowstats(const lec_rowstats_args* a) {
     const int kernel = ek ? atoi(ek) : 1;
     // Single-sweep kernels (default).  All terms with dT/dt from the cube on one fixed box (the headline configuration):
     // a row reads T(t+1) only and the time-derivative parts of [Q], [Q'T'] are completed from the records afterwards
-    // (lec_qtime_kernel); the first time step goes to the one-wave-per-row kernel and the rest to the
+    // (lec_qtime_kernel); it runs on the
     // row-block kernel, 2 time steps x 2 latitudes per workgroup (lec_rowblock.hip; fp64 storage: 17.6-17.9 vs 18.4 ms
     // per 64 steps).  LEC_BLK=<bt><bk><bj> picks another block shape, LEC_BLK=0 the one-wave-per-row kernel everywhere
     // (bit-identical results).
@@ -399,9 +399,9 @@ extern "C" int lec_rowstats(const lec_rowstats_args* a) {
     if (kernel == 1) {
         const int mode = (wq == 1 && a->n_box == 1) ? 3 : wq;       // time stencil on one fixed box: through cross-time covariances
         const bool block_ok = blk > 0 && mode == 3 && a->geopt_d && a->t_count >= 2 && !getenv("LEC_ORDER");
-        rc = lec_launch_rowsweep(p, a->dtype, aligned, aligned8, uni, mode, block_ok, st);
-        if (rc == LEC_OK && block_ok) {
-            RowParams pb = later_steps(p);
+        if (!block_ok) rc = lec_launch_rowsweep(p, a->dtype, aligned, aligned8, uni, mode, st);
+        else {
+            RowParams pb = p;
             const char* etg = getenv("LEC_TG"); const char* ejg = getenv("LEC_JG");
             pb.order = 8; pb.tgroup = etg ? atoi(etg) : 2; pb.jgroup = ejg ? atoi(ejg) : 4;      // tile: 2 x 4 blocks at one level, levels next
             rc = lec_launch_rowblock(pb, a->dtype, aligned, aligned8, uni, blk / 100, (blk / 10) % 10, blk % 10, st);

@@ -268,14 +268,14 @@ int launch_one(RowParams p, bool uniform, int mode, hipStream_t st) {
 }
 
 // mode 3 (time stencil on one fixed box): the first time step of the launch forms both cross-time covariances, the
-// others only the forward one (`first_only`: the row-block kernel takes the rest)
+// others only the forward one
 template <typename TIN, int VEC>
-int launch_vec(const RowParams& p, bool uniform, int mode, bool first_only, hipStream_t st) {
+int launch_vec(const RowParams& p, bool uniform, int mode, hipStream_t st) {
     if (mode != 3) return launch_one<TIN, VEC, false>(p, uniform, mode, st);
     RowParams p0 = p;
     p0.t_count = 1;
     int rc = launch_one<TIN, VEC, true>(p0, uniform, mode, st);
-    if (rc != LEC_OK || first_only || p.t_count < 2) return rc;
+    if (rc != LEC_OK || p.t_count < 2) return rc;
     return launch_one<TIN, VEC, false>(later_steps(p), uniform, mode, st);
 }
 
@@ -285,11 +285,11 @@ int launch_vec(const RowParams& p, bool uniform, int mode, bool first_only, hipS
 // `aligned8` (fp32 only) = 8-byte aligned bases and even nx.  fp32 storage uses float4 vectors when it can
 // (four elements per lane and trip, operands kept as floats and converted at use, one element finished before the
 // next starts: 141 VGPRs, 3 waves/SIMD, 10.5 ms per 64 steps) and float2 otherwise (11.0 ms; LEC_F32VEC=2 forces it).
-int lec_launch_rowsweep(const lec::RowParams& p, int dtype, bool aligned, bool aligned8, bool uniform, int mode, bool first_only, hipStream_t st) {
-    if (dtype == LEC_F64) return aligned ? launch_vec<double, 2>(p, uniform, mode, first_only, st) : launch_vec<double, 1>(p, uniform, mode, first_only, st);
+int lec_launch_rowsweep(const lec::RowParams& p, int dtype, bool aligned, bool aligned8, bool uniform, int mode, hipStream_t st) {
+    if (dtype == LEC_F64) return aligned ? launch_vec<double, 2>(p, uniform, mode, st) : launch_vec<double, 1>(p, uniform, mode, st);
     const char* ev = getenv("LEC_F32VEC");
-    if (aligned && !(ev && atoi(ev) == 2)) return launch_vec<float, 4>(p, uniform, mode, first_only, st);
-    return aligned8 ? launch_vec<float, 2>(p, uniform, mode, first_only, st) : launch_vec<float, 1>(p, uniform, mode, first_only, st);
+    if (aligned && !(ev && atoi(ev) == 2)) return launch_vec<float, 4>(p, uniform, mode, st);
+    return aligned8 ? launch_vec<float, 2>(p, uniform, mode, st) : launch_vec<float, 1>(p, uniform, mode, st);
 }
 
 int lec_launch_qtime(const lec::RowParams& p, hipStream_t st) {
