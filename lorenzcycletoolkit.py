@@ -97,7 +97,11 @@ def main(argv=None):
             data = prepare_streamed(args, "inputs/namelist", app_logger)
         else:
             data = prepare_data(args, "inputs/namelist", app_logger)
-        run_lec_analysis(data, args, results_subdirectory, figures_directory, results_subdirectory_vertical_levels, app_logger)
+        try:
+            run_lec_analysis(data, args, results_subdirectory, figures_directory, results_subdirectory_vertical_levels, app_logger)
+        finally:
+            if args.device_ingest:
+                data.raw.close()
     except Exception:
         app_logger.exception("LEC analysis failed")
         raise

@@ -3,8 +3,8 @@ preprocessing semantics of the reference's ``prepare_data`` (src/utils/preproces
 src/utils/select_area.py:254-338, src/utils/validation.py), without xarray.
 
 Only the plumbing the LEC path needs is reproduced; the arrays stay NumPy on the host until the
-framework moves them to the GPU.  NetCDF-4/HDF5 files need an HDF5 reader that this image lacks
-(SURVEY.md section 8f-1): classic NetCDF-3 (CDF-1/2/5) files are read through scipy.
+framework moves them to the GPU.  Classic NetCDF-3 (CDF-1/2/5) files are read through scipy, NetCDF-4 / HDF5
+files through the pure-Python reader in hdf5_lite.py (the image has no HDF5 library).
 """
 from __future__ import annotations
 
@@ -140,50 +140,97 @@ def _decode_time(values: np.ndarray, units: str) -> np.ndarray:
 FIELD_ROLES = ("Air Temperature", "Omega Velocity", "Eastward Wind Component", "Northward Wind Component")
 
 
-def _attr(v, name):
-    a = getattr(v, name, None)
-    if isinstance(a, bytes):
-        a = a.decode()
-    if isinstance(a, np.ndarray) and a.size == 1:
-        a = a.reshape(()).item()
-    return a
+class _NcVar:
+    """One variable of either container format: ``data`` (ndarray, memory map, or a lazy HDF5 variable that is indexed
+    by time step), ``dimensions`` and attributes."""
+
+    def __init__(self, data, dimensions, attrs):
+        self.data, self.dimensions, self._attrs = data, tuple(dimensions), attrs
+
+    def attr(self, name):
+        a = self._attrs(name)
+        if isinstance(a, bytes):
+            a = a.decode()
+        if isinstance(a, np.ndarray) and a.size == 1:
+            a = a.reshape(()).item()
+        return a
+
+    def values(self) -> np.ndarray:
+        """The whole variable in native byte order."""
+        a = self.data.read() if hasattr(self.data, "read") else np.array(self.data)
+        return a.astype(a.dtype.newbyteorder("="))
+
+
+class _Container:
+    """Classic NetCDF (scipy) or NetCDF-4 / HDF5 (hdf5_lite) behind one face."""
+
+    def __init__(self, path: str, mmap: bool):
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"Input file not found: {path}")
+        with open(path, "rb") as f:
+            magic = f.read(8)
+        self.mapped = mmap
+        if magic[:3] == b"CDF":
+            from scipy.io import netcdf_file
+            self._nc = netcdf_file(path, mmap=mmap)
+            self.kind = "netcdf3"
+            self.variables = {n: _NcVar(v.data, v.dimensions, (lambda name, v=v: getattr(v, name, None)))
+                              for n, v in self._nc.variables.items()}
+        elif magic == b"\x89HDF\r\n\x1a\n":
+            from .hdf5_lite import H5File
+            self._nc = H5File(path)
+            self.kind = "hdf5"
+            self.variables = {n: _NcVar(v, v.dims, (lambda name, v=v: v.attrs.get(name)))
+                              for n, v in self._nc.variables.items()}
+        else:
+            raise ValueError(f"{path}: neither a classic NetCDF file nor an HDF5 (NetCDF-4) file (magic {magic[:4]!r})")
+
+    def close(self):
+        self.variables = {}
+        if self.kind == "netcdf3" and self.mapped:
+            _close_mapped(self._nc)
+        else:
+            self._nc.close()
+
+
+def _close_mapped(nc):
+    """Closes a memory-mapped netcdf_file; scipy warns when views of the map are still alive (the map goes with them)."""
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        try:
+            nc.close()
+        except Exception:
+            pass
 
 
 def _open_nc(path: str, variable_list_df: pd.DataFrame, mmap: bool):
-    """Opens a classic NetCDF file and checks it against the namelist (get_data, preprocessing.py:35-146;
+    """Opens a data file and checks it against the namelist (get_data, preprocessing.py:35-146;
     validate_variable_match / validate_required_coordinates, validation.py:247-356)."""
-    from scipy.io import netcdf_file
-
-    if not os.path.exists(path):
-        raise FileNotFoundError(f"Input file not found: {path}")
-    with open(path, "rb") as f:
-        magic = f.read(4)
-    if magic[:3] != b"CDF":
-        raise ValueError(f"{path}: not a classic NetCDF-3 file (magic {magic!r}); NetCDF-4/HDF5 input needs an HDF5 "
-                         "reader that is not available in this environment (convert with `nccopy -k classic`)")
-    nc = netcdf_file(path, mmap=mmap)
+    nc = _Container(path, mmap)
     var = lambda role: str(variable_list_df.loc[role]["Variable"])
     names = {r: var(r) for r in REQUIRED_ROLES}
     geo_role = "Geopotential" if "Geopotential" in variable_list_df.index else "Geopotential Height"
     names[geo_role] = var(geo_role)
     missing = [f"{r} -> {n}" for r, n in names.items() if n not in nc.variables]
     if missing:
+        have = list(nc.variables)
         nc.close()
-        raise KeyError(f"namelist variables not found in {path}: {missing}; file has {list(nc.variables)}")
-    native = lambda n: np.array(nc.variables[n].data).astype(nc.variables[n].data.dtype.newbyteorder("="))
+        raise KeyError(f"namelist variables not found in {path}: {missing}; file has {have}")
+    native = lambda n: nc.variables[n].values()
     lat, lon, lev = native(names["Latitude"]), native(names["Longitude"]), native(names["Vertical Level"])
-    time = _decode_time(native(names["Time"]), _attr(nc.variables[names["Time"]], "units"))
-    level_units = _attr(nc.variables[names["Vertical Level"]], "units")
+    time = _decode_time(native(names["Time"]), nc.variables[names["Time"]].attr("units"))
+    level_units = nc.variables[names["Vertical Level"]].attr("units")
     want = (names["Time"], names["Vertical Level"], names["Latitude"], names["Longitude"])
     return nc, names, geo_role, lat, lon, lev, time, level_units, want
 
 
 def _packing(v):
     """CF packing attributes of a variable: (scale_factor, add_offset, fill value) with None for absent ones."""
-    scale, offset = _attr(v, "scale_factor"), _attr(v, "add_offset")
-    fill = _attr(v, "_FillValue")
+    scale, offset = v.attr("scale_factor"), v.attr("add_offset")
+    fill = v.attr("_FillValue")
     if fill is None:
-        fill = _attr(v, "missing_value")
+        fill = v.attr("missing_value")
     return (None if scale is None else float(scale), None if offset is None else float(offset),
             None if fill is None else float(fill))
 
@@ -196,7 +243,7 @@ def open_dataset(path: str, variable_list_df: pd.DataFrame) -> LECDataset:
     variables = {}
     for role in FIELD_ROLES + (geo_role,):
         v = nc.variables[names[role]]
-        raw = np.array(v.data).astype(v.data.dtype.newbyteorder("="))
+        raw = v.values()
         scale, offset, fill = _packing(v)
         a = raw
         if scale is not None or offset is not None:
@@ -239,19 +286,8 @@ class RawDataset:
     def close(self):
         if self._nc is not None:
             self.variables.clear()
-            _close_mapped(self._nc)
+            self._nc.close()
             self._nc = None
-
-
-def _close_mapped(nc):
-    """Closes a memory-mapped netcdf_file; scipy warns when views of the map are still alive (the map goes with them)."""
-    import warnings
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore", RuntimeWarning)
-        try:
-            nc.close()
-        except Exception:
-            pass
 
 
 def open_raw(path: str, variable_list_df: pd.DataFrame) -> RawDataset:
@@ -261,10 +297,10 @@ def open_raw(path: str, variable_list_df: pd.DataFrame) -> RawDataset:
     for role in FIELD_ROLES + (geo_role,):
         v = nc.variables[names[role]]
         if tuple(v.dimensions) != want:
-            _close_mapped(nc)
+            nc.close()
             raise ValueError(f"{names[role]} has dimensions {v.dimensions}; the device ingest needs {want} order")
         if v.data.dtype.kind not in "if" or v.data.dtype.itemsize not in (2, 4, 8) or (v.data.dtype.kind == "i" and v.data.dtype.itemsize != 2):
-            _close_mapped(nc)
+            nc.close()
             raise ValueError(f"{names[role]}: the device ingest reads int16, float32 and float64 variables, not {v.data.dtype}")
         scale, offset, fill = _packing(v)
         variables[names[role]] = RawVariable(v.data, scale, offset, fill)

@@ -1,0 +1,681 @@
+"""A small read-only HDF5 reader for NetCDF-4 files (this image has no HDF5 library for
+the default interpreter).  Pure Python + zlib + NumPy; it understands what netCDF-C / h5netcdf / h5py write for
+gridded data:
+
+* superblock versions 0-3; object headers version 1 and 2 (with continuation blocks);
+* the root group as a symbol table (v1 B-tree + local heap), as compact link messages, or as dense link storage
+  (v2 B-tree name index + fractal heap);
+* datasets: contiguous, compact, and chunked (layout v3 with a v1 B-tree; layout v4 single-chunk / implicit /
+  fixed-array indexes), filters deflate + shuffle (+ fletcher32, ignored);
+* datatypes: integers and IEEE floats of 1-8 bytes in either byte order, fixed- and variable-length strings,
+  object references (for DIMENSION_LIST);
+* attributes in the object header or in dense storage.
+
+Not supported (raises Hdf5Error): sub-groups, compound / enum data, other filters (szip, lzf, zstd ...), external or
+virtual storage, extensible-array and v2-B-tree chunk indexes.  Format reference: "HDF5 File Format Specification
+Version 3.0" (The HDF Group).
+"""
+from __future__ import annotations
+
+import zlib
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+SIGNATURE = b"\x89HDF\r\n\x1a\n"
+
+
+class Hdf5Error(ValueError):
+    pass
+
+
+@dataclass
+class _Dtype:
+    kind: str                       # "num", "str", "vlen_str", "vlen", "ref", "other"
+    np_dtype: Optional[np.dtype] = None
+    size: int = 0
+    base: Optional["_Dtype"] = None
+
+
+@dataclass
+class H5Variable:
+    """One dataset: shape, NumPy dtype (file byte order), attributes, dimension names, and lazy reads along axis 0."""
+    name: str
+    shape: Tuple[int, ...]
+    dtype: np.dtype
+    attrs: Dict[str, object]
+    dims: Tuple[str, ...] = ()
+    _file: "H5File" = None
+    _layout: dict = field(default_factory=dict)
+    _filters: list = field(default_factory=list)
+    _cache: dict = field(default_factory=dict)
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    def read(self) -> np.ndarray:
+        """The whole array."""
+        return self._file._read_dataset(self, None)
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.read()
+        return a if dtype is None else a.astype(dtype)
+
+    def __getitem__(self, t) -> np.ndarray:
+        """``var[t]`` for an integer t: the block at index t of axis 0 (a contiguous array)."""
+        if not isinstance(t, (int, np.integer)):
+            raise TypeError("H5Variable supports integer indexing along axis 0 and read()")
+        t = int(t)
+        if t < 0:
+            t += self.shape[0]
+        if not 0 <= t < self.shape[0]:
+            raise IndexError(t)
+        return self._file._read_dataset(self, t)
+
+
+class H5File:
+    def __init__(self, path: str):
+        self.path = path
+        self._f = open(path, "rb")
+        import mmap
+        self._m = mmap.mmap(self._f.fileno(), 0, access=mmap.ACCESS_READ)
+        self.variables: Dict[str, H5Variable] = {}
+        self.attrs: Dict[str, object] = {}
+        self._parse()
+
+    def close(self):
+        self.variables.clear()
+        try:
+            self._m.close()
+        except BufferError:
+            pass
+        self._f.close()
+
+    # ---- primitive reads -------------------------------------------------------------------
+    def _u(self, off: int, n: int) -> int:
+        return int.from_bytes(self._m[off: off + n], "little")
+
+    def _addr(self, off: int) -> int:
+        return self._u(off, self.O)
+
+    def _len(self, off: int) -> int:
+        return self._u(off, self.L)
+
+    # ---- superblock ------------------------------------------------------------------------
+    def _parse(self):
+        m = self._m
+        base = 0
+        while m[base: base + 8] != SIGNATURE:
+            base = 512 if base == 0 else base * 2
+            if base + 8 > len(m):
+                raise Hdf5Error(f"{self.path}: not an HDF5 file")
+        ver = m[base + 8]
+        if ver in (0, 1):
+            self.O, self.L = m[base + 13], m[base + 14]
+            p = base + 24 + (4 if ver == 1 else 0)
+            self.base = self._addr(p)
+            p += 4 * self.O                          # base, free-space info, end of file, driver info
+            root = self._addr(p + self.O)            # symbol table entry: link name offset, object header address
+        elif ver in (2, 3):
+            self.O, self.L = m[base + 9], m[base + 10]
+            p = base + 12
+            self.base = self._addr(p)
+            root = self._addr(p + 3 * self.O)
+        else:
+            raise Hdf5Error(f"superblock version {ver} not supported")
+        if self.base not in (0, base):
+            raise Hdf5Error("non-zero base address not supported")
+        self.base = base
+        msgs = self._object_messages(root)
+        self.attrs = self._attributes(msgs)
+        links = self._group_links(msgs)
+        by_addr = {}
+        for name, addr in links.items():
+            try:
+                dm = self._object_messages(addr)
+            except Hdf5Error:
+                continue
+            var = self._dataset(name, dm)
+            if var is not None:
+                self.variables[name] = var
+                by_addr[addr] = name
+        # dimension names from DIMENSION_LIST (one variable-length list of object references per axis)
+        for var in self.variables.values():
+            dl = var.attrs.pop("DIMENSION_LIST", None)
+            if isinstance(dl, list) and len(dl) == var.ndim:
+                names = []
+                for refs in dl:
+                    a = int(refs[0]) if len(refs) else None
+                    names.append(by_addr.get(a, ""))
+                var.dims = tuple(names)
+            elif var.ndim == 1:
+                var.dims = (var.name,)
+            for k in ("REFERENCE_LIST", "CLASS", "NAME", "_Netcdf4Dimid", "_Netcdf4Coordinates", "_nc3_strict", "_NCProperties"):
+                var.attrs.pop(k, None)
+
+    # ---- object headers --------------------------------------------------------------------
+    def _object_messages(self, addr: int) -> List[Tuple[int, int, int]]:
+        """(type, offset of data, size) of every header message of the object at `addr`."""
+        m, a = self._m, addr + self.base
+        out: List[Tuple[int, int, int]] = []
+        if m[a: a + 4] == b"OHDR":
+            if m[a + 4] != 2:
+                raise Hdf5Error("object header version")
+            flags = m[a + 5]
+            p = a + 6
+            if flags & 0x20:
+                p += 16
+            if flags & 0x10:
+                p += 4
+            nsz = 1 << (flags & 3)
+            chunk = self._u(p, nsz)
+            p += nsz
+            blocks = [(p, chunk)]
+            while blocks:
+                p, size = blocks.pop(0)
+                end = p + size
+                while p + 4 <= end:
+                    mtype, msize, _mflags = m[p], self._u(p + 1, 2), m[p + 3]
+                    p += 4 + (2 if flags & 0x04 else 0)
+                    if p + msize > end:
+                        break
+                    if mtype == 0x10:
+                        ca, cl = self._addr(p) + self.base, self._len(p + self.O)
+                        if m[ca: ca + 4] != b"OCHK":
+                            raise Hdf5Error("bad continuation block")
+                        blocks.append((ca + 4, cl - 8))
+                    elif mtype != 0:
+                        out.append((mtype, p, msize))
+                    p += msize
+            return out
+        if m[a] != 1:
+            raise Hdf5Error(f"no object header at {addr}")
+        nmsg, hsize = self._u(a + 2, 2), self._u(a + 8, 4)
+        blocks = [(a + 16, hsize)]
+        while blocks and nmsg > 0:
+            p, size = blocks.pop(0)
+            end = p + size
+            while p + 8 <= end and nmsg > 0:
+                mtype, msize = self._u(p, 2), self._u(p + 2, 2)
+                p += 8
+                nmsg -= 1
+                if mtype == 0x10:
+                    blocks.append((self._addr(p) + self.base, self._len(p + self.O)))
+                elif mtype != 0:
+                    out.append((mtype, p, msize))
+                p += msize
+        return out
+
+    # ---- groups ----------------------------------------------------------------------------
+    def _group_links(self, msgs) -> Dict[str, int]:
+        links: Dict[str, int] = {}
+        for mtype, p, size in msgs:
+            if mtype == 0x11:                                   # symbol table: v1 B-tree + local heap
+                btree, heap = self._addr(p), self._addr(p + self.O)
+                h = heap + self.base
+                if self._m[h: h + 4] != b"HEAP":
+                    raise Hdf5Error("bad local heap")
+                data = self._addr(h + 8 + 2 * self.L) + self.base
+                self._walk_group_btree(btree, data, links)
+            elif mtype == 0x06:
+                name, addr = self._link(p)
+                if addr is not None:
+                    links[name] = addr
+            elif mtype == 0x02:                                 # link info: dense storage in a fractal heap
+                flags = self._m[p + 1]
+                q = p + 2 + (8 if flags & 1 else 0)
+                fheap, btree = self._addr(q), self._addr(q + self.O)
+                if fheap != (1 << (8 * self.O)) - 1:
+                    for off in self._dense_objects(fheap, btree, 5):
+                        name, addr = self._link(off)
+                        if addr is not None:
+                            links[name] = addr
+        return links
+
+    def _walk_group_btree(self, addr, heap_data, links):
+        a = addr + self.base
+        m = self._m
+        if m[a: a + 4] == b"SNOD":
+            n = self._u(a + 6, 2)
+            p = a + 8
+            for _ in range(n):
+                noff, oaddr = self._addr(p), self._addr(p + self.O)
+                s = heap_data + noff
+                e = m.find(b"\0", s)
+                links[m[s:e].decode("utf-8")] = oaddr
+                p += 2 * self.O + 24
+            return
+        if m[a: a + 4] != b"TREE":
+            raise Hdf5Error("bad group B-tree node")
+        n = self._u(a + 6, 2)
+        p = a + 8 + 2 * self.O
+        for i in range(n):
+            child = self._addr(p + self.L)
+            self._walk_group_btree(child, heap_data, links)
+            p += self.L + self.O
+
+    def _link(self, off):
+        """(name, object header address or None) of the link message at file offset `off`."""
+        b = bytes(self._m[off: off + 1100])
+        if len(b) < 4 or b[0] != 1:
+            return "", None
+        flags = b[1]
+        p = 2
+        ltype = 0
+        if flags & 0x08:
+            ltype = b[p]; p += 1
+        if flags & 0x04:
+            p += 8
+        if flags & 0x10:
+            p += 1
+        nl = 1 << (flags & 3)
+        n = int.from_bytes(b[p: p + nl], "little"); p += nl
+        name = b[p: p + n].decode("utf-8"); p += n
+        if ltype != 0:
+            return name, None
+        return name, int.from_bytes(b[p: p + self.O], "little")
+
+    # ---- dense storage: a v2 B-tree of names whose records carry fractal-heap IDs ----------------------------
+    def _dense_objects(self, fheap: int, btree: int, rec_type: int) -> List[int]:
+        """File offsets of the link (rec_type 5) or attribute (rec_type 8) messages of a dense-storage object."""
+        locate = self._fractal_heap(fheap)
+        out = []
+        for rec in self._btree2_records(btree, rec_type):
+            hid = rec[4:] if rec_type == 5 else rec[:8]        # type 5: hash (4) + heap ID (7); type 8: heap ID (8) + flags + order + hash
+            pos = locate(hid)
+            if pos is not None:
+                out.append(pos)
+        return out
+
+    def _btree2_records(self, addr: int, rec_type: int):
+        m, a = self._m, addr + self.base
+        if m[a: a + 4] != b"BTHD":
+            raise Hdf5Error("bad v2 B-tree header")
+        if m[a + 5] != rec_type:
+            raise Hdf5Error(f"v2 B-tree of type {m[a + 5]}, expected {rec_type}")
+        node_size, rec_size, depth = self._u(a + 6, 4), self._u(a + 10, 2), self._u(a + 12, 2)
+        root, nroot = self._addr(a + 16), self._u(a + 16 + self.O, 2)
+        if root == (1 << (8 * self.O)) - 1 or nroot == 0:
+            return
+        max_leaf = (node_size - 10) // rec_size
+        nrec_bytes = (max_leaf.bit_length() + 7) // 8
+
+        def node(naddr, nrec, level):
+            b = naddr + self.base
+            sig = b"BTLF" if level == 0 else b"BTIN"
+            if m[b: b + 4] != sig:
+                raise Hdf5Error("bad v2 B-tree node")
+            p = b + 6
+            recs = [bytes(m[p + i * rec_size: p + (i + 1) * rec_size]) for i in range(nrec)]
+            if level == 0:
+                yield from recs
+                return
+            if level > 1:
+                raise Hdf5Error("v2 B-trees deeper than 2 levels are not supported")
+            p += nrec * rec_size
+            for i in range(nrec + 1):
+                child, cn = self._addr(p), self._u(p + self.O, nrec_bytes)
+                p += self.O + nrec_bytes
+                yield from node(child, cn, level - 1)
+                if i < nrec:
+                    yield recs[i]
+        yield from node(root, nroot, depth)
+
+    def _fractal_heap(self, addr: int):
+        """Returns locate(heap_id_bytes) -> file offset of a managed object (None for other ID types)."""
+        m, a = self._m, addr + self.base
+        if m[a: a + 4] != b"FRHP":
+            raise Hdf5Error("bad fractal heap")
+        p = a + 5
+        filt_len = self._u(p + 2, 2)
+        p += 5 + 4                                     # heap ID length, filter length, flags, max size of managed objects
+        max_managed = self._u(p - 4, 4)
+        p += self.L + self.O                           # next huge id, huge b-tree
+        p += self.L + self.O                           # free space, free-space manager
+        p += 4 * self.L                                # managed space, allocated, iterator offset, number of managed objects
+        p += 4 * self.L                                # huge size/count, tiny size/count
+        width = self._u(p, 2); p += 2
+        start = self._len(p); p += self.L
+        max_direct = self._len(p); p += self.L
+        max_bits = self._u(p, 2); p += 2
+        p += 2                                         # starting rows of the root indirect block
+        root = self._addr(p); p += self.O
+        cur_rows = self._u(p, 2)
+        if filt_len:
+            raise Hdf5Error("filtered fractal heaps not supported")
+        off_bytes = (max_bits + 7) // 8
+        len_bytes = (min(max_direct, max_managed).bit_length() + 7) // 8
+        max_direct_rows = (max_direct // start).bit_length() - 1 + 2
+
+        def locate(hid: bytes):
+            if (hid[0] >> 4) & 3 != 0:                 # tiny / huge objects: not used for links and attributes of this size
+                return None
+            off = int.from_bytes(hid[1: 1 + off_bytes], "little")
+            if cur_rows == 0:
+                return root + self.base + off
+            b = root + self.base
+            if m[b: b + 4] != b"FHIB":
+                raise Hdf5Error("bad fractal heap indirect block")
+            q = b + 5 + self.O + off_bytes
+            row_off = 0
+            for r in range(cur_rows):
+                size = start if r < 2 else start << (r - 1)
+                if off < row_off + width * size:
+                    if r >= max_direct_rows:
+                        raise Hdf5Error("nested fractal-heap indirect blocks are not supported")
+                    c = (off - row_off) // size
+                    child = self._addr(q + (r * width + c) * self.O)
+                    return child + self.base + (off - row_off - c * size)
+                row_off += width * size
+            return None
+        _ = len_bytes
+        return locate
+
+    # ---- datatype / dataspace ---------------------------------------------------------------
+    def _datatype(self, p) -> _Dtype:
+        m = self._m
+        cls, ver = m[p] & 0x0F, m[p] >> 4
+        bits = self._u(p + 1, 3)
+        size = self._u(p + 4, 4)
+        order = ">" if bits & 1 else "<"
+        if cls == 0:
+            return _Dtype("num", np.dtype(f"{order}{'i' if bits & 8 else 'u'}{size}"), size)
+        if cls == 1:
+            return _Dtype("num", np.dtype(f"{order}f{size}"), size)
+        if cls == 3:
+            return _Dtype("str", np.dtype(f"S{size}"), size)
+        if cls == 7:
+            return _Dtype("ref", np.dtype(f"<u{size}"), size)
+        if cls == 9:
+            base = self._datatype(p + 8)
+            return _Dtype("vlen_str" if (bits & 0x0F) == 1 else "vlen", None, size, base)
+        return _Dtype("other", None, size)
+
+    def _dataspace(self, p) -> Tuple[int, ...]:
+        m = self._m
+        ver, rank = m[p], m[p + 1]
+        if ver == 1:
+            q = p + 8
+        elif ver == 2:
+            if m[p + 3] == 2:          # null dataspace
+                return (0,)
+            q = p + 4
+        else:
+            raise Hdf5Error("dataspace version")
+        return tuple(self._len(q + i * self.L) for i in range(rank))
+
+    # ---- attributes -------------------------------------------------------------------------
+    def _attributes(self, msgs) -> Dict[str, object]:
+        out: Dict[str, object] = {}
+        for mtype, p, size in msgs:
+            if mtype == 0x0C:
+                self._attribute(p, out)
+            elif mtype == 0x15:                                # attribute info: dense storage
+                flags = self._m[p + 1]
+                q = p + 2 + (2 if flags & 1 else 0)
+                fheap, btree = self._addr(q), self._addr(q + self.O)
+                if fheap != (1 << (8 * self.O)) - 1:
+                    for off in self._dense_objects(fheap, btree, 8):
+                        self._attribute(off, out)
+        return out
+
+    def _attribute(self, p, out):
+        m = self._m
+        ver = m[p]
+        if ver not in (1, 2, 3):
+            return
+        ns, ds, ss = self._u(p + 2, 2), self._u(p + 4, 2), self._u(p + 6, 2)
+        q = p + 8 + (1 if ver == 3 else 0)
+        pad = (lambda x: (x + 7) & ~7) if ver == 1 else (lambda x: x)
+        name = bytes(m[q: q + ns]).split(b"\0")[0].decode("utf-8")
+        q += pad(ns)
+        dt = self._datatype(q); q += pad(ds)
+        shape = self._dataspace(q); q += pad(ss)
+        n = int(np.prod(shape)) if shape else 1
+        out[name] = self._decode(dt, q, n, shape)
+
+    def _decode(self, dt: _Dtype, q: int, n: int, shape):
+        m = self._m
+        if dt.kind == "num":
+            a = np.frombuffer(m[q: q + n * dt.size], dtype=dt.np_dtype).astype(dt.np_dtype.newbyteorder("="))
+            return a[0].item() if not shape else a.reshape(shape)
+        if dt.kind == "str":
+            vals = [bytes(m[q + i * dt.size: q + (i + 1) * dt.size]).split(b"\0")[0].decode("utf-8", "replace") for i in range(n)]
+            return vals[0] if not shape or n == 1 else vals
+        if dt.kind in ("vlen_str", "vlen"):
+            vals = []
+            for i in range(n):
+                e = q + i * (4 + self.O + 4)
+                cnt, coll, idx = self._u(e, 4), self._addr(e + 4), self._u(e + 4 + self.O, 4)
+                raw = self._global_heap_object(coll, idx)
+                if dt.kind == "vlen_str":
+                    vals.append(raw[:cnt].decode("utf-8", "replace"))
+                else:
+                    base = dt.base.np_dtype if dt.base is not None and dt.base.np_dtype is not None else np.dtype("u1")
+                    vals.append(np.frombuffer(raw[: cnt * base.itemsize], dtype=base))
+            if dt.kind == "vlen_str":
+                return vals[0] if not shape or n == 1 else vals
+            return vals
+        if dt.kind == "ref":
+            return np.frombuffer(m[q: q + n * dt.size], dtype=dt.np_dtype)
+        return None
+
+    def _global_heap_object(self, coll: int, idx: int) -> bytes:
+        m, a = self._m, coll + self.base
+        if m[a: a + 4] != b"GCOL":
+            raise Hdf5Error("bad global heap collection")
+        size = self._len(a + 8)
+        p, end = a + 8 + self.L, a + size
+        while p + 8 + self.L <= end:
+            i, osz = self._u(p, 2), self._len(p + 8)
+            if i == idx:
+                return bytes(m[p + 8 + self.L: p + 8 + self.L + osz])
+            if i == 0:
+                break
+            p += 8 + self.L + ((osz + 7) & ~7)
+        raise Hdf5Error("global heap object not found")
+
+    # ---- datasets ---------------------------------------------------------------------------
+    def _dataset(self, name, msgs) -> Optional[H5Variable]:
+        dt = shape = layout = None
+        filters = []
+        for mtype, p, size in msgs:
+            if mtype == 0x03:
+                dt = self._datatype(p)
+            elif mtype == 0x01:
+                shape = self._dataspace(p)
+            elif mtype == 0x08:
+                layout = self._layout(p)
+            elif mtype == 0x0B:
+                filters = self._filter_pipeline(p)
+        if dt is None or shape is None or layout is None or dt.kind != "num":
+            return None
+        return H5Variable(name, tuple(shape), dt.np_dtype, self._attributes(msgs), (), self, layout, filters)
+
+    def _layout(self, p) -> dict:
+        m = self._m
+        ver, cls = m[p], m[p + 1]
+        if ver == 3:
+            if cls == 0:
+                n = self._u(p + 2, 2)
+                return {"class": "compact", "offset": p + 4, "size": n}
+            if cls == 1:
+                return {"class": "contiguous", "addr": self._addr(p + 2), "size": self._len(p + 2 + self.O)}
+            if cls == 2:
+                nd = m[p + 2]
+                btree = self._addr(p + 3)
+                dims = [self._u(p + 3 + self.O + 4 * i, 4) for i in range(nd)]
+                return {"class": "chunked", "index": "btree1", "addr": btree, "chunk": tuple(dims[:-1])}
+        if ver == 4:
+            if cls == 1:
+                return {"class": "contiguous", "addr": self._addr(p + 2), "size": self._len(p + 2 + self.O)}
+            if cls == 0:
+                n = self._u(p + 2, 2)
+                return {"class": "compact", "offset": p + 4, "size": n}
+            if cls == 2:
+                flags, nd, enc = m[p + 2], m[p + 3], m[p + 4]
+                dims = [self._u(p + 5 + enc * i, enc) for i in range(nd)]
+                q = p + 5 + enc * nd
+                itype = m[q]; q += 1
+                lay = {"class": "chunked", "chunk": tuple(dims[:-1]), "flags": flags}
+                if itype == 1:
+                    if flags & 2:
+                        lay.update(index="single", fsize=self._len(q), fmask=self._u(q + self.L, 4), addr=self._addr(q + self.L + 4))
+                    else:
+                        lay.update(index="single", fsize=None, fmask=0, addr=self._addr(q))
+                elif itype == 2:
+                    lay.update(index="implicit", addr=self._addr(q))
+                elif itype == 3:
+                    lay.update(index="farray", addr=self._addr(q + 1))
+                else:
+                    raise Hdf5Error(f"chunk index type {itype} (extensible array / v2 B-tree) not supported")
+                return lay
+        raise Hdf5Error(f"data layout version {ver} class {cls} not supported")
+
+    def _filter_pipeline(self, p) -> list:
+        m = self._m
+        ver, n = m[p], m[p + 1]
+        q = p + (8 if ver == 1 else 2)
+        out = []
+        for _ in range(n):
+            fid = self._u(q, 2); q += 2
+            nlen = 0
+            if ver == 1 or fid >= 256:
+                nlen = self._u(q, 2); q += 2
+            q += 2                                     # flags
+            ncd = self._u(q, 2); q += 2
+            q += ((nlen + 7) & ~7) if ver == 1 else nlen
+            cd = [self._u(q + 4 * i, 4) for i in range(ncd)]
+            q += 4 * ncd
+            if ver == 1 and ncd % 2:
+                q += 4
+            out.append((fid, cd))
+        return out
+
+    def _chunks(self, var: H5Variable) -> Dict[Tuple[int, ...], Tuple[int, int, int]]:
+        """chunk offset (element coordinates) -> (file address, stored size, filter mask)"""
+        if "table" in var._cache:
+            return var._cache["table"]
+        lay = var._layout
+        table: Dict[Tuple[int, ...], Tuple[int, int, int]] = {}
+        rank = len(var.shape)
+        chunk = lay["chunk"]
+        nbytes = int(np.prod(chunk)) * var.dtype.itemsize
+        if lay["index"] == "btree1":
+            def walk(addr):
+                a = addr + self.base
+                m = self._m
+                if m[a: a + 4] != b"TREE" or m[a + 4] != 1:
+                    raise Hdf5Error("bad chunk B-tree node")
+                level, n = m[a + 5], self._u(a + 6, 2)
+                p = a + 8 + 2 * self.O
+                ksz = 8 + 8 * (rank + 1)
+                for i in range(n):
+                    size, mask = self._u(p, 4), self._u(p + 4, 4)
+                    offs = tuple(self._u(p + 8 + 8 * d, 8) for d in range(rank))
+                    child = self._addr(p + ksz)
+                    if level == 0:
+                        table[offs] = (child, size, mask)
+                    else:
+                        walk(child)
+                    p += ksz + self.O
+            if lay["addr"] != (1 << (8 * self.O)) - 1:
+                walk(lay["addr"])
+        elif lay["index"] == "single":
+            table[(0,) * rank] = (lay["addr"], lay["fsize"] if lay["fsize"] is not None else nbytes, lay["fmask"])
+        else:
+            counts = [-(-s // c) for s, c in zip(var.shape, chunk)]
+            coords = list(np.ndindex(*counts))
+            if lay["index"] == "implicit":
+                for i, c in enumerate(coords):
+                    table[tuple(ci * ch for ci, ch in zip(c, chunk))] = (lay["addr"] + i * nbytes, nbytes, 0)
+            else:                                      # fixed array
+                a = lay["addr"] + self.base
+                m = self._m
+                if m[a: a + 4] != b"FAHD":
+                    raise Hdf5Error("bad fixed array header")
+                client, esize, pbits = m[a + 5], m[a + 6], m[a + 7]
+                nent = self._len(a + 8)
+                db = self._addr(a + 8 + self.L) + self.base
+                if m[db: db + 4] != b"FADB":
+                    raise Hdf5Error("bad fixed array data block")
+                p = db + 6 + self.O
+                if nent > (1 << pbits):
+                    raise Hdf5Error("paged fixed-array chunk index not supported")
+                for i, c in enumerate(coords[:nent]):
+                    off = tuple(ci * ch for ci, ch in zip(c, chunk))
+                    if client == 0:
+                        table[off] = (self._addr(p), nbytes, 0); p += esize
+                    else:
+                        csz = esize - self.O - 4
+                        table[off] = (self._addr(p), self._u(p + self.O, csz), self._u(p + self.O + csz, 4)); p += esize
+        var._cache["table"] = table
+        return table
+
+    def _read_chunk(self, var: H5Variable, addr: int, size: int, mask: int) -> np.ndarray:
+        raw = bytes(self._m[addr + self.base: addr + self.base + size])
+        for i, (fid, cd) in reversed(list(enumerate(var._filters))):
+            if mask & (1 << i):
+                continue
+            if fid == 1:
+                raw = zlib.decompress(raw)
+            elif fid == 2:                             # shuffle
+                es = cd[0] if cd else var.dtype.itemsize
+                n = len(raw) // es
+                raw = np.frombuffer(raw, dtype=np.uint8)[: n * es].reshape(es, n).T.tobytes()
+            elif fid == 3:                             # fletcher32: checksum at the end
+                raw = raw[:-4]
+            else:
+                raise Hdf5Error(f"HDF5 filter {fid} not supported (deflate, shuffle and fletcher32 are)")
+        return np.frombuffer(raw, dtype=var.dtype)
+
+    def _read_dataset(self, var: H5Variable, t: Optional[int]) -> np.ndarray:
+        lay = var._layout
+        shape = var.shape
+        if lay["class"] in ("contiguous", "compact"):
+            n = int(np.prod(shape))
+            if lay["class"] == "compact":
+                a = np.frombuffer(self._m[lay["offset"]: lay["offset"] + n * var.dtype.itemsize], dtype=var.dtype)
+            elif lay["addr"] == (1 << (8 * self.O)) - 1:
+                a = np.zeros(n, dtype=var.dtype)
+            else:
+                a = np.frombuffer(self._m, dtype=var.dtype, count=n, offset=lay["addr"] + self.base)
+            a = a.reshape(shape)
+            return a if t is None else a[t]
+        chunk = lay["chunk"]
+        table = self._chunks(var)
+        if t is None:
+            out = np.zeros(shape, dtype=var.dtype)
+            lo0, hi0 = 0, shape[0]
+        else:
+            out = np.zeros((1,) + shape[1:], dtype=var.dtype)
+            lo0, hi0 = t, t + 1
+        fill = var.attrs.get("_FillValue")
+        if fill is not None and not isinstance(fill, (list, str)):
+            out[...] = fill
+        for offs, (addr, size, mask) in table.items():
+            if offs[0] + chunk[0] <= lo0 or offs[0] >= hi0:
+                continue
+            key = offs
+            data = var._cache.get(("chunk", key))
+            if data is None:
+                data = self._read_chunk(var, addr, size, mask).reshape(chunk)
+                if len(var._cache) > 64:
+                    for k in [k for k in var._cache if isinstance(k, tuple) and k and k[0] == "chunk"][:32]:
+                        del var._cache[k]
+                var._cache[("chunk", key)] = data
+            src, dst = [], []
+            for d in range(len(shape)):
+                a0 = max(offs[d], lo0 if d == 0 else 0)
+                a1 = min(offs[d] + chunk[d], hi0 if d == 0 else shape[d])
+                src.append(slice(a0 - offs[d], a1 - offs[d]))
+                dst.append(slice(a0 - (lo0 if d == 0 else 0), a1 - (lo0 if d == 0 else 0)))
+            out[tuple(dst)] = data[tuple(src)]
+        return out if t is None else out[0]
+
+
+def is_hdf5(path: str) -> bool:
+    with open(path, "rb") as f:
+        return f.read(8) == SIGNATURE

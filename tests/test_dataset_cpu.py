@@ -101,9 +101,12 @@ def test_prepare_data_track_selects_times_and_extent(workdir, golden_dir):
         ds.prepare_data(args, "inputs/namelist")
 
 
-def test_open_dataset_rejects_hdf5(workdir):
-    (workdir / "x.nc").write_bytes(b"\x89HDF\r\n\x1a\n" + b"0" * 64)
-    with pytest.raises(ValueError, match="NetCDF-3"):
+def test_open_dataset_rejects_unknown_containers(workdir):
+    (workdir / "x.nc").write_bytes(b"GRIB" + b"0" * 64)
+    with pytest.raises(ValueError, match="neither"):
         ds.open_dataset("x.nc", ds.read_namelist("inputs/namelist"))
+    (workdir / "y.nc").write_bytes(b"\x89HDF\r\n\x1a\n" + b"\xff" * 64)          # HDF5 signature, garbage behind it
+    with pytest.raises(ValueError):
+        ds.open_dataset("y.nc", ds.read_namelist("inputs/namelist"))
     with pytest.raises(FileNotFoundError):
         ds.open_dataset("missing.nc", ds.read_namelist("inputs/namelist"))

@@ -72,3 +72,22 @@ def test_packed_int16_file_streamed_equals_resident(workdir, chunk_steps):
     assert torch.isfinite(a.scalars[:, :4]).all()
     full_bytes = 5 * 7 * 9 * 49 * 144 * 2
     assert stats["bytes_moved"] <= 1.6 * full_bytes                            # int16 over PCIe (+ T halo), not fp64
+
+
+@pytest.mark.parametrize("name,storage", [("packed_chunked_tracked.nc", "float64"), ("float_chunked_latest.nc", "float32"),
+                                          ("packed_chunked_earliest.nc", "float64")])
+def test_netcdf4_file_streamed_equals_resident(workdir, name, storage):
+    """NetCDF-4 / HDF5 input (hdf5_lite): chunks are inflated on the host per time step, then take the same device path."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "tests", "golden", "hdf5", name)
+    (workdir / "inputs" / "namelist").write_text(
+        ";Variable;Units\nAir Temperature;t;K\nGeopotential;z;m**2/s**2\nOmega Velocity;w;Pa/s\n"
+        "Eastward Wind Component;u;m/s\nNorthward Wind Component;v;m/s\nLongitude;longitude\nLatitude;latitude\n"
+        "Time;time\nVertical Level;level\n")
+    limits = (-60.0, 30.0, -40.0, 30.0)
+    (workdir / "inputs" / "box_limits").write_text("min_lon;-60\nmax_lon;30\nmin_lat;-40\nmax_lat;30\n")
+    a, b, stats = _both_paths(path, "inputs/namelist", limits, 2)
+    assert stats["storage"] == storage and stats["chunks"] == 3
+    assert torch.equal(a.scalars, b.scalars)
+    assert np.array_equal(a.levels.cpu().numpy(), b.levels.cpu().numpy(), equal_nan=True)
+    assert torch.isfinite(a.scalars[:, :4]).all()

@@ -1,0 +1,116 @@
+"""NetCDF-4 / HDF5 input through the pure-Python reader (hdf5_lite): the committed fixtures were written with h5py by
+tools/make_hdf5_fixtures.py (h5py exists only in the build container's conda interpreter); their content is a pure
+function of a seed, so the expected arrays are regenerated here.  Variants: old-style group + v1 chunk B-tree
+(libver earliest), creation-order tracked group with dense links and dense attributes, libver latest with the fixed-
+array chunk index, contiguous and chunked, shuffle + deflate, int16-packed and float32, fixed- and variable-length
+string attributes, dimension scales."""
+import argparse
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+from lorenzcycletoolkit_amd import dataset as ds
+from lorenzcycletoolkit_amd import hdf5_lite, ingest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FIX = os.path.join(ROOT, "tests", "golden", "hdf5")
+FILES = ["packed_chunked_earliest.nc", "packed_chunked_tracked.nc", "float_contiguous_latest.nc", "float_chunked_latest.nc"]
+
+
+def _generator():
+    """fields() / pack() of the fixture writer, without importing h5py."""
+    src = open(os.path.join(ROOT, "tools", "make_hdf5_fixtures.py")).read().replace("import h5py\n", "")
+    mod = {"__name__": "fixtures", "__file__": os.path.join(ROOT, "tools", "make_hdf5_fixtures.py")}
+    exec(compile(src, "make_hdf5_fixtures", "exec"), mod)
+    return mod
+
+
+@pytest.mark.parametrize("name", FILES)
+def test_reader_reproduces_the_written_arrays(name):
+    gen = _generator()
+    lev, lat, lon, f = gen["fields"](5, 6, 13, 24)
+    h = hdf5_lite.H5File(os.path.join(FIX, name))
+    assert np.array_equal(h.variables["level"].read(), lev.astype(np.int32))
+    assert np.array_equal(h.variables["latitude"].read(), lat.astype(np.float32))
+    assert np.array_equal(h.variables["longitude"].read(), lon.astype(np.float32))
+    assert h.variables["time"].attrs["units"] == "hours since 2020-01-01 00:00:00"
+    assert h.variables["level"].attrs["units"] == "millibars"
+    for vn, a in f.items():
+        v = h.variables[vn]
+        assert v.dims == ("time", "level", "latitude", "longitude") and v.shape == a.shape
+        got = v.read()
+        if name.startswith("packed"):
+            q, scale, offset = gen["pack"](a)
+            if vn == "v":
+                q[1, 0, :, :] = -32767
+            assert got.dtype == np.int16 and np.array_equal(got, q)
+            # (regenerated under another NumPy version: the last bit of min / max arithmetic may differ)
+            assert v.attrs["scale_factor"] == pytest.approx(scale, rel=1e-12) and v.attrs["add_offset"] == pytest.approx(offset, rel=1e-12)
+            assert v.attrs["_FillValue"] == -32767 and isinstance(v.attrs["scale_factor"], float)
+        else:
+            assert got.dtype == np.float32 and np.array_equal(got, a.astype(np.float32))
+        for t in (0, 3, -1):
+            assert np.array_equal(v[t], got[t])                 # time-step reads assemble the same chunks
+        assert v.attrs["units"] == "K" and v.attrs["long_name"] == "field " + vn
+        if "tracked" in name or "contiguous" in name:
+            assert v.attrs["extra_07"] == 7.0                   # dense attribute storage
+    h.close()
+
+
+@pytest.fixture
+def workdir(tmp_path, monkeypatch):
+    os.makedirs(tmp_path / "inputs")
+    (tmp_path / "inputs" / "namelist").write_text(
+        ";Variable;Units\nAir Temperature;t;K\nGeopotential;z;m**2/s**2\nOmega Velocity;w;Pa/s\n"
+        "Eastward Wind Component;u;m/s\nNorthward Wind Component;v;m/s\nLongitude;longitude\nLatitude;latitude\n"
+        "Time;time\nVertical Level;level\n")
+    (tmp_path / "inputs" / "box_limits").write_text("min_lon;-60\nmax_lon;30\nmin_lat;-40\nmax_lat;30\n")
+    monkeypatch.chdir(tmp_path)
+    return tmp_path
+
+
+@pytest.mark.parametrize("name", FILES)
+def test_prepare_data_from_hdf5(workdir, name):
+    """The whole host preparation on a NetCDF-4 file: decode, longitude wrap, sorts, 10 hPa filter, crop."""
+    gen = _generator()
+    lev, lat, lon, f = gen["fields"](5, 6, 13, 24)
+    args = argparse.Namespace(infile=os.path.join(FIX, name), fixed=True, track=False, trackfile=None, cdsapi=False)
+    data = ds.prepare_data(args, "inputs/namelist")
+    assert data.level.tolist() == [20000.0, 30000.0, 50000.0, 70000.0, 85000.0, 100000.0]
+    assert np.all(np.diff(data.lat) > 0) and np.all(np.diff(data.lon) > 0)
+    assert data.lon[0] == -60.0 and data.lon[-1] == 30.0 and data.lat[0] == -40.0 and data.lat[-1] == 30.0
+    assert data.time[1] - data.time[0] == np.timedelta64(6, "h")
+    # one element by hand: 500 hPa (file level index 3), lat -40 (file index 10), lon 0 (file index 0), time 2
+    j, i = int(np.argmin(np.abs(lat - data.lat[0]))), 0
+    T = data.variables["t"]
+    k_out, i_out = data.level.tolist().index(50000.0), data.lon.tolist().index(0.0)
+    if name.startswith("packed"):
+        q, _, _ = gen["pack"](f["t"])
+        h = hdf5_lite.H5File(args.infile)
+        scale, offset = h.variables["t"].attrs["scale_factor"], h.variables["t"].attrs["add_offset"]
+        h.close()
+        assert T.dtype == np.float64 and T[2, k_out, 0, i_out] == q[2, 3, j, i] * scale + offset
+        assert np.isnan(data.variables["v"][1, -1]).all()        # the fill values of the 1000 hPa level
+    else:
+        assert T.dtype == np.float32 and T[2, k_out, 0, i_out] == np.float32(f["t"][2, 3, j, i])
+    # and the device-ingest plan over the same file gives the same arrays
+    df = ds.read_namelist("inputs/namelist")
+    raw = ds.open_raw(args.infile, df)
+    plan = ingest.make_plan(raw, args)
+    from tests.test_ingest_cpu import _emulate_lec_ingest
+    for vn, var in raw.variables.items():
+        assert np.array_equal(_emulate_lec_ingest(var, plan), data.variables[vn], equal_nan=True), vn
+    raw.close()
+
+
+def test_unsupported_filter_is_reported(tmp_path):
+    """A filter the reader does not know must fail loudly, not decode garbage."""
+    h = hdf5_lite.H5File(os.path.join(FIX, "packed_chunked_earliest.nc"))
+    v = h.variables["t"]
+    v._filters = [(32015, [])] + list(v._filters)              # zstd's registered id
+    v._cache.clear()
+    with pytest.raises(hdf5_lite.Hdf5Error, match="filter"):
+        v.read()
+    h.close()

@@ -1,0 +1,90 @@
+#!/opt/conda/bin/python3.9
+"""Writes the small NetCDF-4-style HDF5 fixtures under tests/golden/hdf5/ with h5py (available only in this
+container's /opt/conda python, not on the GPU box -- hence committed fixtures).  They imitate what netCDF-C /
+h5netcdf produce: dimension scales with DIMENSION_LIST references, chunked + shuffle + deflate int16 variables with
+scale_factor / add_offset / _FillValue, fixed- and variable-length string attributes, creation-order tracking, old-
+and new-style groups.  The data are a pure function of the seed below, so tests regenerate the expected arrays.
+
+    /opt/conda/bin/python3.9 tools/make_hdf5_fixtures.py
+"""
+import os
+import sys
+
+import h5py
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "tests", "golden", "hdf5")
+
+
+def fields(nt, nl, ny, nx, seed=7):
+    rng = np.random.default_rng(seed)
+    lev = np.array([1000, 850, 700, 500, 300, 200, 100, 50, 5][:nl], dtype=np.float64)
+    lat = np.linspace(60.0, -60.0, ny)
+    lon = np.arange(nx) * (360.0 / nx)
+    p = (lev[None, :, None, None] * 100.0) / 1e5
+    shp = (nt, nl, ny, nx)
+    f = {
+        "t": 288.0 * p ** 0.19 + 8.0 * np.cos(np.deg2rad(2 * lat))[None, None, :, None] * p + rng.standard_normal(shp),
+        "u": 20.0 * np.cos(np.deg2rad(lat))[None, None, :, None] * (1 - p / 1.2) + 5 * rng.standard_normal(shp),
+        "v": 3.0 * rng.standard_normal(shp),
+        "w": 0.1 * rng.standard_normal(shp),
+        "z": 9.80665 * 7000.0 * np.log(1.0 / p) + 100.0 * rng.standard_normal(shp),
+    }
+    return lev, lat, lon, f
+
+
+def pack(a):
+    lo, hi = a.min(), a.max()
+    scale = (hi - lo) / 65000.0
+    offset = 0.5 * (hi + lo)
+    return np.clip(np.round((a - offset) / scale), -32000, 32000).astype(np.int16), float(scale), float(offset)
+
+
+def write(path, libver, track_order, packed, chunks, vlen_units, many_attrs, nt=5, nl=6, ny=13, nx=24):
+    lev, lat, lon, f = fields(nt, nl, ny, nx)
+    with h5py.File(path, "w", libver=libver, track_order=track_order) as h:
+        h.attrs["Conventions"] = np.string_("CF-1.6")
+        coords = {"time": (6 * np.arange(nt)).astype(np.int32), "level": lev.astype(np.int32),
+                  "latitude": lat.astype(np.float32), "longitude": lon.astype(np.float32)}
+        for name, vals in coords.items():
+            d = h.create_dataset(name, data=vals)
+            d.make_scale(name)
+        units = {"time": "hours since 2020-01-01 00:00:00", "level": "millibars", "latitude": "degrees_north", "longitude": "degrees_east"}
+        for name, u in units.items():
+            h[name].attrs["units"] = u if vlen_units else np.string_(u)
+        for name, a in f.items():
+            kw = {}
+            if chunks:
+                kw = dict(chunks=(1, 2, ny, nx // 2), compression="gzip", compression_opts=4, shuffle=True)
+            if packed:
+                q, scale, offset = pack(a)
+                if name == "v":
+                    q[1, 0, :, :] = -32767
+                d = h.create_dataset(name, data=q, **kw)
+                d.attrs["scale_factor"] = np.float64(scale)
+                d.attrs["add_offset"] = np.float64(offset)
+                d.attrs["_FillValue"] = np.int16(-32767)
+                d.attrs["missing_value"] = np.int16(-32767)
+            else:
+                d = h.create_dataset(name, data=a.astype(np.float32), **kw)
+            d.attrs["units"] = "K" if vlen_units else np.string_("K")
+            d.attrs["long_name"] = np.string_("field " + name)
+            if many_attrs:
+                for i in range(10):
+                    d.attrs["extra_%02d" % i] = np.float32(i)
+            for i, dn in enumerate(("time", "level", "latitude", "longitude")):
+                d.dims[i].attach_scale(h[dn])
+        if many_attrs:      # more than 8 links: dense link storage in new-style groups
+            for i in range(6):
+                h.create_dataset("pad_%d" % i, data=np.arange(3, dtype=np.int32))
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    write(os.path.join(OUT, "packed_chunked_earliest.nc"), "earliest", False, True, True, False, False)
+    write(os.path.join(OUT, "packed_chunked_tracked.nc"), ("earliest", "v110"), True, True, True, True, True)
+    write(os.path.join(OUT, "float_contiguous_latest.nc"), "latest", True, False, False, True, True)
+    write(os.path.join(OUT, "float_chunked_latest.nc"), "latest", False, False, True, False, False)
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
