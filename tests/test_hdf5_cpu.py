@@ -16,7 +16,8 @@ from lorenzcycletoolkit_amd import hdf5_lite, ingest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FIX = os.path.join(ROOT, "tests", "golden", "hdf5")
-FILES = ["packed_chunked_earliest.nc", "packed_chunked_tracked.nc", "float_contiguous_latest.nc", "float_chunked_latest.nc"]
+FILES = ["packed_chunked_earliest.nc", "packed_chunked_tracked.nc", "float_contiguous_latest.nc", "float_chunked_latest.nc",
+         "packed_unlimited_v18.nc"]       # the last: unlimited time dimension (chunked coordinate), fletcher32 checksums
 
 
 def _generator():
@@ -54,7 +55,7 @@ def test_reader_reproduces_the_written_arrays(name):
         for t in (0, 3, -1):
             assert np.array_equal(v[t], got[t])                 # time-step reads assemble the same chunks
         assert v.attrs["units"] == "K" and v.attrs["long_name"] == "field " + vn
-        if "tracked" in name or "contiguous" in name:
+        if "chunked_tracked" in name or "contiguous" in name:
             assert v.attrs["extra_07"] == 7.0                   # dense attribute storage
     h.close()
 

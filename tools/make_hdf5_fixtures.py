@@ -41,14 +41,17 @@ def pack(a):
     return np.clip(np.round((a - offset) / scale), -32000, 32000).astype(np.int16), float(scale), float(offset)
 
 
-def write(path, libver, track_order, packed, chunks, vlen_units, many_attrs, nt=5, nl=6, ny=13, nx=24):
+def write(path, libver, track_order, packed, chunks, vlen_units, many_attrs, nt=5, nl=6, ny=13, nx=24, unlimited=False):
     lev, lat, lon, f = fields(nt, nl, ny, nx)
     with h5py.File(path, "w", libver=libver, track_order=track_order) as h:
         h.attrs["Conventions"] = np.string_("CF-1.6")
         coords = {"time": (6 * np.arange(nt)).astype(np.int32), "level": lev.astype(np.int32),
                   "latitude": lat.astype(np.float32), "longitude": lon.astype(np.float32)}
         for name, vals in coords.items():
-            d = h.create_dataset(name, data=vals)
+            if unlimited and name == "time":     # netCDF's record dimension: extendible, hence chunked
+                d = h.create_dataset(name, data=vals, maxshape=(None,), chunks=(4,))
+            else:
+                d = h.create_dataset(name, data=vals)
             d.make_scale(name)
         units = {"time": "hours since 2020-01-01 00:00:00", "level": "millibars", "latitude": "degrees_north", "longitude": "degrees_east"}
         for name, u in units.items():
@@ -57,6 +60,8 @@ def write(path, libver, track_order, packed, chunks, vlen_units, many_attrs, nt=
             kw = {}
             if chunks:
                 kw = dict(chunks=(1, 2, ny, nx // 2), compression="gzip", compression_opts=4, shuffle=True)
+            if unlimited:
+                kw.update(maxshape=(None, nl, ny, nx), fletcher32=True)
             if packed:
                 q, scale, offset = pack(a)
                 if name == "v":
@@ -86,5 +91,6 @@ if __name__ == "__main__":
     write(os.path.join(OUT, "packed_chunked_tracked.nc"), ("earliest", "v110"), True, True, True, True, True)
     write(os.path.join(OUT, "float_contiguous_latest.nc"), "latest", True, False, False, True, True)
     write(os.path.join(OUT, "float_chunked_latest.nc"), "latest", False, False, True, False, False)
+    write(os.path.join(OUT, "packed_unlimited_v18.nc"), ("earliest", "v108"), True, True, True, False, False, unlimited=True)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
