@@ -655,17 +655,21 @@ class H5File:
         fill = var.attrs.get("_FillValue")
         if fill is not None and not isinstance(fill, (list, str)):
             out[...] = fill
-        for offs, (addr, size, mask) in table.items():
-            if offs[0] + chunk[0] <= lo0 or offs[0] >= hi0:
-                continue
-            key = offs
-            data = var._cache.get(("chunk", key))
-            if data is None:
-                data = self._read_chunk(var, addr, size, mask).reshape(chunk)
-                if len(var._cache) > 64:
-                    for k in [k for k in var._cache if isinstance(k, tuple) and k and k[0] == "chunk"][:32]:
-                        del var._cache[k]
-                var._cache[("chunk", key)] = data
+        need = [(offs, loc) for offs, loc in table.items() if offs[0] + chunk[0] > lo0 and offs[0] < hi0]
+        missing = [(offs, loc) for offs, loc in need if ("chunk", offs) not in var._cache]
+        if len(var._cache) + len(missing) > 256:               # bounded chunk cache (time-step reads revisit chunks that span steps)
+            for k in [k for k in var._cache if isinstance(k, tuple) and k and k[0] == "chunk"]:
+                del var._cache[k]
+            missing = need
+        inflate = lambda item: (item[0], self._read_chunk(var, *item[1]).reshape(chunk))
+        if len(missing) > 1 and var._filters:
+            results = list(_inflate_pool().map(inflate, missing))          # zlib releases the GIL
+        else:
+            results = [inflate(item) for item in missing]
+        for offs, data in results:
+            var._cache[("chunk", offs)] = data
+        for offs, _loc in need:
+            data = var._cache[("chunk", offs)]
             src, dst = [], []
             for d in range(len(shape)):
                 a0 = max(offs[d], lo0 if d == 0 else 0)
@@ -674,6 +678,18 @@ class H5File:
                 dst.append(slice(a0 - (lo0 if d == 0 else 0), a1 - (lo0 if d == 0 else 0)))
             out[tuple(dst)] = data[tuple(src)]
         return out if t is None else out[0]
+
+
+_POOL = None
+
+
+def _inflate_pool():
+    global _POOL
+    if _POOL is None:
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL = ThreadPoolExecutor(max_workers=max(1, min(16, os.cpu_count() or 1)), thread_name_prefix="h5-inflate")
+    return _POOL
 
 
 def is_hdf5(path: str) -> bool:
