@@ -189,7 +189,7 @@ def main():
                              f"fixed box = whole grid, storage {args.storage}, terms = ")
                             + ("Az Ae Kz Ke Cz Ca Ck Ce BAz BAe BKz BKe (T,u,v,omega only)" if args.no_q else "all 16 (incl. BPhi, Gz, Ge)"),
                 "timesteps_per_gpu": T_local, "timesteps_global": T_global,
-                "parallelism": f"time-sharded x{world}, RCCL all_gather of per-time-step results",
+                "parallelism": f"time-sharded x{world}, RCCL all_reduce of the NaN-level mask + all_gather of per-time-step results",
                 "results_finite": finite,
             },
             "roofline": {

@@ -655,7 +655,14 @@ class H5File:
         fill = var.attrs.get("_FillValue")
         if fill is not None and not isinstance(fill, (list, str)):
             out[...] = fill
-        need = [(offs, loc) for offs, loc in table.items() if offs[0] + chunk[0] > lo0 and offs[0] < hi0]
+        if "by_t" not in var._cache:                           # chunks grouped by their first-axis offset: a time-step read looks at its own only
+            by_t = {}
+            for offs, loc in table.items():
+                by_t.setdefault(offs[0], []).append((offs, loc))
+            var._cache["by_t"] = by_t
+        by_t = var._cache["by_t"]
+        first = (lo0 // chunk[0]) * chunk[0]
+        need = [item for o0 in range(first, hi0, chunk[0]) for item in by_t.get(o0, ())]
         missing = [(offs, loc) for offs, loc in need if ("chunk", offs) not in var._cache]
         if len(var._cache) + len(missing) > 256:               # bounded chunk cache (time-step reads revisit chunks that span steps)
             for k in [k for k in var._cache if isinstance(k, tuple) and k and k[0] == "chunk"]:
