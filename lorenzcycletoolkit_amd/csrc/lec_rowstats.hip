@@ -353,63 +353,54 @@ extern "C" int lec_rowstats(const lec_rowstats_args* a) {
     p.box = a->box_d; p.boxtab = a->boxtab_d; p.wlon = a->wlon_d; p.glon = a->glon_d;
     p.lattab = a->lattab_d; p.levtab = a->levtab_d; p.tcoef = a->tcoef_d;
     p.rows = a->rows_d;
-    // defaults from the round-1 A/B on MI355X (profiles/r01_notes.md): XCD-chunked latitude-fastest order and
-    // nontemporal loads for the once-read fields cut fabric reads by 36 % and time by 10-20 %
-    const int wq_mode = !a->with_q ? 0 : (a->dTdt_d ? 2 : 1);
-    p.order = 2; p.jchunk = 0;
-    long long nblocks = nrows;
-    {   // experiment knobs (defaults chosen from measurements)
-        const char* eo = getenv("LEC_ORDER");
-        // all terms with dT/dt from the cube on a fixed box: tiled order (see lec_rowsweep.hip); else latitude-fastest
-        if (wq_mode == 1 && a->n_box == 1 && a->t_count >= 2 && !kernel_is_two_sweep()) p.order = 7;
-        if (eo) p.order = atoi(eo);
-        const char* etg = getenv("LEC_TG"); const char* ejg = getenv("LEC_JG");
-        const int ntile = (a->t_count + 3) / 4;                   // time tiles of (almost) equal size, at most 4 steps each
-        p.tgroup = etg ? atoi(etg) : (a->t_count + ntile - 1) / ntile; p.jgroup = ejg ? atoi(ejg) : 8;
-        if (p.jgroup > (a->nyb_max + 7) / 8) p.jgroup = (a->nyb_max + 7) / 8;    // never wider than an XCD's latitude chunk
-        if (p.tgroup < 1) p.tgroup = 1;
-        if (p.jgroup < 1) p.jgroup = 1;
-        if (p.order == 7 && (wq_mode != 1 || a->n_box != 1 || kernel_is_two_sweep())) p.order = 2;
-        if (p.order) {
-            p.jchunk = (a->nyb_max + 7) / 8;
-            nblocks = (long long)a->t_count * 8 * p.jchunk * a->nl;
-            if (p.order == 7) {
-                const long long tgc = (a->t_count + p.tgroup - 1) / p.tgroup, jgc = (p.jchunk + p.jgroup - 1) / p.jgroup;
-                nblocks = 8LL * jgc * tgc * a->nl * p.tgroup * p.jgroup;
-            }
-            if (nblocks > 0x7fffffffLL) { p.order = 0; nblocks = nrows; }
-        }
-    }
     hipStream_t st = (hipStream_t)a->stream;
     const bool uni = a->lon_uniform != 0;
-    const int wq = !a->with_q ? 0 : (a->dTdt_d ? 2 : 1);
+    const int wq = !a->with_q ? 0 : (a->dTdt_d ? 2 : 1);      // Q: none / dT/dt from the cube's time axis / dT/dt cube
+    const bool two_sweep = kernel_is_two_sweep();
+
+    // Workgroup -> row order (speed only; defaults from the round-1 A/B on MI355X, profiles/r01_notes.md).  Workgroups are dealt
+    // to the 8 XCDs round-robin, so blockIdx % 8 labels the XCD: order 2 gives every XCD a contiguous latitude chunk, walked
+    // latitude-fastest per (time, level); order 7 (all terms on one fixed box) walks tiles of tgroup time steps x jgroup
+    // latitudes at one level, levels next; order 0 is memory order.  LEC_ORDER / LEC_TG / LEC_JG override (experiments).
+    const bool fixed_time_stencil = (wq == 1 && a->n_box == 1);
+    p.order = (fixed_time_stencil && a->t_count >= 2 && !two_sweep) ? 7 : 2;
+    if (const char* eo = getenv("LEC_ORDER")) p.order = atoi(eo);
+    if (p.order == 7 && (!fixed_time_stencil || two_sweep)) p.order = 2;
+    p.jchunk = p.order ? (a->nyb_max + 7) / 8 : 0;
+    const char* etg = getenv("LEC_TG"); const char* ejg = getenv("LEC_JG");
+    const int ntile = (a->t_count + 3) / 4;                       // time tiles of (almost) equal size, at most 4 steps each
+    p.tgroup = etg ? atoi(etg) : (a->t_count + ntile - 1) / ntile;
+    p.jgroup = ejg ? atoi(ejg) : 8;
+    if (p.jgroup > (a->nyb_max + 7) / 8) p.jgroup = (a->nyb_max + 7) / 8;    // never wider than an XCD's latitude chunk
+    if (p.tgroup < 1) p.tgroup = 1;
+    if (p.jgroup < 1) p.jgroup = 1;
+
     int rc;
-    // 1 (default): single-sweep shifted-moment kernel (lec_rowsweep.hip); 0: two-sweep kernel (this file), kept as
-    // an independent formulation (deviation from the zonal mean, then products) for cross-checks
-    const char* ek = getenv("LEC_KERNEL");
-    const int kernel = ek ? atoi(ek) : 1;
-    // Single-sweep kernels (default).  All terms with dT/dt from the cube on one fixed box (the headline configuration):
-    // a row reads T(t+1) only and the time-derivative parts of [Q], [Q'T'] are completed from the records afterwards
-    // (lec_qtime_kernel); it runs on the
-    // row-block kernel, 2 time steps x 2 latitudes per workgroup (lec_rowblock.hip; fp64 storage: 17.6-17.9 vs 18.4 ms
-    // per 64 steps).  LEC_BLK=<bt><bk><bj> picks another block shape, LEC_BLK=0 the one-wave-per-row kernel everywhere
-    // (bit-identical results).
-    const char* eblk = getenv("LEC_BLK");
-    const int blk = eblk ? atoi(eblk) : (a->dtype == LEC_F64 ? 212 : 0);     // fp32 storage: no gain measured
-    if (kernel == 1) {
-        const int mode = (wq == 1 && a->n_box == 1) ? 3 : wq;       // time stencil on one fixed box: through cross-time covariances
+    if (two_sweep) {
+        // LEC_KERNEL=0: the two-sweep kernel of this file (deviation from the zonal mean, then products -- the reference's own
+        // order; Q per point), kept as an independent formulation for cross-checks
+        long long nblocks = p.order ? (long long)a->t_count * 8 * p.jchunk * a->nl : nrows;
+        if (nblocks > 0x7fffffffLL) { p.order = 0; nblocks = nrows; }
+        if (a->dtype == LEC_F64) rc = aligned ? launch_vec<double, 2>(p, uni, wq, (int)nblocks, st) : launch_vec<double, 1>(p, uni, wq, (int)nblocks, st);
+        else                     rc = aligned ? launch_vec<float, 4>(p, uni, wq, (int)nblocks, st) : launch_vec<float, 1>(p, uni, wq, (int)nblocks, st);
+    } else {
+        // Single-sweep kernels (default).  All terms with dT/dt from the cube on one fixed box (the headline configuration, mode
+        // 3): a row reads T(t+1) only and the time-derivative parts of [Q], [Q'T'] are completed from the records afterwards
+        // (lec_qtime_kernel).  With fp64 storage it runs on the row-block kernel, 2 time steps x 2 latitudes per workgroup
+        // (lec_rowblock.hip: 17.3-17.6 vs 17.5-17.9 ms per 64 steps); LEC_BLK=<bt><bk><bj> picks another block shape, LEC_BLK=0
+        // the one-wave-per-row kernel everywhere (bit-identical results; fp32 storage: no gain measured, not used).
+        const int mode = fixed_time_stencil ? 3 : wq;
+        const char* eblk = getenv("LEC_BLK");
+        const int blk = eblk ? atoi(eblk) : (a->dtype == LEC_F64 ? 212 : 0);
         const bool block_ok = blk > 0 && mode == 3 && a->geopt_d && a->t_count >= 2 && !getenv("LEC_ORDER");
         if (!block_ok) rc = lec_launch_rowsweep(p, a->dtype, aligned, aligned8, uni, mode, st);
         else {
             RowParams pb = p;
-            const char* etg = getenv("LEC_TG"); const char* ejg = getenv("LEC_JG");
             pb.order = 8; pb.tgroup = etg ? atoi(etg) : 2; pb.jgroup = ejg ? atoi(ejg) : 4;      // tile: 2 x 4 blocks at one level, levels next
             rc = lec_launch_rowblock(pb, a->dtype, aligned, aligned8, uni, blk / 100, (blk / 10) % 10, blk % 10, st);
         }
         if (rc == LEC_OK && mode == 3) rc = lec_launch_qtime(p, st);
     }
-    else if (a->dtype == LEC_F64) rc = aligned ? launch_vec<double, 2>(p, uni, wq, (int)nblocks, st) : launch_vec<double, 1>(p, uni, wq, (int)nblocks, st);
-    else                     rc = aligned ? launch_vec<float, 4>(p, uni, wq, (int)nblocks, st) : launch_vec<float, 1>(p, uni, wq, (int)nblocks, st);
     if (rc != LEC_OK) return lec_set_error(rc, "lec_rowstats: row too long for the compiled kernels");
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return lec_set_error(LEC_ERR_LAUNCH, hipGetErrorString(e));
