@@ -410,10 +410,74 @@ def field_scale(variable_list_df: pd.DataFrame, role: str) -> float:
     return _UNIT_SCALE[units] * (G if role == "Geopotential Height" else 1.0)
 
 
+@dataclass
+class IngestPlan:
+    """Index maps from the analysis domain (sorted, cropped) to file positions, plus the domain's coordinates."""
+    tsel: np.ndarray        # file time index of every processed time step
+    kmap: np.ndarray        # int32 [nl]
+    jmap: np.ndarray        # int32 [ny]
+    imap: np.ndarray        # int32 [nx]
+    lat: np.ndarray
+    lon: np.ndarray
+    level: np.ndarray       # Pa
+    time: np.ndarray        # datetime64[ns]
+
+    @property
+    def time_s(self) -> np.ndarray:
+        return (self.time - self.time.min()) / np.timedelta64(1, "s")
+
+
+def make_plan(raw: "RawDataset", args, app_logger=None) -> IngestPlan:
+    """process_data + slice_domain (preprocessing.py:149-371, select_area.py:254-338) as index maps."""
+    px = process_index(raw.lat, raw.lon, raw.level, raw.time, raw.level_units, raw.names, args, app_logger)
+    js, is_ = domain_slices(px.lat, px.lon, args)
+    tsel = np.arange(raw.time.size) if px.tpos is None else np.asarray(px.tpos)
+    i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+    return IngestPlan(tsel, i32(px.ik), i32(px.ij[js]), i32(px.io[is_]), px.lat[js], px.lon[is_], px.level, px.time)
+
+
+
+def gather_on_host(var: RawVariable, plan: IngestPlan) -> np.ndarray:
+    """The analysis-domain cube of one raw variable, decoded -- what lec_ingest does on the GPU, one time step at a time
+    on the host, so that only the selected time steps and the cropped domain are ever read from a large file."""
+    out = None
+    packed = var.scale_factor is not None or var.add_offset is not None
+    for n, ft in enumerate(plan.tsel):
+        raw = np.asarray(var.data[int(ft)])[plan.kmap][:, plan.jmap][:, :, plan.imap]
+        raw = raw.astype(raw.dtype.newbyteorder("="))
+        a = raw
+        if packed:
+            a = raw.astype(np.float64)
+            if var.scale_factor is not None:
+                a *= var.scale_factor
+            if var.add_offset is not None:
+                a += var.add_offset
+        if var.fill_value is not None and np.issubdtype(a.dtype, np.floating):
+            a = np.where(raw == var.fill_value, np.nan, a)
+        if out is None:
+            out = np.empty((len(plan.tsel),) + a.shape, dtype=a.dtype)
+        out[n] = a
+    return out
+
+
 def prepare_data(args, varlist: str = "inputs/namelist", app_logger=None) -> LECDataset:
-    """prepare_data (preprocessing.py:374-413)."""
+    """prepare_data (preprocessing.py:374-413): open, process, crop.  The reference relies on xarray's lazy indexing to touch
+    only what the analysis needs; here the index maps are built from the coordinates first (make_plan) and the variables are
+    gathered time step by time step.  Files whose variables are not in (time, level, lat, lon) order take the whole-file
+    path (open_dataset + process_data + slice_domain), which gives the same arrays."""
     if getattr(args, "cdsapi", False):
         raise NotImplementedError("--cdsapi downloads need network access and are out of scope")
     variable_list_df = read_namelist(varlist, app_logger)
-    data = open_dataset(args.infile, variable_list_df)
-    return slice_domain(process_data(data, args, variable_list_df, app_logger), args, variable_list_df)
+    try:
+        raw = open_raw(args.infile, variable_list_df)
+    except ValueError as e:
+        if "order" not in str(e) and "device ingest reads" not in str(e):
+            raise
+        data = open_dataset(args.infile, variable_list_df)
+        return slice_domain(process_data(data, args, variable_list_df, app_logger), args, variable_list_df)
+    try:
+        plan = make_plan(raw, args, app_logger)
+        variables = {name: gather_on_host(var, plan) for name, var in raw.variables.items()}
+        return LECDataset(variables, plan.lat, plan.lon, plan.level, plan.time, dict(raw.names), "Pa")
+    finally:
+        raw.close()

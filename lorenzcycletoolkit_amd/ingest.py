@@ -33,30 +33,7 @@ _ROLE_KEYS = {"Air Temperature": "tair", "Eastward Wind Component": "u", "Northw
               "Omega Velocity": "omega"}
 
 
-@dataclass
-class IngestPlan:
-    """Index maps from the analysis domain (sorted, cropped) to file positions, plus the domain's coordinates."""
-    tsel: np.ndarray        # file time index of every processed time step
-    kmap: np.ndarray        # int32 [nl]
-    jmap: np.ndarray        # int32 [ny]
-    imap: np.ndarray        # int32 [nx]
-    lat: np.ndarray
-    lon: np.ndarray
-    level: np.ndarray       # Pa
-    time: np.ndarray        # datetime64[ns]
-
-    @property
-    def time_s(self) -> np.ndarray:
-        return (self.time - self.time.min()) / np.timedelta64(1, "s")
-
-
-def make_plan(raw: ds.RawDataset, args, app_logger=None) -> IngestPlan:
-    """process_data + slice_domain (preprocessing.py:149-371, select_area.py:254-338) as index maps."""
-    px = ds.process_index(raw.lat, raw.lon, raw.level, raw.time, raw.level_units, raw.names, args, app_logger)
-    js, is_ = ds.domain_slices(px.lat, px.lon, args)
-    tsel = np.arange(raw.time.size) if px.tpos is None else np.asarray(px.tpos)
-    i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
-    return IngestPlan(tsel, i32(px.ik), i32(px.ij[js]), i32(px.io[is_]), px.lat[js], px.lon[is_], px.level, px.time)
+IngestPlan, make_plan = ds.IngestPlan, ds.make_plan        # the index maps are built on the host side of the package
 
 
 @dataclass

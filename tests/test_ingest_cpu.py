@@ -99,3 +99,44 @@ def test_open_raw_rejects_what_the_kernel_cannot_read(workdir, golden_dir):
     df = ds.read_namelist("inputs/namelist")
     with pytest.raises(ValueError, match="order"):
         ds.open_raw(path, df)
+
+
+def test_prepare_data_is_the_lazy_gather_and_equals_the_whole_file_path(workdir, golden_dir):
+    (workdir / "inputs" / "box_limits").write_text("min_lon;-55\nmax_lon;-36\nmin_lat;-35\nmax_lat;-20\n")
+    args = argparse.Namespace(fixed=True, track=False, trackfile=None, cdsapi=False,
+                              infile=os.path.join(golden_dir, "Catarina_NCEP-R2.nc"))
+    df = ds.read_namelist("inputs/namelist")
+    whole = ds.slice_domain(ds.process_data(ds.open_dataset(args.infile, df), args, df), args, df)
+    lazy = ds.prepare_data(args, "inputs/namelist")
+    assert np.array_equal(lazy.lat, whole.lat) and np.array_equal(lazy.lon, whole.lon) and np.array_equal(lazy.time, whole.time)
+    for k in whole.variables:
+        assert lazy.variables[k].dtype == whole.variables[k].dtype and np.array_equal(lazy.variables[k], whole.variables[k]), k
+
+
+def test_prepare_data_falls_back_for_other_axis_orders(workdir):
+    """A file whose variables are (time, lat, level, lon) cannot be streamed; the whole-file path transposes it."""
+    from scipy.io import netcdf_file
+    rng = np.random.default_rng(2)
+    path = str(workdir / "odd.nc")
+    f = netcdf_file(path, "w")
+    sizes = {"time": 3, "level": 4, "lat": 6, "lon": 8}
+    coords = {"time": np.arange(3) * 6.0, "level": np.array([1000.0, 850.0, 500.0, 200.0]), "lat": np.linspace(-50, -25, 6), "lon": np.linspace(-60, -25, 8)}
+    for n, sz in sizes.items():
+        f.createDimension(n, sz)
+        v = f.createVariable(n, "d", (n,)); v[:] = coords[n]
+    f.variables["time"].units = "hours since 2000-01-01"
+    f.variables["level"].units = "hPa"
+    data = {}
+    for n in ("t", "u", "v", "w", "z"):
+        data[n] = rng.standard_normal((3, 6, 4, 8))
+        v = f.createVariable(n, "d", ("time", "lat", "level", "lon")); v[:] = data[n]
+    f.close()
+    (workdir / "inputs" / "namelist").write_text(
+        ";Variable;Units\nAir Temperature;t;K\nGeopotential;z;m**2/s**2\nOmega Velocity;w;Pa/s\n"
+        "Eastward Wind Component;u;m/s\nNorthward Wind Component;v;m/s\nLongitude;lon\nLatitude;lat\nTime;time\nVertical Level;level\n")
+    (workdir / "inputs" / "box_limits").write_text("min_lon;-55\nmax_lon;-30\nmin_lat;-45\nmax_lat;-30\n")
+    args = argparse.Namespace(fixed=True, track=False, trackfile=None, cdsapi=False, infile=path)
+    got = ds.prepare_data(args, "inputs/namelist")
+    assert got.variables["t"].shape == (3, 4, 4, 6) and got.level.tolist() == [20000.0, 50000.0, 85000.0, 100000.0]
+    want = np.transpose(data["t"], (0, 2, 1, 3))[:, ::-1][:, :, 1:5][:, :, :, 1:7]
+    assert np.array_equal(got.variables["t"], want)
