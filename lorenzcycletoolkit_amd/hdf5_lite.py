@@ -6,13 +6,13 @@ gridded data:
 * the root group as a symbol table (v1 B-tree + local heap), as compact link messages, or as dense link storage
   (v2 B-tree name index + fractal heap);
 * datasets: contiguous, compact, and chunked (layout v3 with a v1 B-tree; layout v4 single-chunk / implicit /
-  fixed-array indexes), filters deflate + shuffle (+ fletcher32, ignored);
+  fixed-array / extensible-array indexes), filters deflate + shuffle (+ fletcher32, ignored);
 * datatypes: integers and IEEE floats of 1-8 bytes in either byte order, fixed- and variable-length strings,
   object references (for DIMENSION_LIST);
 * attributes in the object header or in dense storage.
 
 Not supported (raises Hdf5Error): sub-groups, compound / enum data, other filters (szip, lzf, zstd ...), external or
-virtual storage, extensible-array and v2-B-tree chunk indexes.  Format reference: "HDF5 File Format Specification
+virtual storage, the v2-B-tree chunk index (more than one unlimited dimension).  Format reference: "HDF5 File Format Specification
 Version 3.0" (The HDF Group).
 """
 from __future__ import annotations
@@ -492,7 +492,18 @@ class H5File:
                 filters = self._filter_pipeline(p)
         if dt is None or shape is None or layout is None or dt.kind != "num":
             return None
-        return H5Variable(name, tuple(shape), dt.np_dtype, self._attributes(msgs), (), self, layout, filters)
+        var = H5Variable(name, tuple(shape), dt.np_dtype, self._attributes(msgs), (), self, layout, filters)
+        for mtype, p, size in msgs:                            # fill value of chunks that were never written
+            if mtype == 0x05:
+                ver = self._m[p]
+                q = None
+                if ver in (1, 2) and (ver == 1 or self._m[p + 3]):
+                    q = p + 4
+                elif ver == 3 and self._m[p + 1] & 0x20:
+                    q = p + 2
+                if q is not None and self._u(q, 4) == dt.size:
+                    var._cache["fill"] = np.frombuffer(self._m[q + 4: q + 4 + dt.size], dtype=dt.np_dtype)[0]
+        return var
 
     def _layout(self, p) -> dict:
         m = self._m
@@ -529,8 +540,10 @@ class H5File:
                     lay.update(index="implicit", addr=self._addr(q))
                 elif itype == 3:
                     lay.update(index="farray", addr=self._addr(q + 1))
+                elif itype == 4:
+                    lay.update(index="earray", addr=self._addr(q + 5))
                 else:
-                    raise Hdf5Error(f"chunk index type {itype} (extensible array / v2 B-tree) not supported")
+                    raise Hdf5Error(f"chunk index type {itype} (v2 B-tree: more than one unlimited dimension) not supported")
                 return lay
         raise Hdf5Error(f"data layout version {ver} class {cls} not supported")
 
@@ -585,6 +598,12 @@ class H5File:
                 walk(lay["addr"])
         elif lay["index"] == "single":
             table[(0,) * rank] = (lay["addr"], lay["fsize"] if lay["fsize"] is not None else nbytes, lay["fmask"])
+        elif lay["index"] == "earray":
+            counts = [-(-s // c) for s, c in zip(var.shape, chunk)]
+            coords = list(np.ndindex(*counts))
+            for i, (caddr, csize, cmask) in enumerate(self._earray_elements(lay["addr"], len(coords), nbytes)):
+                if caddr != (1 << (8 * self.O)) - 1:
+                    table[tuple(ci * ch for ci, ch in zip(coords[i], chunk))] = (caddr, csize, cmask)
         else:
             counts = [-(-s // c) for s, c in zip(var.shape, chunk)]
             coords = list(np.ndindex(*counts))
@@ -613,6 +632,84 @@ class H5File:
                         table[off] = (self._addr(p), self._u(p + self.O, csz), self._u(p + self.O + csz, 4)); p += esize
         var._cache["table"] = table
         return table
+
+    def _earray_elements(self, addr: int, want: int, chunk_bytes: int):
+        """The first `want` chunk records (address, stored size, filter mask) of an extensible-array chunk index
+        (one unlimited dimension, written with libver >= v110)."""
+        m, a = self._m, addr + self.base
+        if m[a: a + 4] != b"EAHD":
+            raise Hdf5Error("bad extensible array header")
+        client, esize, max_bits, idx_elmts, dblk_min, sblk_min_ptrs, page_bits = (m[a + 5 + i] for i in range(7))
+        nelmts_set = self._len(a + 12 + 4 * self.L)          # max_idx_set
+        iblk = self._addr(a + 12 + 6 * self.L) + self.base
+        undef = (1 << (8 * self.O)) - 1
+        off_size = (max_bits + 7) // 8
+        page_n = 1 << page_bits
+
+        def element(p):
+            if client == 0:
+                return self._addr(p), chunk_bytes, 0
+            csz = esize - self.O - 4
+            return self._addr(p), self._u(p + self.O, csz), self._u(p + self.O + csz, 4)
+
+        out = []
+        if m[iblk: iblk + 4] != b"EAIB":
+            raise Hdf5Error("bad extensible array index block")
+        p = iblk + 6 + self.O
+        for _ in range(idx_elmts):
+            out.append(element(p)); p += esize
+        nsblks_total = 1 + (max_bits - (dblk_min.bit_length() - 1))
+        iblk_nsblks = 2 * (sblk_min_ptrs.bit_length() - 1)
+        ndblk_addrs = 2 * (sblk_min_ptrs - 1)
+        dblk_addrs = [self._addr(p + i * self.O) for i in range(ndblk_addrs)]
+        p += ndblk_addrs * self.O
+        sblk_addrs = [self._addr(p + i * self.O) for i in range(max(nsblks_total - iblk_nsblks, 0))]
+
+        def data_block(daddr, nel):
+            if daddr == undef:
+                out.extend([(undef, 0, 0)] * nel)
+                return
+            b = daddr + self.base
+            if m[b: b + 4] != b"EADB":
+                raise Hdf5Error("bad extensible array data block")
+            q = b + 6 + self.O + off_size
+            if nel <= page_n:
+                for _ in range(nel):
+                    out.append(element(q)); q += esize
+            else:                                      # paged: the pages follow the block's own checksum, each with a checksum
+                q += 4
+                for _ in range(nel // page_n):
+                    for _ in range(page_n):
+                        out.append(element(q)); q += esize
+                    q += 4
+
+        di = 0
+        for u in range(nsblks_total):
+            if len(out) >= want:
+                break
+            ndblks, nel = 1 << (u // 2), (1 << ((u + 1) // 2)) * dblk_min
+            if u < iblk_nsblks:
+                for _ in range(ndblks):
+                    if len(out) >= want:
+                        break
+                    data_block(dblk_addrs[di], nel); di += 1
+            else:
+                saddr = sblk_addrs[u - iblk_nsblks]
+                if saddr == undef:
+                    out.extend([(undef, 0, 0)] * (ndblks * nel))
+                    continue
+                b = saddr + self.base
+                if m[b: b + 4] != b"EASB":
+                    raise Hdf5Error("bad extensible array super block")
+                q = b + 6 + self.O + off_size
+                if nel > page_n:                       # page-initialised bitmaps, one per data block
+                    q += ndblks * (((nel // page_n) + 7) // 8)
+                for i in range(ndblks):
+                    if len(out) >= want:
+                        break
+                    data_block(self._addr(q + i * self.O), nel)
+        _ = nelmts_set
+        return out[:want]
 
     def _read_chunk(self, var: H5Variable, addr: int, size: int, mask: int) -> np.ndarray:
         raw = bytes(self._m[addr + self.base: addr + self.base + size])
@@ -652,7 +749,7 @@ class H5File:
         else:
             out = np.zeros((1,) + shape[1:], dtype=var.dtype)
             lo0, hi0 = t, t + 1
-        fill = var.attrs.get("_FillValue")
+        fill = var._cache.get("fill", var.attrs.get("_FillValue"))
         if fill is not None and not isinstance(fill, (list, str)):
             out[...] = fill
         if "by_t" not in var._cache:                           # chunks grouped by their first-axis offset: a time-step read looks at its own only

@@ -17,7 +17,8 @@ from lorenzcycletoolkit_amd import hdf5_lite, ingest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FIX = os.path.join(ROOT, "tests", "golden", "hdf5")
 FILES = ["packed_chunked_earliest.nc", "packed_chunked_tracked.nc", "float_contiguous_latest.nc", "float_chunked_latest.nc",
-         "packed_unlimited_v18.nc"]       # the last: unlimited time dimension (chunked coordinate), fletcher32 checksums
+         "packed_unlimited_v18.nc",       # unlimited time dimension (chunked coordinate), fletcher32 checksums
+         "packed_unlimited_latest.nc"]    # the same with libver latest: extensible-array chunk index
 
 
 def _generator():

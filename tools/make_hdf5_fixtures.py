@@ -92,5 +92,6 @@ if __name__ == "__main__":
     write(os.path.join(OUT, "float_contiguous_latest.nc"), "latest", True, False, False, True, True)
     write(os.path.join(OUT, "float_chunked_latest.nc"), "latest", False, False, True, False, False)
     write(os.path.join(OUT, "packed_unlimited_v18.nc"), ("earliest", "v108"), True, True, True, False, False, unlimited=True)
+    write(os.path.join(OUT, "packed_unlimited_latest.nc"), "latest", False, True, True, True, False, unlimited=True)    # extensible-array chunk index
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
