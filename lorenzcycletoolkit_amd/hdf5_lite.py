@@ -6,13 +6,13 @@ gridded data:
 * the root group as a symbol table (v1 B-tree + local heap), as compact link messages, or as dense link storage
   (v2 B-tree name index + fractal heap);
 * datasets: contiguous, compact, and chunked (layout v3 with a v1 B-tree; layout v4 single-chunk / implicit /
-  fixed-array / extensible-array indexes), filters deflate + shuffle (+ fletcher32, ignored);
+  fixed-array / extensible-array / v2-B-tree indexes), filters deflate + shuffle (+ fletcher32, ignored);
 * datatypes: integers and IEEE floats of 1-8 bytes in either byte order, fixed- and variable-length strings,
   object references (for DIMENSION_LIST);
 * attributes in the object header or in dense storage.
 
 Not supported (raises Hdf5Error): sub-groups, compound / enum data, other filters (szip, lzf, zstd ...), external or
-virtual storage, the v2-B-tree chunk index (more than one unlimited dimension).  Format reference: "HDF5 File Format Specification
+virtual storage, v2 B-trees deeper than two levels.  Format reference: "HDF5 File Format Specification
 Version 3.0" (The HDF Group).
 """
 from __future__ import annotations
@@ -542,8 +542,10 @@ class H5File:
                     lay.update(index="farray", addr=self._addr(q + 1))
                 elif itype == 4:
                     lay.update(index="earray", addr=self._addr(q + 5))
+                elif itype == 5:
+                    lay.update(index="btree2", addr=self._addr(q + 6))
                 else:
-                    raise Hdf5Error(f"chunk index type {itype} (v2 B-tree: more than one unlimited dimension) not supported")
+                    raise Hdf5Error(f"chunk index type {itype} not supported")
                 return lay
         raise Hdf5Error(f"data layout version {ver} class {cls} not supported")
 
@@ -598,6 +600,22 @@ class H5File:
                 walk(lay["addr"])
         elif lay["index"] == "single":
             table[(0,) * rank] = (lay["addr"], lay["fsize"] if lay["fsize"] is not None else nbytes, lay["fmask"])
+        elif lay["index"] == "btree2":                     # several unlimited dimensions: records carry the scaled chunk offsets
+            a = lay["addr"] + self.base
+            rtype = self._m[a + 5]
+            if rtype not in (10, 11):
+                raise Hdf5Error("unexpected v2 B-tree type for a chunk index")
+            rec_size = self._u(a + 10, 2)
+            csz = rec_size - self.O - 8 * rank - 4 if rtype == 11 else 0
+            for rec in self._btree2_records(lay["addr"], rtype):
+                caddr = int.from_bytes(rec[: self.O], "little")
+                q = self.O
+                size, mask = nbytes, 0
+                if rtype == 11:
+                    size = int.from_bytes(rec[q: q + csz], "little"); q += csz
+                    mask = int.from_bytes(rec[q: q + 4], "little"); q += 4
+                offs = tuple(int.from_bytes(rec[q + 8 * d: q + 8 * d + 8], "little") * chunk[d] for d in range(rank))
+                table[offs] = (caddr, size, mask)
         elif lay["index"] == "earray":
             counts = [-(-s // c) for s, c in zip(var.shape, chunk)]
             coords = list(np.ndindex(*counts))

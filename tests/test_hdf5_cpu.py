@@ -116,3 +116,15 @@ def test_unsupported_filter_is_reported(tmp_path):
     with pytest.raises(hdf5_lite.Hdf5Error, match="filter"):
         v.read()
     h.close()
+
+
+def test_structural_errors_are_reported(tmp_path):
+    bad = tmp_path / "bad.h5"
+    bad.write_bytes(hdf5_lite.SIGNATURE + bytes([9]) + b"\0" * 100)            # superblock version 9
+    with pytest.raises(hdf5_lite.Hdf5Error, match="superblock"):
+        hdf5_lite.H5File(str(bad))
+    notes = tmp_path / "notes.txt"
+    notes.write_bytes(b"plain text, long enough to look for a signature in " * 40)
+    with pytest.raises(hdf5_lite.Hdf5Error, match="not an HDF5"):
+        hdf5_lite.H5File(str(notes))
+    assert hdf5_lite.is_hdf5(os.path.join(FIX, "float_chunked_latest.nc")) and not hdf5_lite.is_hdf5(str(notes))
