@@ -82,6 +82,20 @@ __device__ __forceinline__ void load_vec(const TIN* __restrict__ rowa, unsigned 
 // (tid % R) == 0 and tid / R < N hold the total of statistic tid / R.
 // `red` needs N * red_stride(NTHR) doubles.
 // ---------------------------------------------------------------------------------------------
+// synchronisation among the NTHR threads that reduce one row: a single wave needs no s_barrier -- its LDS operations are
+// processed in order -- only the compiler must not move them across this point; so one-wave rows of a multi-wave
+// workgroup stay independent of each other (no workgroup barrier in their epilogue)
+template <int NTHR>
+__device__ __forceinline__ void row_sync() {
+    if (NTHR <= 64) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
 constexpr int red_stride(int nthr) { return nthr + 8; }   // (stride mod 32) == 8: a wave's 8 statistics land on disjoint LDS banks
 constexpr int red_rshift(int nthr) { return nthr >= 256 ? 3 : (nthr == 128 ? 2 : 1); }
 constexpr int kRedStride = red_stride(256);
@@ -92,7 +106,7 @@ __device__ __forceinline__ double block_sums(const double (&v)[N], double* red, 
     static_assert(N * R <= NTHR, "too many statistics for this block size");
 #pragma unroll
     for (int s = 0; s < N; ++s) red[s * stride + tid] = v[s];
-    __syncthreads();
+    row_sync<NTHR>();
     const int s = tid >> rshift, part = tid & (R - 1);
     double acc = 0.0;
     if (s < N) {

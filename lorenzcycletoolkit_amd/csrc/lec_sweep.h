@@ -187,12 +187,12 @@ __device__ __forceinline__ void finish_row(const double (&acc)[kNA], const doubl
         const double t0 = block_sums<NR, NTHR>(h, red, tid);
         if ((tid & ((1 << rshift) - 1)) == 0 && (tid >> rshift) < NR && r0 + (tid >> rshift) < kNA)
             tot[r0 + (tid >> rshift)] = t0 * ((r0 + (tid >> rshift) == 5 || r0 + (tid >> rshift) == 15) ? scale * kCp : scale);   // <f>, <fa>: Q = cp f
-        __syncthreads();
+        row_sync<NTHR>();
     }
     if (XCOV) {
         const double t0 = block_sums<kNX, NTHR>(xacc, red, tid);
         if ((tid & ((1 << rshift) - 1)) == 0 && (tid >> rshift) < kNX) tot[kNA + (tid >> rshift)] = t0 * scale;
-        __syncthreads();
+        row_sync<NTHR>();
     }
     if (tid < 22) {
         const double da = tot[0], db = tot[1], dc = tot[2], dd = tot[3], de = tot[4], df = tot[5];
