@@ -85,7 +85,6 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
-    from lorenzcycletoolkit_amd import _lib
     from lorenzcycletoolkit_amd.engine import LECEngine
     from lorenzcycletoolkit_amd.parallel import compute_shard, gather_result, halo_range, shard_range
     from lorenzcycletoolkit_amd.synthetic import era5_like_levels, synthetic_cube

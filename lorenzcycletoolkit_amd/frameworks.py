@@ -21,7 +21,7 @@ import pandas as pd
 import torch
 
 from . import dataset as ds
-from .constants import LEVEL_TERMS, SCALAR_TERMS
+from .constants import LEVEL_TERMS
 from .engine import LECEngine, LECResult
 from .tables import budgets_and_residuals
 

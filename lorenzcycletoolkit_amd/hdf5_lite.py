@@ -331,7 +331,6 @@ class H5File:
         p = a + 5
         filt_len = self._u(p + 2, 2)
         p += 5 + 4                                     # heap ID length, filter length, flags, max size of managed objects
-        max_managed = self._u(p - 4, 4)
         p += self.L + self.O                           # next huge id, huge b-tree
         p += self.L + self.O                           # free space, free-space manager
         p += 4 * self.L                                # managed space, allocated, iterator offset, number of managed objects
@@ -346,7 +345,6 @@ class H5File:
         if filt_len:
             raise Hdf5Error("filtered fractal heaps not supported")
         off_bytes = (max_bits + 7) // 8
-        len_bytes = (min(max_direct, max_managed).bit_length() + 7) // 8
         max_direct_rows = (max_direct // start).bit_length() - 1 + 2
 
         def locate(hid: bytes):
@@ -370,7 +368,6 @@ class H5File:
                     return child + self.base + (off - row_off - c * size)
                 row_off += width * size
             return None
-        _ = len_bytes
         return locate
 
     # ---- datatype / dataspace ---------------------------------------------------------------
@@ -658,7 +655,6 @@ class H5File:
         if m[a: a + 4] != b"EAHD":
             raise Hdf5Error("bad extensible array header")
         client, esize, max_bits, idx_elmts, dblk_min, sblk_min_ptrs, page_bits = (m[a + 5 + i] for i in range(7))
-        nelmts_set = self._len(a + 12 + 4 * self.L)          # max_idx_set
         iblk = self._addr(a + 12 + 6 * self.L) + self.base
         undef = (1 << (8 * self.O)) - 1
         off_size = (max_bits + 7) // 8
@@ -726,7 +722,6 @@ class H5File:
                     if len(out) >= want:
                         break
                     data_block(self._addr(q + i * self.O), nel)
-        _ = nelmts_set
         return out[:want]
 
     def _read_chunk(self, var: H5Variable, addr: int, size: int, mask: int) -> np.ndarray:

@@ -8,7 +8,6 @@ and new-style groups.  The data are a pure function of the seed below, so tests 
     /opt/conda/bin/python3.9 tools/make_hdf5_fixtures.py
 """
 import os
-import sys
 
 import h5py
 import numpy as np

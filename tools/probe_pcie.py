@@ -1,4 +1,4 @@
-import os, time, mmap, numpy as np, torch
+import os, time, numpy as np, torch
 from concurrent.futures import ThreadPoolExecutor
 n = 1 << 30
 dev = torch.device("cuda:0")
