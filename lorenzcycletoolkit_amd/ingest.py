@@ -90,11 +90,27 @@ def _pool():
 
 
 class _Stager:
-    """One variable's path to the GPU: a pinned host buffer and a raw device buffer per pipeline slot."""
+    """One variable's path to the GPU: a pinned host buffer and a raw device buffer per pipeline slot.
 
-    def __init__(self, var: ds.RawVariable, steps: int, device, slots: int = 2):
+    Only what the analysis domain touches is staged: the file levels in ``levels`` (ascending file index, so that runs of
+    neighbouring levels are single copies when the band is the whole latitude range) and the latitude band [j0, j1] of
+    each -- whole longitude rows, which stay contiguous in the file.  A regional box out of a global file moves
+    a fraction of the bytes (a 15-degree band of a 0.25-degree grid: 1/12)."""
+
+    def __init__(self, var: ds.RawVariable, steps: int, device, levels: np.ndarray, j0: int, j1: int, slots: int = 2):
         self.var = var
-        self.step_elems = int(np.prod(var.data.shape[1:]))
+        self.levels = [int(k) for k in levels]
+        self.j0, self.j1 = int(j0), int(j1)
+        self.nx = int(var.data.shape[3])
+        full = self.j0 == 0 and self.j1 == int(var.data.shape[2]) - 1
+        self.runs = []                                   # (first staged level, first file level, count): contiguous in the file
+        for n, k in enumerate(self.levels):
+            if full and self.runs and self.runs[-1][1] + self.runs[-1][2] == k:
+                self.runs[-1][2] += 1
+            else:
+                self.runs.append([n, k, 1])
+        self.level_elems = (self.j1 - self.j0 + 1) * self.nx
+        self.step_elems = len(self.levels) * self.level_elems
         self.itemsize = var.data.dtype.itemsize
         carrier = {2: torch.int16, 4: torch.int32, 8: torch.int64}[self.itemsize]      # bytes only; never interpreted
         self.pinned = [torch.empty((steps, self.step_elems), dtype=carrier, pin_memory=True) for _ in range(slots)]
@@ -104,8 +120,7 @@ class _Stager:
     def stage(self, slot: int, file_steps: np.ndarray, at: int):
         """File time steps -> pinned rows [at, at + len): the only host touch of the data (page cache -> pinned)."""
         dst = self.pinned[slot].numpy()
-        n = len(file_steps)
-        if n == 0:
+        if len(file_steps) == 0:
             return
         # one time step of a variable is contiguous in the file even when the time axis is the record dimension
         # (record variables are interleaved per record): never reshape across time, that would copy the variable
@@ -116,9 +131,11 @@ class _Stager:
             block = self.var.data[int(ft)]
             if not block.flags["C_CONTIGUOUS"]:
                 raise ValueError("the device ingest needs each time step of a variable to be contiguous in the file")
-            src, out = as_bytes(block.reshape(-1)), dst[at + r]
-            for a in range(0, self.step_elems, piece):
-                jobs.append((out[a: a + piece], src[a: a + piece]))
+            for n, k, cnt in self.runs:
+                src = as_bytes(block[k: k + cnt, self.j0: self.j1 + 1].reshape(-1))
+                out = dst[at + r, n * self.level_elems: (n + cnt) * self.level_elems]
+                for a in range(0, cnt * self.level_elems, piece):
+                    jobs.append((out[a: a + piece], src[a: a + piece]))
         if len(jobs) == 1:
             np.copyto(*jobs[0])
         else:
@@ -154,11 +171,14 @@ def lec_fixed_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, b
     out_dtype = torch.float32 if (all_f32 and not packed_any) else torch.float64      # the file's precision, fp64 for packed data
     slots = 2
     span = chunk_steps + 2                                                # own steps + the one-step halo of T either side
-    nl_in, ny_in, nx_in = (int(x) for x in rvars["Air Temperature"].data.shape[1:])
-    stagers = {r: _Stager(rvars[r], span, dev, slots) for r in roles}
+    # staged sub-cube of every file time step: the kept levels (already in output order) x the latitude band of the domain
+    j0, j1 = int(plan.jmap.min()), int(plan.jmap.max())
+    nl_in, ny_in, nx_in = nl, j1 - j0 + 1, int(rvars["Air Temperature"].data.shape[3])
+    file_levels = np.sort(plan.kmap)
+    stagers = {r: _Stager(rvars[r], span, dev, file_levels, j0, j1, slots) for r in roles}
     cubes = [{keys[r]: torch.empty((span, nl, ny, nx), dtype=out_dtype, device=dev) for r in roles} for _ in range(slots)]
     up = lambda a: torch.as_tensor(a, dtype=torch.int32).to(dev)
-    kmap, jmap, imap = up(plan.kmap), up(plan.jmap), up(plan.imap)
+    kmap, jmap, imap = up(np.searchsorted(file_levels, plan.kmap)), up(plan.jmap - j0), up(plan.imap)   # maps into the staged sub-cube
     bt, _ = engine._box_tables([box])
     rows = torch.empty((nt, nl, bt.nyb_max, _lib.LEC_NSTAT), dtype=torch.float64, device=dev)
     time_s = plan.time_s

@@ -71,7 +71,8 @@ def test_packed_int16_file_streamed_equals_resident(workdir, chunk_steps):
     assert np.array_equal(a.levels.cpu().numpy(), b.levels.cpu().numpy(), equal_nan=True)     # NaN levels stay NaN in the tables
     assert torch.isfinite(a.scalars[:, :4]).all()
     full_bytes = 5 * 7 * 9 * 49 * 144 * 2
-    assert stats["bytes_moved"] <= 1.6 * full_bytes                            # int16 over PCIe (+ T halo), not fp64
+    band = (30 + 45) / 2.5 + 1                                                 # latitudes of the box: only that band of the 8 kept levels is staged
+    assert stats["bytes_moved"] <= 1.6 * full_bytes * (8 / 9) * (band / 49)    # int16 over PCIe (+ T halo), not fp64, not the whole globe
 
 
 @pytest.mark.parametrize("name,storage", [("packed_chunked_tracked.nc", "float64"), ("float_chunked_latest.nc", "float32"),
