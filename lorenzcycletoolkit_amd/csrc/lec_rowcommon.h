@@ -100,9 +100,9 @@ constexpr int red_stride(int nthr) { return nthr + 8; }   // (stride mod 32) == 
 constexpr int red_rshift(int nthr) { return nthr >= 256 ? 3 : (nthr == 128 ? 2 : 1); }
 constexpr int kRedStride = red_stride(256);
 
-template <int N, int NTHR>
+template <int N, int NTHR, int RSHIFT = red_rshift(NTHR)>
 __device__ __forceinline__ double block_sums(const double (&v)[N], double* red, int tid) {
-    constexpr int stride = red_stride(NTHR), rshift = red_rshift(NTHR), R = 1 << rshift, M = NTHR / R;
+    constexpr int stride = red_stride(NTHR), rshift = RSHIFT, R = 1 << rshift, M = NTHR / R;
     static_assert(N * R <= NTHR, "too many statistics for this block size");
 #pragma unroll
     for (int s = 0; s < N; ++s) red[s * stride + tid] = v[s];

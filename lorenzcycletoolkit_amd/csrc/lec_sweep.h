@@ -12,7 +12,8 @@
 namespace lec {
 
 constexpr int kNA = 20;     // shifted sums per row
-constexpr int kHalf = 10;   // statistics per reduction round (2 rounds x 10)
+constexpr int kHalf = 8;    // statistics per reduction round of a one-wave row: 8 statistics x 8 lanes fill the wave (3 rounds for 20)
+constexpr int kRowShift = 3;  // log2 of the lanes that cooperate on one statistic
 
 template <typename TIN, int VEC, int MODE>
 constexpr int sweep_min_waves() {
@@ -177,54 +178,54 @@ template <int NTHR, int NR = kHalf, bool XCOV = false>
 __device__ __forceinline__ void finish_row(const double (&acc)[kNA], const double (&xacc)[kNX], double* red, double* tot, int tid,
                                            double scale, const SweepRow& r, double* __restrict__ out, bool store = true) {
 #pragma clang fp contract(off)
-    constexpr int rshift = red_rshift(NTHR);
+    constexpr int rshift = (NTHR == 64) ? kRowShift : red_rshift(NTHR);
+    static_assert(NR << rshift <= NTHR, "a reduction round must fit the row's threads");
     const double cT = r.cT, cU = r.cU, cV = r.cV, cW = r.cW, cP = r.cP;
 #pragma unroll
     for (int r0 = 0; r0 < kNA; r0 += NR) {      // rounds of NR statistics through the same LDS tile
         double h[NR];
 #pragma unroll
         for (int s = 0; s < NR; ++s) h[s] = (r0 + s < kNA) ? acc[(r0 + s < kNA) ? r0 + s : 0] : 0.0;
-        const double t0 = block_sums<NR, NTHR>(h, red, tid);
+        const double t0 = block_sums<NR, NTHR, rshift>(h, red, tid);
         if ((tid & ((1 << rshift) - 1)) == 0 && (tid >> rshift) < NR && r0 + (tid >> rshift) < kNA)
             tot[r0 + (tid >> rshift)] = t0 * ((r0 + (tid >> rshift) == 5 || r0 + (tid >> rshift) == 15) ? scale * kCp : scale);   // <f>, <fa>: Q = cp f
         row_sync<NTHR>();
     }
     if (XCOV) {
-        const double t0 = block_sums<kNX, NTHR>(xacc, red, tid);
+        const double t0 = block_sums<kNX, NTHR, rshift>(xacc, red, tid);
         if ((tid & ((1 << rshift) - 1)) == 0 && (tid >> rshift) < kNX) tot[kNA + (tid >> rshift)] = t0 * scale;
         row_sync<NTHR>();
     }
     if (tid < 22) {
-        const double da = tot[0], db = tot[1], dc = tot[2], dd = tot[3], de = tot[4], df = tot[5];
-        const double mT = cT + da, mU = cU + db, mV = cV + dc, mW = cW + dd;
-        const double sTT = tot[6] - da * da, sUU = tot[7] - db * db, sVV = tot[8] - dc * dc;
-        const double sUV = tot[11] - db * dc, sWU = tot[12] - dd * db, sWV = tot[13] - dd * dc;
-        double o;
-        switch (tid) {
-            case 0: o = mT; break;
-            case 1: o = mU; break;
-            case 2: o = mV; break;
-            case 3: o = mW; break;
-            case 4: o = cP + de; break;
-            case 5: o = df; break;
-            case 6: o = sTT; break;
-            case 7: o = sUU; break;
-            case 8: o = sVV; break;
-            case 9: o = tot[9] - dc * da; break;                       // [v'T']
-            case 10: o = tot[10] - dd * da; break;                     // [w'T']
-            case 11: o = sUV; break;
-            case 12: o = sWU; break;
-            case 13: o = sWV; break;
-            case 14: o = tot[14] - dd * de; break;                     // [w'Phi']
-            case 15: o = tot[15] - df * da; break;                     // [Q'T']
-            case 16: o = tot[16] - 2 * da * tot[9] + da * da * dc + cV * sTT; break;     // [v T'T']
-            case 17: o = tot[17] - 2 * da * tot[10] + da * da * dd + cW * sTT; break;    // [w T'T']
-            case 18: o = 2 * mU * sUV + mU * mU * mV + 2 * mV * sVV + mV * mV * mV; break;   // [K v]
-            case 19: o = 2 * mU * sWU + mU * mU * mW + 2 * mV * sWV + mV * mV * mW; break;   // [K w]
-            case 20: o = tot[18] - 2 * db * tot[11] + db * db * dc - 2 * dc * tot[8] + dc * dc * dc
-                         + cV * (sUU + sVV); break;                                           // [E v]
-            default: o = tot[19] - 2 * db * tot[12] + db * db * dd - 2 * dc * tot[13] + dc * dc * dd
-                         + cW * (sUU + sVV); break;                                           // [E w]
+        // lanes 0..15: one branch-free form  o = tot[L] + shift_L - tot[ib] * tot[ic]  (means: product masked out;
+        // second moments: no shift); ib / ic are 3-bit codes packed per lane: the d-values tot[0..5]
+        //   L:   6 7 8 9 10 11 12 13 14 15
+        //   ib:  0 1 2 2  3  1  3  3  3  5       [T'T'] [u'u'] [v'v'] [v'T'] [w'T'] [u'v'] [w'u'] [w'v'] [w'Phi'] [Q'T']
+        //   ic:  0 1 2 0  0  2  1  2  4  0
+        constexpr unsigned long long kIB = 0x0ULL | (0ULL << 18) | (1ULL << 21) | (2ULL << 24) | (2ULL << 27) | (3ULL << 30) | (1ULL << 33) |
+                                           (3ULL << 36) | (3ULL << 39) | (3ULL << 42) | (5ULL << 45);
+        constexpr unsigned long long kIC = 0x0ULL | (0ULL << 18) | (1ULL << 21) | (2ULL << 24) | (0ULL << 27) | (0ULL << 30) | (2ULL << 33) |
+                                           (1ULL << 36) | (2ULL << 39) | (4ULL << 42) | (0ULL << 45);
+        const int L = min(tid, 15);
+        const int ib = (int)((kIB >> (3 * L)) & 7), ic = (int)((kIC >> (3 * L)) & 7);
+        const double prod = tot[ib] * tot[ic];
+        const double shift = (tid == 0) ? cT : (tid == 1) ? cU : (tid == 2) ? cV : (tid == 3) ? cW : (tid == 4) ? cP : 0.0;
+        double o = (tot[L] + shift) - ((tid >= 6) ? prod : 0.0);
+        if (tid >= 16) {                                  // third-order forms: three pairs of lanes
+            const double da = tot[0], db = tot[1], dc = tot[2], dd = tot[3];
+            const bool w = (tid & 1) != 0;                // the omega twin of each pair
+            const double sTT = tot[6] - da * da, sUU = tot[7] - db * db, sVV = tot[8] - dc * dc;
+            if (tid < 18) {                               // [v T'T'], [w T'T']
+                const double x0 = w ? tot[17] : tot[16], x1 = w ? tot[10] : tot[9], x2 = w ? dd : dc, sh = w ? cW : cV;
+                o = x0 - 2 * da * x1 + da * da * x2 + sh * sTT;
+            } else if (tid < 20) {                        // [K v], [K w]
+                const double mU = cU + db, mV = cV + dc, m = w ? cW + dd : mV;
+                const double s1 = w ? tot[12] - dd * db : tot[11] - db * dc, s2 = w ? tot[13] - dd * dc : sVV;
+                o = 2 * mU * s1 + mU * mU * m + 2 * mV * s2 + mV * mV * m;
+            } else {                                      // [E v], [E w]
+                const double x0 = w ? tot[19] : tot[18], x1 = w ? tot[12] : tot[11], x2 = w ? dd : dc, x3 = w ? tot[13] : tot[8], sh = w ? cW : cV;
+                o = x0 - 2 * db * x1 + db * db * x2 - 2 * dc * x3 + dc * dc * x2 + sh * (sUU + sVV);
+            }
         }
         if (store) out[tid] = o;
     }
