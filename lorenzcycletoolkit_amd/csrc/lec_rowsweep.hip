@@ -45,7 +45,13 @@ __global__ void __launch_bounds__(kThreads, (sweep_min_waves<TIN, VEC, MODE>()))
 
     const int tid = threadIdx.x;
     int jb, k, tl;
-    if (p.order == 0) {
+    if (ONE_TRIP) {
+        // short rows are instruction-bound (a 61-point row is ~1000 instructions, a third of them index arithmetic): a 3-D
+        // grid hands out (latitude, level, time step) without a single integer division
+        jb = (int)(blockIdx.x & 7) * p.jchunk + (int)(blockIdx.x >> 3);      // blockIdx.x % 8 labels the XCD: contiguous latitude chunks
+        k = blockIdx.y; tl = blockIdx.z;
+        if (jb >= p.nyb_max || (int)(blockIdx.x >> 3) >= p.jchunk) return;
+    } else if (p.order == 0) {
         int r = blockIdx.x;
         jb = r % p.nyb_max; r /= p.nyb_max;
         k = r % p.nl;
@@ -258,7 +264,10 @@ int launch_one(RowParams p, bool uniform, int mode, hipStream_t st) {
     if (nblocks == 0) { p.order = 0; nblocks = grid_blocks(p); }
     if (nblocks == 0) return LEC_ERR_UNSUPPORTED;
     dim3 grid((unsigned)nblocks), block(kThreads);
-#define LEC_LAUNCH(U, M) do { if (p.ntrips == 1) hipLaunchKernelGGL((lec_rowsweep_kernel<TIN, VEC, U, M, true, BOTH && M == 3>), grid, block, 0, st, p); \
+    if (p.jchunk < 1) p.jchunk = (p.nyb_max + 7) / 8;
+    dim3 grid3(8u * (unsigned)p.jchunk, (unsigned)p.nl, (unsigned)p.t_count);    // one-trip rows: (XCD x latitude, level, time step)
+    if (p.ntrips == 1 && (p.nl > 65535 || p.t_count > 65535)) return LEC_ERR_UNSUPPORTED;
+#define LEC_LAUNCH(U, M) do { if (p.ntrips == 1) hipLaunchKernelGGL((lec_rowsweep_kernel<TIN, VEC, U, M, true, BOTH && M == 3>), grid3, block, 0, st, p); \
                               else hipLaunchKernelGGL((lec_rowsweep_kernel<TIN, VEC, U, M, false, BOTH && M == 3>), grid, block, 0, st, p); } while (0)
 #define LEC_MODES(U) do { if (mode == 0) LEC_LAUNCH(U, 0); else if (mode == 1) LEC_LAUNCH(U, 1); else if (mode == 2) LEC_LAUNCH(U, 2); else LEC_LAUNCH(U, 3); } while (0)
     if (uniform) LEC_MODES(true); else LEC_MODES(false);
