@@ -38,7 +38,7 @@ __device__ __forceinline__ void lds_barrier() {
 template <typename TIN, int VEC, bool UNIFORM, int BT, int BK, int BJ>
 __global__ void __launch_bounds__(64 * BT * BK * BJ, LEC_MINW_SINGLE) lec_rowblock_kernel(const RowParams p) {
     constexpr int NW = BT * BK * BJ;
-    __shared__ double red[NW][kHalf * red_stride(64)];
+    __shared__ double red[NW][kRound * red_stride(64)];
     __shared__ double tot[NW][24];
     __shared__ __attribute__((aligned(16))) TIN xch[2][NW][64 * VEC];
 
@@ -192,7 +192,7 @@ __global__ void __launch_bounds__(64 * BT * BK * BJ, LEC_MINW_SINGLE) lec_rowblo
     };
     if (both) sweep(std::true_type{}); else sweep(std::false_type{});
 
-    finish_row<64, kHalf, true>(acc, xacc, red[wave], tot[wave], tid, UNIFORM ? h_rad * inv_xlen : inv_xlen, r, out, store);
+    finish_row<64, kRound, true>(acc, xacc, red[wave], tot[wave], tid, UNIFORM ? h_rad * inv_xlen : inv_xlen, r, out, store);
     if (store && tid == 0) {
         out[LEC_S_TW] = r.cT; out[LEC_S_UW] = r.cU; out[LEC_S_VW] = r.cV;
         out[LEC_S_TE] = eT; out[LEC_S_UE] = eU; out[LEC_S_VE] = eV;

@@ -30,7 +30,7 @@ using namespace lec;
 namespace {
 
 constexpr int kThreads = 64; // one wave per row: measured best (64 / 128 / 256 threads: 19.0 / 19.1 / 20.1 ms per 64 steps)
-// one workgroup per (time, level, box-latitude) row, ONE sweep over the row (see the header comment)
+// one wave per (time, level, box-latitude) row, ONE sweep over the row (see the header comment)
 // MODE: 0 no Q; 1 dT/dt from the cube's time neighbours per point; 2 dT/dt cube; 3 as 1 on one fixed box, through
 // cross-time covariances (sweep_elems).  BOTH (MODE 3 only): the row also forms the covariance with T(t-1) -- the first
 // processed time step of a launch
@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(kThreads, (sweep_min_waves<TIN, VEC, MODE>()))
     constexpr bool WITH_Q = MODE != 0;
     constexpr bool TIME_NB = (MODE == 1 || MODE == 3);      // reads T at t+1 (and t-1)
     constexpr int nthr = NTHR;
-    __shared__ double red[kHalf * red_stride(NTHR)];
+    __shared__ double red[kRound * red_stride(NTHR)];
     __shared__ double tot[24];
 
     const int tid = threadIdx.x;
@@ -212,7 +212,7 @@ __global__ void __launch_bounds__(kThreads, (sweep_min_waves<TIN, VEC, MODE>()))
         for (int it = max(mid_end, 1); it < ntrips; ++it) trip(std::true_type{}, it);
     }
 
-    finish_row<NTHR, kHalf, MODE == 3>(acc, xacc, red, tot, tid, UNIFORM ? h_rad * inv_xlen : inv_xlen, r, out);
+    finish_row<NTHR, kRound, MODE == 3>(acc, xacc, red, tot, tid, UNIFORM ? h_rad * inv_xlen : inv_xlen, r, out);
     // T, u, v at the west / east box columns (boundary terms): wave-uniform scalar loads
     if (tid == 0) {
         out[LEC_S_TW] = r.cT; out[LEC_S_UW] = r.cU; out[LEC_S_VW] = r.cV;

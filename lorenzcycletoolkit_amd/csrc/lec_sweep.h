@@ -12,7 +12,7 @@
 namespace lec {
 
 constexpr int kNA = 20;     // shifted sums per row
-constexpr int kHalf = 8;    // statistics per reduction round of a one-wave row: 8 statistics x 8 lanes fill the wave (3 rounds for 20)
+constexpr int kRound = 8;    // statistics per reduction round of a one-wave row: 8 statistics x 8 lanes fill the wave (3 rounds for 20)
 constexpr int kRowShift = 3;  // log2 of the lanes that cooperate on one statistic
 
 template <typename TIN, int VEC, int MODE>
@@ -174,7 +174,7 @@ __device__ __forceinline__ void sweep_elems(double (&acc)[kNA], double (&xacc)[k
 // statistics from the shifted sums (lanes 0..21) written to the row record.  XCOV: the cross-time sums go to the
 // record's scratch slots 28..31 as [T'(t)T'(t+1)], [T](t+1), [T'(t)T'(t-1)], [T](t-1) for lec_qtime_kernel.
 // Contraction is off: the epilogue must give the same bits in every kernel instantiation.
-template <int NTHR, int NR = kHalf, bool XCOV = false>
+template <int NTHR, int NR = kRound, bool XCOV = false>
 __device__ __forceinline__ void finish_row(const double (&acc)[kNA], const double (&xacc)[kNX], double* red, double* tot, int tid,
                                            double scale, const SweepRow& r, double* __restrict__ out, bool store = true) {
 #pragma clang fp contract(off)
