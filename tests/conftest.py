@@ -12,6 +12,12 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the C-ABI library is a build artefact (git-ignored): build it once if this checkout does not have it yet
+    # (hipcc cross-compiles gfx950 without a GPU; on the GPU box the snapshot already carries the built .so)
+    lib = os.path.join(ROOT, "lorenzcycletoolkit_amd", "liblec_hip.so")
+    if not os.path.exists(lib) and os.path.exists("/opt/rocm/bin/hipcc"):
+        import __graft_entry__
+        __graft_entry__.build()
 
 
 @pytest.fixture(scope="session")
