@@ -342,6 +342,16 @@ def test_full_size_band_and_properties(dtype):
     s3 = r3.scalars_dict()
     assert np.array_equal(s3["Kz"], 4 * s1["Kz"]) and np.array_equal(s3["Ke"], 4 * s1["Ke"])
     assert np.array_equal(s3["Az"], s1["Az"]) and np.array_equal(s3["Ae"], s1["Ae"])
+    # omega -> -omega: the conversions that are linear in omega (Cz, Ce) change sign exactly, the energies do not move,
+    # and so do the level tables of those terms
+    r4 = eng.compute(f["tair"], f["u"], f["v"], -f["omega"], f["geopt"], [box], time_s=time_s)
+    s4 = r4.scalars_dict()
+    for name in ("Az", "Ae", "Kz", "Ke"):
+        assert np.array_equal(s4[name], s1[name]), name
+    for name in ("Cz", "Ce"):
+        assert np.array_equal(s4[name], -s1[name]), name
+    l1, l4 = r1.levels_dict(), r4.levels_dict()
+    assert np.array_equal(l4["Ce"], -l1["Ce"]) and np.array_equal(l4["Cz_2"], -l1["Cz_2"])
 
 
 def test_full_size_zonally_symmetric_fields_have_no_eddy_energy():
