@@ -104,6 +104,8 @@ def main():
     # weak scaling: `timesteps` per GPU; global series of world * timesteps steps, contiguous shards
     T_local = args.timesteps
     T_global = T_local * world
+    if T_global < 2 and not args.no_q:
+        raise SystemExit("bench.py: the diabatic-heating terms differentiate T in time: need at least 2 time steps in all (or --no-q)")
     t0, t1 = shard_range(T_global, world, rank)
     h0, h1 = halo_range(t0, t1, T_global)                    # one-step halo for dT/dt (thermodynamics.py:109-110)
     fields = synthetic_cube(h1 - h0, level, lat, lon, device=device, dtype=tdtype, seed=1234, t0_global=h0)
