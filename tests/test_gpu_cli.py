@@ -107,3 +107,73 @@ def test_device_ingest_flag_writes_identical_csvs(workdir, golden_dir):
     assert (out / "host.csv").read_bytes() == (out / "device.csv").read_bytes()
     a = pd.read_csv(out / "device.csv", index_col=0)
     assert len(a) == 36 and np.isfinite(a.values).all()
+
+
+def _write_era5_style(path, nt=6):
+    """What the reference's missing samples/testdata_ERA5.nc looks like to the toolkit: namelist_ERA5 names (T, Z, W, U, V; time,
+    level, latitude, longitude), hourly from 2005-08-09, int16-packed, latitudes N -> S, levels in millibars incl. 850 hPa."""
+    from scipy.io import netcdf_file
+    rng = np.random.default_rng(11)
+    lon = np.arange(-80.0, -9.0, 1.25)
+    lat = np.arange(0.0, -61.25, -1.25)
+    lev = np.array([1000, 925, 850, 700, 500, 300, 200, 100], dtype=np.int32)
+    nl, ny, nx = lev.size, lat.size, lon.size
+    f = netcdf_file(path, "w", version=2)
+    for n, s in (("time", nt), ("level", nl), ("latitude", ny), ("longitude", nx)):
+        f.createDimension(n, s)
+    tv = f.createVariable("time", "i", ("time",)); tv[:] = 925704 + np.arange(nt); tv.units = "hours since 1900-01-01 00:00:00.0"
+    lv = f.createVariable("level", "i", ("level",)); lv[:] = lev; lv.units = "millibars"
+    la = f.createVariable("latitude", "f", ("latitude",)); la[:] = lat
+    lo = f.createVariable("longitude", "f", ("longitude",)); lo[:] = lon
+    p = (lev[None, :, None, None] * 100.0) / 1e5
+    tt = np.arange(nt)[:, None, None, None]
+    lam, phi = np.deg2rad(lon)[None, None, None, :], np.deg2rad(lat)[None, None, :, None]
+    fields = {
+        "T": 288.0 * p ** 0.19 + 8.0 * np.cos(2 * phi) * p + 2.0 * np.sin(3 * lam + 0.1 * tt) + 0.3 * rng.standard_normal((nt, nl, ny, nx)),
+        "U": 20.0 * np.cos(phi) * (1 - p / 1.2) + 3 * rng.standard_normal((nt, nl, ny, nx)),
+        "V": 3.0 * np.sin(2 * lam) + 2 * rng.standard_normal((nt, nl, ny, nx)),
+        "W": 0.1 * rng.standard_normal((nt, nl, ny, nx)),
+        "Z": 9.80665 * 7000.0 * np.log(1.0 / p) + 50.0 * rng.standard_normal((nt, nl, ny, nx)),
+    }
+    for name, a in fields.items():
+        lo_, hi_ = a.min(), a.max()
+        scale, offset = (hi_ - lo_) / 65000.0, 0.5 * (hi_ + lo_)
+        v = f.createVariable(name, "h", ("time", "level", "latitude", "longitude"))
+        v[:] = np.clip(np.round((a - offset) / scale), -32000, 32000).astype(np.int16)
+        v.scale_factor = float(scale); v.add_offset = float(offset); v._FillValue = np.int16(-32767); v.missing_value = np.int16(-32767)
+    f.close()
+
+
+def test_era5_style_fixed_and_track_cli(workdir, golden_dir):
+    """The reference's tests/test_ERA5_fixed.py and tests/test_ERA5_track.py re-stated (same namelist, box and track inputs, flags
+    -r -f -p -v and -r -t -p -v); numbers against the oracle on the host-decoded data."""
+    import lorenzcycletoolkit
+    from lorenzcycletoolkit_amd import dataset as ds
+    shutil.copy(os.path.join(golden_dir, "inputs", "namelist_ERA5"), workdir / "inputs" / "namelist")
+    shutil.copy(os.path.join(golden_dir, "inputs", "box_limits_Reg1"), workdir / "inputs" / "box_limits")
+    shutil.copy(os.path.join(golden_dir, "inputs", "track_testdata_ERA5"), workdir / "inputs" / "track")
+    _write_era5_style("testdata_ERA5.nc")
+    # fixed, host path and device ingest
+    args = _main(["testdata_ERA5.nc", "-r", "-f", "-p", "-v"])
+    assert args.residuals and args.fixed and args.plots and args.verbosity
+    out = workdir / "LEC_Results" / "testdata_ERA5_fixed"
+    got = pd.read_csv(out / "testdata_ERA5_fixed_results.csv", index_col=0)
+    assert len(got) == 6 and np.isfinite(got.values).all() and str(got.index[0]) == "2005-08-09 00:00:00"
+    df = ds.read_namelist("inputs/namelist")
+    host = ds.prepare_data(lorenzcycletoolkit.create_arg_parser().parse_args(["testdata_ERA5.nc", "-r", "-f"]), "inputs/namelist")
+    nm = lambda role: str(df.loc[role]["Variable"])
+    dom = o.Domain(*(host.variables[nm(r)].astype(np.float64) for r in ("Air Temperature", "Eastward Wind Component", "Northward Wind Component",
+                                                                       "Omega Velocity", "Geopotential")),
+                   host.lat.astype(np.float64), host.lon.astype(np.float64), host.level, host.time_s)     # (the file's coordinates are float32)
+    ref, _ = o.lec_fixed(dom, -60.0, -30.0, -42.5, -17.5)
+    for c in ("Az", "Ae", "Kz", "Ke", "Cz", "Ca", "Ck", "Ce", "BAz", "BAe", "BKz", "BKe", "Gz", "Ge"):
+        r = np.asarray(ref[c], dtype=np.float64)
+        assert np.max(np.abs(got[c].values - r)) <= 1e-9 * np.max(np.abs(r)), c
+    _main(["testdata_ERA5.nc", "-r", "-f", "--device-ingest", "-o", "device"])
+    assert (out / "device.csv").read_bytes() == (out / "testdata_ERA5_fixed_results.csv").read_bytes()
+    # track
+    args = _main(["testdata_ERA5.nc", "-r", "-t", "-p", "-v"])
+    assert args.track and args.plots
+    tr = pd.read_csv(workdir / "LEC_Results" / "testdata_ERA5_track" / "testdata_ERA5_track_results.csv", index_col=0)
+    assert len(tr) == 5 and np.isfinite(tr[["Az", "Ae", "Kz", "Ke", "Cz", "Ca", "Ck", "Ce", "Gz", "Ge"]].values).all()
+    assert (workdir / "LEC_Results" / "testdata_ERA5_track" / "testdata_ERA5_track_trackfile").exists()
