@@ -79,6 +79,11 @@ def load():
         raise LecLibraryError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C lorenzcycletoolkit_amd/csrc` (there is no CPU fallback)")
+    # PyTorch-ROCm bundles its own libamdhip64 (same SONAME as /opt/rocm's).  The process must end up with ONE HIP runtime: if
+    # this library were loaded first it would pull in /opt/rocm's copy, torch would then load its bundled one, and kernels
+    # launched through the first runtime would see no device.  Importing torch first makes the loader resolve our dependency
+    # to the runtime torch already brought.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     lib.lec_version.restype = C.c_int
     lib.lec_last_error.restype = C.c_char_p
