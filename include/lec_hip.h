@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define LEC_ABI_VERSION 3
+#define LEC_ABI_VERSION 4
 
 /* number of fp64 values per (time, level, lat) row record written by lec_rowstats */
 #define LEC_NSTAT 32
@@ -53,6 +53,35 @@ extern "C" {
 #define LEC_NLEVTAB 21 /* Az Ae Kz Ke Ge Gz Cz Cz_1 Cz_2 Ca Ca_1 Ca_2 Ce Ce_1 Ce_2 Ck Ck_1..Ck_5 */
 
 enum lec_dtype { LEC_F64 = 0, LEC_F32 = 1, LEC_I16 = 2 /* lec_ingest source only */ };
+
+/* Stage-1 kernel families (lec_tuning.kernel).  Every family writes the same row records; AUTO is what is
+ * measured and shipped, the others exist for cross-checks and A/B measurements.  The library reads NO
+ * environment variables: everything that steers it is in the argument structs. */
+enum lec_kernel {
+    LEC_KERNEL_AUTO = 0,       /* box tiles for per-time-step boxes, row blocks for all terms on one fixed fp64 box, else one wave per row */
+    LEC_KERNEL_TWO_SWEEP = 1,  /* lec_rowstats.hip: the reference's own order (deviation from the zonal mean, then products); rows <= lec_max_row() */
+    LEC_KERNEL_ROW_SWEEP = 2,  /* lec_rowsweep.hip: one wave per row, one sweep */
+    LEC_KERNEL_ROW_BLOCK = 3,  /* lec_rowblock.hip: blocks of neighbouring rows exchange T through LDS (all terms, one fixed box, dT/dt from the cube) */
+    LEC_KERNEL_BOX_TILE = 4    /* lec_boxtile.hip: a (time, level) box tile staged through LDS, one lane per latitude row */
+};
+
+/* workgroup -> row order of the row kernels (speed only) */
+enum lec_order {
+    LEC_ORDER_AUTO = 0,
+    LEC_ORDER_MEMORY = 1,      /* rows in memory order */
+    LEC_ORDER_XCD_LAT = 2,     /* every XCD owns a latitude chunk, walked latitude-fastest per (time, level) */
+    LEC_ORDER_XCD_TILED = 7    /* tiles of tile_t time steps x tile_j latitudes at one level, levels next (all terms on one fixed box) */
+};
+
+/* Kernel selection of lec_rowstats; all zero = library defaults. */
+typedef struct lec_tuning {
+    int32_t kernel;        /* enum lec_kernel */
+    int32_t block_shape;   /* LEC_KERNEL_ROW_BLOCK: 100 bt + 10 bk + bj waves (time x level x latitude, each 1 or 2); 0 = 212 */
+    int32_t order;         /* enum lec_order */
+    int32_t tile_t, tile_j; /* tile extents of LEC_ORDER_XCD_TILED / of the row-block kernel (in blocks); 0 = default; must be >= 0 */
+    int32_t f32_vec;       /* fp32 storage, one wave per row: 0 = float4 trips when the cubes are 16-byte aligned, 2 = float2 trips */
+    int32_t reserved[2];   /* must be 0 */
+} lec_tuning;
 
 enum lec_status {
     LEC_OK = 0,
@@ -74,9 +103,11 @@ enum lec_stat {
 /*
  * Stage 1: one pass over the field cubes -> LEC_NSTAT row statistics per (time, level, box-lat) row.
  *
- * Boxes: `box_d` holds n_box quadruples {iw, ie, js, jn} (inclusive grid indices).  n_box == 1: one
- * fixed (Eulerian) box for every time step; n_box == t_count: one box per processed time step
- * (semi-Lagrangian).  Every table indexed by box has room for nxb_max / nyb_max entries per box.
+ * Boxes: `box_d` holds n_box quadruples {iw, ie, js, jn} (inclusive grid indices).  box_per_step == 0: one
+ * fixed (Eulerian) box for every time step, n_box == 1; box_per_step == 1: one box per processed time step
+ * (semi-Lagrangian), n_box == t_count -- also when t_count == 1, so that a one-step shard or chunk of a
+ * moving series runs the same kernels (and gives the same bits) as the whole series.  Every table indexed
+ * by box has room for nxb_max / nyb_max entries per box.
  *
  * dT/dt for the diabatic-heating residual: if dTdt_d != NULL it is a cube like the fields (moving
  * framework, lorenzcycletoolkit.py:184-186); otherwise dT/dt = tc[t][0] T[t-1] + tc[t][1] T[t] +
@@ -99,6 +130,8 @@ typedef struct lec_rowstats_args {
     /* boxes */
     int32_t n_box, nxb_max, nyb_max;
     int32_t lon_uniform;        /* 1: longitudes of every box are uniformly spaced (fast path) */
+    int32_t box_per_step;       /* 0: one fixed box (n_box == 1); 1: one box per processed time step (n_box == t_count) */
+    int32_t reserved0;          /* must be 0 */
     const int32_t* box_d;       /* [n_box][4] iw ie js jn */
     const double* boxtab_d;     /* [n_box][4]  1/xlength [rad^-1], h_rad, 1/h_deg, spare (h_* used if lon_uniform) */
     const double* wlon_d;       /* [n_box][nxb_max]     trapezoid weights in radians   (used if !lon_uniform) */
@@ -109,11 +142,16 @@ typedef struct lec_rowstats_args {
     /* output */
     double* rows_d;             /* [t_count][nl][nyb_max][LEC_NSTAT] */
     void* stream;
+    lec_tuning tuning;          /* all zero = defaults */
 } lec_rowstats_args;
 
 /*
  * Stage 2: (level x lat) math on the row records -> per-time scalars and per-level tables.
+ * Limits: nl <= 160 levels (LEC_ERR_UNSUPPORTED beyond), t_count <= 65535 time steps per call (split longer
+ * series into several calls; with drop_any_time use lec_dropmask per call, merge, then mode 2).
  */
+#define LEC_MAX_LEVELS 160
+#define LEC_MAX_STEPS_PER_REDUCE 65535
 typedef struct lec_reduce_args {
     const double* rows_d;       /* [t_count][nl][nyb_max][LEC_NSTAT] from lec_rowstats */
     int32_t t_count, nl;
@@ -172,8 +210,9 @@ typedef struct lec_ingest_args {
 int lec_version(void);
 const char* lec_last_error(void);
 
-/* longest box row (in grid points) lec_rowstats accepts for the given dtype / alignment */
-int lec_max_row(int dtype, int aligned);
+/* longest box row (in grid points) lec_rowstats accepts for the given dtype / alignment / kernel family
+ * (enum lec_kernel; only LEC_KERNEL_TWO_SWEEP, which holds a row in registers, has a practical limit) */
+int lec_max_row(int dtype, int aligned, int kernel);
 
 int lec_rowstats(const lec_rowstats_args* args);
 int lec_ingest(const lec_ingest_args* args);

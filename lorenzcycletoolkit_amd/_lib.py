@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # LEC_LIB: alternative build of the same ABI (kernel experiments only)
 LIB_PATH = os.environ.get("LEC_LIB") or os.path.join(_HERE, "liblec_hip.so")
 
-LEC_ABI_VERSION = 3
+LEC_ABI_VERSION = 4
 LEC_NSTAT = 32
 LEC_NLEVRAW = 40
 LEC_NSCALAR = 16
@@ -18,7 +18,19 @@ LEC_NLEVTAB = 21
 LEC_NLEVFUN = 28
 LEC_F64, LEC_F32, LEC_I16 = 0, 1, 2
 
+# enum lec_kernel / enum lec_order (include/lec_hip.h)
+KERNEL_AUTO, KERNEL_TWO_SWEEP, KERNEL_ROW_SWEEP, KERNEL_ROW_BLOCK, KERNEL_BOX_TILE = 0, 1, 2, 3, 4
+ORDER_AUTO, ORDER_MEMORY, ORDER_XCD_LAT, ORDER_XCD_TILED = 0, 1, 2, 7
+
 EXPORTS = ["lec_version", "lec_last_error", "lec_max_row", "lec_rowstats", "lec_reduce", "lec_dropmask", "lec_ingest"]
+
+
+class Tuning(C.Structure):
+    """struct lec_tuning (include/lec_hip.h): kernel selection of lec_rowstats; all zero = library defaults."""
+    _fields_ = [
+        ("kernel", C.c_int32), ("block_shape", C.c_int32), ("order", C.c_int32),
+        ("tile_t", C.c_int32), ("tile_j", C.c_int32), ("f32_vec", C.c_int32), ("reserved", C.c_int32 * 2),
+    ]
 
 
 class RowstatsArgs(C.Structure):
@@ -30,9 +42,11 @@ class RowstatsArgs(C.Structure):
         ("nt", C.c_int32), ("nl", C.c_int32), ("ny", C.c_int32), ("nx", C.c_int32),
         ("t_begin", C.c_int32), ("t_count", C.c_int32),
         ("n_box", C.c_int32), ("nxb_max", C.c_int32), ("nyb_max", C.c_int32), ("lon_uniform", C.c_int32),
+        ("box_per_step", C.c_int32), ("reserved0", C.c_int32),
         ("box_d", C.c_void_p), ("boxtab_d", C.c_void_p), ("wlon_d", C.c_void_p), ("glon_d", C.c_void_p),
         ("lattab_d", C.c_void_p), ("levtab_d", C.c_void_p), ("tcoef_d", C.c_void_p),
         ("rows_d", C.c_void_p), ("stream", C.c_void_p),
+        ("tuning", Tuning),
     ]
 
 
@@ -88,7 +102,7 @@ def load():
     lib.lec_version.restype = C.c_int
     lib.lec_last_error.restype = C.c_char_p
     lib.lec_max_row.restype = C.c_int
-    lib.lec_max_row.argtypes = [C.c_int, C.c_int]
+    lib.lec_max_row.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.lec_rowstats.restype = C.c_int
     lib.lec_rowstats.argtypes = [C.POINTER(RowstatsArgs)]
     lib.lec_reduce.restype = C.c_int

@@ -1,0 +1,447 @@
+// lec_boxtile.hip -- stage 1 for short rows: per-time-step boxes of the moving (semi-Lagrangian) framework.
+//
+// A moving box is ~61 x 61 points per (time, level).  With one wave per 61-point row (lec_rowsweep.hip) the fixed per-row
+// work -- a 20-statistic cross-lane reduction through LDS, the row epilogue, ~450 scalar instructions of row set-up -- is 20 x
+// the useful arithmetic (~1100 instructions per row; 29 % of the HBM roofline in round 1).  Here a 256-thread workgroup owns
+// 16 box rows of one time step and walks a chunk of levels; one PASS = 16 rows x 64 columns of one level:
+//
+//   load layout    lanes along longitude, WHOLE BOX ROWS per wave instruction (61 lanes x 8 B = 488 contiguous bytes): the
+//                  access shape the memory system serves best for this pattern (tools/probes/probe_boxread.hip: 4.75 TB/s,
+//                  against 3.0 TB/s for 128-byte column strips and 5.3 TB/s for a contiguous stream).  Wave w owns rows
+//                  4w .. 4w+3 of the pass.  Everything a point's diabatic-heating residual needs is in that lane's registers
+//                  (T at j+-1 are the wave's neighbouring rows, T at i+-1 come from the adjacent lanes by DPP, T at k+-1 from a
+//                  three-level register window that slides down the levels: every T row is loaded ONCE per level chunk), so
+//                  f = Q / cp is formed here, with wave-uniform (scalar) row coefficients;
+//   LDS transpose  only the six shifted values a .. f of a point go to LDS (row stride = 4 mod 32 words, one pad word per
+//                  16 columns: conflict-free both ways).  With uniform longitudes the trapezoid's end points and the lanes
+//                  outside the box are written as zeros -- they add nothing to any of the 20 monomial sums -- and the two end
+//                  points reach the row's finishing lane through a small side array, so the inner loop is unweighted;
+//   compute layout lane (r, g) of wave w owns row r and columns 16 g + 4 w + (0..3): six LDS reads and the 20 shifted sums
+//                  per point, serially over longitude;
+//   pass end       the four column groups of a row sit in one quad: two DPP quad_perm adds per sum (VALU only, fixed order);
+//                  the four waves' partial sums meet in LDS and 16 lanes of one wave finish the pass's 16 rows, one row per
+//                  lane (end-point terms, scaling, centred statistics) while the other waves already work on the next level.
+//
+// The loads of pass p+1 are in flight while pass p is computed.  Results are deterministic and depend only on the box of the
+// time step (passes, column groups and wave partials are cut in box-relative rows / columns), so sharding / chunking a series
+// changes no bit.  Any box size works: rows wider than 64 columns take several column chunks per level (no level window
+// then: same arithmetic, T neighbours loaded per pass), row blocks of 16 cover any height.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/lec_hip.h"
+#include "lec_internal.h"
+#include "lec_rowcommon.h"
+#include "lec_sweep.h"
+
+using namespace lec;
+
+// measurement builds only (tools/build_variant.sh), bit mask: 1 = no compute-layout phase, 2 = no global loads, 4 = no row epilogue,
+// 8 = no quad reduction / hand-over, 16 = no load-layout arithmetic (values straight to LDS)
+#ifndef LEC_BT_ABLATE
+#define LEC_BT_ABLATE 0
+#endif
+
+namespace {
+
+constexpr int kRB = 16;              // rows per pass
+constexpr int kCW = 64;              // columns per pass (one wave-wide row segment)
+constexpr int kSF = 68;              // tile row stride in doubles: 64 columns + one pad per 16, = 4 (mod 32)
+constexpr int kTile = kRB * kSF;
+constexpr int kSide = 16;            // per-row side values: 5 shifts, f of the first point, a..f of the last point, T u v at the east column
+constexpr int kLevelChunk = 10;      // levels per workgroup (the T window's prologue is paid once per chunk)
+
+template <bool UNIFORM, int MODE> constexpr int n_tiles() { return (MODE == 0 ? 5 : 6) + (UNIFORM ? 0 : 1); }
+template <bool UNIFORM, int MODE> constexpr int lds_doubles() { return n_tiles<UNIFORM, MODE>() * kTile + 4 * kNA * kRB + 2 * kRB * kSide; }
+
+__device__ __forceinline__ int pos(int c) { return c + (c >> 4); }      // LDS column of tile column c (one pad per 16 columns)
+
+template <int CTRL>
+__device__ __forceinline__ double quad_swap(double v) {      // every lane of a quad is a valid source: no "old" value to set up
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+// sums over the four lanes of every quad, the same bits in every lane: (x0 + x1) + (x2 + x3); two phases over all values so
+// that independent DPP moves fill each other's hazard slots
+template <int N>
+__device__ __forceinline__ void quad_sums(double (&v)[N]) {
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int s = 0; s < N; ++s) v[s] = v[s] + quad_swap<0xB1>(v[s]);      // quad_perm [1, 0, 3, 2]
+#pragma unroll
+    for (int s = 0; s < N; ++s) v[s] = v[s] + quad_swap<0x4E>(v[s]);      // quad_perm [2, 3, 0, 1]
+}
+
+// value of lane `src` (wave-uniform) in every lane
+__device__ __forceinline__ double lane_value(double v, int src) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+
+// centred row statistics from the 20 shifted sums (already scaled): the formulas of finish_row (lec_sweep.h), one row per lane
+__device__ __forceinline__ void finish_lane(const double (&tot)[kNA], double cT, double cU, double cV, double cW, double cP,
+                                            double (&o)[22]) {
+#pragma clang fp contract(off)
+    const double da = tot[0], db = tot[1], dc = tot[2], dd = tot[3], de = tot[4], df = tot[5];
+    o[0] = da + cT; o[1] = db + cU; o[2] = dc + cV; o[3] = dd + cW; o[4] = de + cP; o[5] = df;
+    o[6] = tot[6] - da * da;        // [T'T']
+    o[7] = tot[7] - db * db;        // [u'u']
+    o[8] = tot[8] - dc * dc;        // [v'v']
+    o[9] = tot[9] - dc * da;        // [v'T']
+    o[10] = tot[10] - dd * da;      // [w'T']
+    o[11] = tot[11] - db * dc;      // [u'v']
+    o[12] = tot[12] - dd * db;      // [w'u']
+    o[13] = tot[13] - dd * dc;      // [w'v']
+    o[14] = tot[14] - dd * de;      // [w'Phi']
+    o[15] = tot[15] - df * da;      // [Q'T']
+    const double sTT = o[6], sUU = o[7], sVV = o[8];
+    o[16] = tot[16] - 2 * da * tot[9] + da * da * dc + cV * sTT;       // [v T'T']
+    o[17] = tot[17] - 2 * da * tot[10] + da * da * dd + cW * sTT;      // [w T'T']
+    const double mU = cU + db, mV = cV + dc, mW = cW + dd;
+    o[18] = 2 * mU * o[11] + mU * mU * mV + 2 * mV * sVV + mV * mV * mV;              // [K v]
+    o[19] = 2 * mU * o[12] + mU * mU * mW + 2 * mV * o[13] + mV * mV * mW;            // [K w]
+    o[20] = tot[18] - 2 * db * tot[11] + db * db * dc - 2 * dc * tot[8] + dc * dc * dc + cV * (sUU + sVV);      // [E v]
+    o[21] = tot[19] - 2 * db * tot[12] + db * db * dd - 2 * dc * tot[13] + dc * dc * dd + cW * (sUU + sVV);     // [E w]
+}
+
+// MODE 0: T, u, v, omega (Phi if present), no Q;  1: dT/dt = ta T(t-1) + tb T(t) + tc T(t+1) per point;  2: dT/dt cube.
+// WINDOW: rows fit one column chunk, so a workgroup walks its level chunk with T(k-1), T(k), T(k+1) sliding through registers;
+// otherwise every pass loads its own T neighbours (wide boxes; same arithmetic, same bits).
+template <typename TIN, bool UNIFORM, int MODE, bool WINDOW>
+__global__ void __launch_bounds__(256, 2) lec_boxtile_kernel(const RowParams p) {
+    constexpr bool WITH_Q = MODE != 0;
+    constexpr int NT = n_tiles<UNIFORM, MODE>();
+    __shared__ double sm[lds_doubles<UNIFORM, MODE>()];
+    double* const comb = sm + NT * kTile;                 // [4 waves][kNA][16 rows]: partial sums of a pass
+    double* const side = comb + 4 * kNA * kRB;            // [2][16 rows][kSide], double-buffered by level parity
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+
+    // block -> (time step, level chunk, row block).  Every XCD (blockIdx % 8, speed only) owns a contiguous chunk of time steps
+    // and walks it in groups of tgroup steps: time step fastest, then row block, then level chunk, so the workgroups resident
+    // on an XCD are neighbours in time: the T rows at t+-1 are rows a sibling workgroup loads as its own (L2)
+    const int n_rb = (p.nyb_max + kRB - 1) / kRB;
+    const int n_kc = (p.nl + kLevelChunk - 1) / kLevelChunk;
+    const int xcd = blockIdx.x & 7;
+    int q0 = blockIdx.x >> 3;
+    const int ti = q0 % p.tgroup; q0 /= p.tgroup;
+    const int rbi = q0 % n_rb; q0 /= n_rb;
+    const int kc = q0 % n_kc;
+    const int tin = (q0 / n_kc) * p.tgroup + ti;          // step inside the XCD's chunk (jchunk = time steps per XCD here)
+    const int tl = xcd * p.jchunk + tin;
+    if (tin >= p.jchunk || tl >= p.t_count) return;      // whole workgroup
+
+    const int bi = (p.n_box == 1) ? 0 : tl;
+    const int iw = p.box[4 * bi + 0], ie = p.box[4 * bi + 1], js = p.box[4 * bi + 2], jn = p.box[4 * bi + 3];
+    const int nxb = ie - iw + 1, nyb = jn - js + 1;
+    const int jb0 = rbi * kRB;
+    const int k0 = kc * kLevelChunk, k1 = min(k0 + kLevelChunk, p.nl);
+    if (jb0 >= nyb) {       // a row block that holds only padding rows of a box lower than nyb_max
+        const int nrow = min(kRB, p.nyb_max - jb0);
+        for (int k = k0; k < k1; ++k) {
+            double* rec = p.rows + ((size_t)(tl * p.nl + k) * p.nyb_max + jb0) * LEC_NSTAT;
+            for (int e = tid; e < nrow * LEC_NSTAT; e += 256) rec[e] = 0.0;
+        }
+        return;
+    }
+
+    const int t = p.t_begin + tl;
+    const size_t plane = (size_t)p.ny * p.nx;
+    const size_t cube = plane * p.nl;
+    const size_t t0off = (size_t)t * cube + (size_t)iw;
+    const TIN* __restrict__ gT = (const TIN*)p.T + t0off;
+    const TIN* __restrict__ gU = (const TIN*)p.U + t0off;
+    const TIN* __restrict__ gV = (const TIN*)p.V + t0off;
+    const TIN* __restrict__ gW = (const TIN*)p.W + t0off;
+    const bool has_p = p.P != nullptr;
+    const TIN* __restrict__ gP = (const TIN*)(has_p ? p.P : p.T) + t0off;
+    // neighbours in time: the own time step where there is none (the coefficient is 0 there); MODE 2: the dT/dt cube
+    const TIN* __restrict__ gD0 = (MODE == 2) ? (const TIN*)p.DT + t0off : ((t > 0) ? gT - cube : gT);
+    const TIN* __restrict__ gD1 = (t < p.nt - 1) ? gT + cube : gT;
+    double ta = 0, tb = 0, tc = 0;
+    if (MODE == 1) { const double* tcf = p.tcoef + (size_t)t * 3; ta = tcf[0]; tb = tcf[1]; tc = tcf[2]; }
+    // Row / level coefficients are wave-uniform, but inside the pass loop (which stores row records) the compiler would fetch them
+    // with VECTOR loads followed by s_waitcnt vmcnt(0) -- draining the prefetched rows every time.  So they are loaded once, here,
+    // spread over the lanes, and picked with v_readlane inside the loop:
+    //   latv: lane 4 i + j = coefficient j (d/dlat a, b, c; 1/dx) of the wave's row i;  levv: lane 3 kk + j = static-stability
+    //   coefficient j of level k0 + kk
+    double latv = 0.0, levv = 0.0;
+    if (WITH_Q) {
+        const int jrow = min(jb0 + 4 * wave + ((lane >> 2) & 3), nyb - 1);
+        latv = p.lattab[((size_t)bi * p.nyb_max + jrow) * 4 + (lane & 3)];
+        levv = p.levtab[(size_t)min(k0 + lane / 3, p.nl - 1) * 3 + lane % 3];
+    }
+    double lga[4], lgb[4], lgc[4], lidx[4];               // the wave's four rows (the same for every level): wave-uniform
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        lga[i] = lane_value(latv, 4 * i); lgb[i] = lane_value(latv, 4 * i + 1); lgc[i] = lane_value(latv, 4 * i + 2);
+        lidx[i] = lane_value(latv, 4 * i + 3);
+    }
+    const double inv_xlen = p.boxtab[4 * bi + 0], h_rad = p.boxtab[4 * bi + 1], inv_hdeg = p.boxtab[4 * bi + 2];
+    const double* __restrict__ wl = UNIFORM ? nullptr : p.wlon + (size_t)bi * p.nxb_max;
+    const double* __restrict__ gl = UNIFORM ? nullptr : p.glon + (size_t)bi * p.nxb_max * 3;
+
+    const int ncc = WINDOW ? 1 : (nxb + kCW - 1) / kCW;   // column chunks per row
+    const int npass = (k1 - k0) * ncc;
+
+    // element offsets (inside a level plane) of the wave's rows: rows -1 .. 4 relative to 4 w, clamped into the box
+    unsigned roff[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) roff[i] = (unsigned)__builtin_amdgcn_readfirstlane((js + min(max(jb0 + 4 * wave + i - 1, 0), nyb - 1)) * p.nx);
+
+    // ---- registers of the load layout.  T window: Tn = level k+1 (rows -1 .. 4), Tc = level k, Tm = level k-1 (rows 0 .. 3);
+    // En / Ec: T at the columns just outside the chunk (lanes 0..31: c0 - 1, lanes 32..63: c0 + 64) of the centre rows at k+1 / k
+    TIN Tn[6], Tc[6], Tm[4], En[4] = {}, Ec[4] = {}, rU[4], rV[4], rW[4], rP[4], rD0[4], rD1[4];
+    double rWl = 0.0, rG[3] = {0.0, 0.0, 0.0};            // non-uniform longitudes: the lane's trapezoid weight and d/dlon coefficients
+    if (LEC_BT_ABLATE & 2) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { Tn[i] = (TIN)(281 + lane + i); Tc[i] = (TIN)(280 + lane + i); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { Tm[i] = (TIN)(279 + lane); En[i] = Ec[i] = (TIN)280; rU[i] = (TIN)lane; rV[i] = (TIN)i; rW[i] = (TIN)0.1; rP[i] = (TIN)(lane * i); rD0[i] = rD1[i] = (TIN)(281 + lane); }
+    }
+    auto lev = [&](int k) -> size_t { return (size_t)min(max(k, 0), p.nl - 1) * plane; };
+    // wave-uniform row pointer + the lane's 32-bit element offset: "global_load v, v_off, s[base]" (no 64-bit address per lane)
+    auto ld = [](const TIN* __restrict__ row, unsigned off) -> TIN {
+        return *reinterpret_cast<const TIN*>(reinterpret_cast<const char*>(row) + off * (unsigned)sizeof(TIN));
+    };
+    auto ldnt = [](const TIN* __restrict__ row, unsigned off) -> TIN {
+        return __builtin_nontemporal_load(reinterpret_cast<const TIN*>(reinterpret_cast<const char*>(row) + off * (unsigned)sizeof(TIN)));
+    };
+    // loads of the pass (level k, column chunk at c0).  `fresh`: the whole T window (no predecessor pass to inherit it from)
+    auto issue_loads = [&](const int k, const int c0, const bool fresh) {
+        if (LEC_BT_ABLATE & 2) return;
+        const unsigned col = (unsigned)min(c0 + lane, nxb - 1);
+        const unsigned ecol = (unsigned)min(max(lane < 32 ? c0 - 1 : c0 + kCW, 0), nxb - 1);
+        const size_t lk = lev(k);
+        if (!UNIFORM) {
+            const int ec = min(c0 + lane, nxb - 1);
+            rWl = wl[ec];
+            if (WITH_Q) { rG[0] = gl[3 * ec]; rG[1] = gl[3 * ec + 1]; rG[2] = gl[3 * ec + 2]; }
+        }
+        if (WITH_Q) {
+            const size_t lp = lev(k + 1);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) Tn[i] = ld(gT + lp + roff[i], col);
+            if (!WINDOW) {      // one column chunk: the columns just outside it are outside the box and never used (one-sided ends)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) En[i] = ld(gT + lp + roff[i + 1], ecol);
+            }
+            if (fresh) {
+                const size_t lm = lev(k - 1);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) Tc[i] = ld(gT + lk + roff[i], col);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { Tm[i] = ld(gT + lm + roff[i + 1], col); if (!WINDOW) Ec[i] = ld(gT + lk + roff[i + 1], ecol); }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Tc[i + 1] = ld(gT + lk + roff[i + 1], col);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const size_t o = lk + roff[i + 1];
+            rU[i] = ldnt(gU + o, col);
+            rV[i] = ldnt(gV + o, col);
+            rW[i] = ldnt(gW + o, col);
+            if (WITH_Q || has_p) rP[i] = ldnt(gP + o, col);
+            if (WITH_Q) {
+                rD0[i] = ld(gD0 + o, col);
+                if (MODE == 1) rD1[i] = ld(gD1 + o, col);
+            }
+        }
+    };
+
+    // ---- compute-layout roles: lane -> (row r of the pass, column group g)
+    const int cr = lane >> 2, cg = lane & 3;
+    double acc[kNA];
+#pragma unroll
+    for (int s = 0; s < kNA; ++s) acc[s] = 0.0;
+    double cT[4], cU[4], cV[4], cW[4], cP[4];              // shifts of the wave's four rows: the row's first box element
+
+    issue_loads(k0, 0, true);
+    if (WINDOW) {
+        for (int e = tid; e < NT * kTile; e += 256) sm[e] = 0.0;
+        __syncthreads();
+    }
+    for (int ps = 0; ps < npass; ++ps) {
+        const int kk = ps / ncc, cc = ps - kk * ncc, k = k0 + kk, c0 = cc * kCW;
+        double* const sd = side + (kk & 1) * kRB * kSide;        // by level parity: a row's side values are gathered over its column chunks
+        // ================= load layout: one point per lane, rows 4w .. 4w+3 =================
+        {
+#pragma clang fp contract(off)
+            const int e = c0 + lane;
+            const bool inside = e < nxb, first = e == 0, last = e == nxb - 1;
+            const bool zero = UNIFORM ? (!inside || first || last) : !inside;     // contributes nothing to the sums taken in LDS
+            const int llast = nxb - 1 - c0;                                        // lane of the row's last point (if in this chunk)
+            const bool has_last = llast >= 0 && llast < kCW;
+            double al = 0, be = 0, gm = 0;
+            if (WITH_Q) { al = lane_value(levv, 3 * kk); be = lane_value(levv, 3 * kk + 1); gm = lane_value(levv, 3 * kk + 2); }
+            const double wgt = UNIFORM ? 0.0 : (inside ? rWl : 0.0);
+            const double g0 = rG[0], g1 = rG[1], g2 = rG[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 4 * wave + i;                    // row of the pass
+                const double T = (double)Tc[i + 1], U = (double)rU[i], V = (double)rV[i], W = (double)rW[i];
+                const double P = (WITH_Q || has_p) ? (has_p ? (double)rP[i] : 0.0) : 0.0;
+                if (cc == 0) {                                 // the row's first box element is lane 0 of the first chunk
+                    cT[i] = lane_value(T, 0); cU[i] = lane_value(U, 0); cV[i] = lane_value(V, 0); cW[i] = lane_value(W, 0);
+                    cP[i] = lane_value(P, 0);
+                }
+                double f = 0.0;
+                if (WITH_Q && !(LEC_BT_ABLATE & 16)) {
+                    const double ga_ = lga[i], gb_ = lgb[i], gc_ = lgc[i], idx = lidx[i];
+                    const double Tl = from_prev_lane(T, WINDOW ? T : (double)Ec[i]), Tr = from_next_lane(T, WINDOW ? T : (double)Ec[i]);
+                    double adv;                               // u dT/dx
+                    if (UNIFORM) {
+                        // centred; one-sided at the row ends: 2 (T[1] - T[0]), 2 (T[n-1] - T[n-2]) -- selects, no branches
+                        const double dd = ((last ? T : Tr) - (first ? T : Tl)) * ((first || last) ? 2.0 : 1.0);
+                        adv = (U * ((0.5 * inv_hdeg) * idx)) * dd;
+                    } else {
+                        adv = U * fma(g2, Tr, fma(g1, T, g0 * Tl)) * idx;
+                    }
+                    const double sP_ = stencil3(ga_, (double)Tc[i], gc_, (double)Tc[i + 2], gb_, T);
+                    const double sS = stencil3(al, (double)Tm[i], gm, (double)Tn[i + 1], be, T);
+                    const double dTdt = (MODE == 1) ? stencil3(ta, (double)rD0[i], tc, (double)rD1[i], tb, T) : (double)rD0[i];
+                    f = fma(-W, sS, fma(V, sP_, dTdt + adv));
+                }
+                const double a = T - cT[i], b = U - cU[i], c = V - cV[i], d = W - cW[i], ee = P - cP[i];
+                const int dst = r * kSF + pos(lane);
+                if (WINDOW) {
+                    // one column chunk: the lanes that contribute nothing are the same in every pass; their tile entries were
+                    // zeroed once before the loop and are never written
+                    if (!zero) {
+                        sm[0 * kTile + dst] = a; sm[1 * kTile + dst] = b; sm[2 * kTile + dst] = c; sm[3 * kTile + dst] = d;
+                        sm[4 * kTile + dst] = ee;
+                        if (WITH_Q) sm[5 * kTile + dst] = f;
+                        if (!UNIFORM) sm[(NT - 1) * kTile + dst] = wgt;
+                    }
+                } else {
+                    sm[0 * kTile + dst] = zero ? 0.0 : a;
+                    sm[1 * kTile + dst] = zero ? 0.0 : b;
+                    sm[2 * kTile + dst] = zero ? 0.0 : c;
+                    sm[3 * kTile + dst] = zero ? 0.0 : d;
+                    sm[4 * kTile + dst] = zero ? 0.0 : ee;
+                    if (WITH_Q) sm[5 * kTile + dst] = zero ? 0.0 : f;
+                    if (!UNIFORM) sm[(NT - 1) * kTile + dst] = wgt;
+                }
+                // the row's side values for its finishing lane
+                double* sr = sd + r * kSide;
+                if (cc == 0 && lane == 0) { sr[0] = cT[i]; sr[1] = cU[i]; sr[2] = cV[i]; sr[3] = cW[i]; sr[4] = cP[i]; sr[5] = f; }
+                if (has_last && lane == llast) {
+                    sr[6] = a; sr[7] = b; sr[8] = c; sr[9] = d; sr[10] = ee; sr[11] = f;
+                    sr[12] = T; sr[13] = U; sr[14] = V;
+                }
+            }
+            if (WITH_Q && WINDOW) {       // slide the window one level down
+#pragma unroll
+                for (int i = 0; i < 4; ++i) Tm[i] = Tc[i + 1];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) Tc[i] = Tn[i];
+            }
+        }
+        __syncthreads();
+        if (ps + 1 < npass) {              // in flight while this pass is reduced
+            const int kn = (ps + 1) / ncc, cn = (ps + 1) - kn * ncc;
+            issue_loads(k0 + kn, cn * kCW, !WINDOW);
+        }
+        // ================= compute layout: lane (cr, cg), columns 16 cg + 4 wave + q =================
+        if (!(LEC_BT_ABLATE & 1)) {
+#pragma clang fp contract(off)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int src = cr * kSF + 17 * cg + 4 * wave + q;      // = row * stride + pos(16 cg + 4 wave + q)
+                const double a = sm[0 * kTile + src], b = sm[1 * kTile + src], c = sm[2 * kTile + src], d = sm[3 * kTile + src];
+                const double ee = sm[4 * kTile + src];
+                const double f = WITH_Q ? sm[5 * kTile + src] : 0.0;
+                if (UNIFORM) accum20<true>(acc, 1.0, a, b, c, d, ee, f);
+                else accum20<false>(acc, sm[(NT - 1) * kTile + src], a, b, c, d, ee, f);
+            }
+        }
+        const bool row_done = cc == ncc - 1;
+        if (row_done && !(LEC_BT_ABLATE & 8)) {      // the level's rows are complete: the four column groups of a row sit in one quad
+            quad_sums(acc);
+            if (cg == 0) {
+#pragma unroll
+                for (int s = 0; s < kNA; ++s) comb[(wave * kNA + s) * kRB + cr] = acc[s];
+            }
+#pragma unroll
+            for (int s = 0; s < kNA; ++s) acc[s] = 0.0;
+        }
+        __syncthreads();
+        // the four waves' partial sums of the pass, added in a fixed order; one row per lane: 16 lanes of one wave finish the
+        // pass's rows while the other waves already work on the next pass
+        if (row_done && wave == (kk & 3) && lane < kRB && !(LEC_BT_ABLATE & 4)) {
+#pragma clang fp contract(off)
+            const int jb = jb0 + lane;
+            if (jb < p.nyb_max) {
+                dbl2_t* __restrict__ out = reinterpret_cast<dbl2_t*>(p.rows + ((size_t)(tl * p.nl + k) * p.nyb_max + jb) * LEC_NSTAT);
+                double o[LEC_NSTAT];
+#pragma unroll
+                for (int s = 0; s < LEC_NSTAT; ++s) o[s] = 0.0;
+                if (jb < nyb) {
+                    const double* sr = sd + lane * kSide;
+                    double tot[kNA];
+#pragma unroll
+                    for (int s = 0; s < kNA; ++s) {
+                        double a = comb[s * kRB + lane];
+#pragma unroll
+                        for (int w2 = 1; w2 < 4; ++w2) a += comb[(w2 * kNA + s) * kRB + lane];
+                        tot[s] = a;
+                    }
+                    double scale = inv_xlen;
+                    if (UNIFORM) {
+                        // the trapezoid's end points, weight 1/2 each: the first point has a = b = c = d = e = 0 (it is the shift),
+                        // so only its f counts; the last point brings all 20 monomials
+                        double ends[kNA];
+#pragma unroll
+                        for (int s = 0; s < kNA; ++s) ends[s] = 0.0;
+                        accum20<true>(ends, 1.0, sr[6], sr[7], sr[8], sr[9], sr[10], sr[11]);
+                        ends[5] += sr[5];
+#pragma unroll
+                        for (int s = 0; s < kNA; ++s) tot[s] = fma(0.5, ends[s], tot[s]);
+                        scale = h_rad * inv_xlen;
+                    }
+#pragma unroll
+                    for (int s = 0; s < kNA; ++s) tot[s] = tot[s] * ((s == 5 || s == 15) ? scale * kCp : scale);      // <f>, <fa>: Q = cp f
+                    double o22[22];
+                    finish_lane(tot, sr[0], sr[1], sr[2], sr[3], sr[4], o22);
+#pragma unroll
+                    for (int s = 0; s < 22; ++s) o[s] = o22[s];
+                    o[LEC_S_TW] = sr[0]; o[LEC_S_TE] = sr[12]; o[LEC_S_UW] = sr[1]; o[LEC_S_UE] = sr[13]; o[LEC_S_VW] = sr[2]; o[LEC_S_VE] = sr[14];
+                }
+#pragma unroll
+                for (int s = 0; s < LEC_NSTAT / 2; ++s) { dbl2_t v2; v2.x = o[2 * s]; v2.y = o[2 * s + 1]; out[s] = v2; }
+            }
+        }
+    }
+}
+
+template <typename TIN>
+int launch_tiles(RowParams p, bool uniform, int mode, hipStream_t st) {
+    const long long n_rb = (p.nyb_max + kRB - 1) / kRB, n_kc = (p.nl + kLevelChunk - 1) / kLevelChunk;
+    p.jchunk = (p.t_count + 7) / 8;                       // time steps per XCD
+    if (p.tgroup < 1) p.tgroup = 8;
+    if (p.tgroup > p.jchunk) p.tgroup = p.jchunk;
+    const long long tgroups = (p.jchunk + p.tgroup - 1) / p.tgroup;
+    const long long nblocks = 8LL * tgroups * p.tgroup * n_rb * n_kc;
+    if (nblocks > 0x7fffffffLL) return LEC_ERR_UNSUPPORTED;
+    if ((unsigned long long)p.ny * (unsigned long long)p.nx > 0xffffffffULL) return LEC_ERR_UNSUPPORTED;     // 32-bit offsets inside a plane
+    dim3 grid((unsigned)nblocks), block(256);
+    const bool window = mode != 0 && p.nxb_max <= kCW;    // same arithmetic either way: only where the T neighbours come from differs
+#define LEC_TILE(U, M, W) hipLaunchKernelGGL((lec_boxtile_kernel<TIN, U, M, W>), grid, block, 0, st, p)
+#define LEC_TILE_W(U, M) do { if (window) LEC_TILE(U, M, true); else LEC_TILE(U, M, false); } while (0)
+    if (uniform) { if (mode == 0) LEC_TILE(true, 0, false); else if (mode == 1) LEC_TILE_W(true, 1); else LEC_TILE_W(true, 2); }
+    else { if (mode == 0) LEC_TILE(false, 0, false); else if (mode == 1) LEC_TILE_W(false, 1); else LEC_TILE_W(false, 2); }
+#undef LEC_TILE_W
+#undef LEC_TILE
+    return LEC_OK;
+}
+
+}  // namespace
+
+// mode: 0 no Q, 1 dT/dt from the cube's time neighbours per point, 2 dT/dt cube; p.tgroup: time steps per tile group (< 1: default)
+int lec_launch_boxtile(const lec::RowParams& p, int dtype, bool uniform, int mode, hipStream_t st) {
+    return dtype == LEC_F64 ? launch_tiles<double>(p, uniform, mode, st) : launch_tiles<float>(p, uniform, mode, st);
+}

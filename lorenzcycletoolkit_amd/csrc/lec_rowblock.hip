@@ -16,7 +16,6 @@
 // block mates read correct data; they just do not store.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 
 #include <type_traits>
 

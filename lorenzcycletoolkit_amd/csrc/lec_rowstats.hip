@@ -11,7 +11,6 @@
 // Reference formulas: SURVEY.md appendix A / F; AdiabaticHEating thermodynamics.py:95-121.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 
 #include "../../include/lec_hip.h"
 #include "lec_internal.h"
@@ -302,17 +301,16 @@ int launch_vec(const RowParams& p, bool uniform, int mode, int nblocks, hipStrea
 
 }  // namespace
 
-static bool kernel_is_two_sweep() { const char* ek = getenv("LEC_KERNEL"); return ek && atoi(ek) == 0; }
-
-int lec_launch_rowsweep(const lec::RowParams& p, int dtype, bool aligned, bool aligned8, bool uniform, int mode, hipStream_t st);
+int lec_launch_rowsweep(const lec::RowParams& p, int dtype, bool aligned, bool aligned8, bool uniform, int mode, int f32_vec, hipStream_t st);
 int lec_launch_rowblock(lec::RowParams p, int dtype, bool aligned, bool aligned8, bool uniform, int bt, int bk, int bj, hipStream_t st);
+int lec_launch_boxtile(const lec::RowParams& p, int dtype, bool uniform, int mode, hipStream_t st);
 int lec_launch_qtime(const lec::RowParams& p, hipStream_t st);
 
-extern "C" int lec_max_row(int dtype, int aligned) {
+extern "C" int lec_max_row(int dtype, int aligned, int kernel) {
     (void)dtype;
-    // the default (single-sweep) kernel walks a row in trips of 64 vectors, so any row the cube can hold is fine;
-    // the two-sweep cross-check kernel (LEC_KERNEL=0) keeps a whole row in registers: 256 * LEC_MAX_ITERS vectors
-    if (kernel_is_two_sweep()) return (256 * LEC_MAX_ITERS - 1) * (aligned ? 2 : 1);
+    // the single-sweep kernels walk a row in trips / strips, so any row the cube can hold is fine; the two-sweep
+    // cross-check kernel keeps a whole row in registers: 256 * LEC_MAX_ITERS vectors
+    if (kernel == LEC_KERNEL_TWO_SWEEP) return (256 * LEC_MAX_ITERS - 1) * (aligned ? 2 : 1);
     return 1 << 24;
 }
 
@@ -323,13 +321,28 @@ extern "C" int lec_rowstats(const lec_rowstats_args* a) {
     if (a->dtype != LEC_F64 && a->dtype != LEC_F32) return lec_set_error(LEC_ERR_ARG, "lec_rowstats: dtype must be LEC_F64 or LEC_F32");
     if (a->nt < 1 || a->nl < 2 || a->ny < 2 || a->nx < 2) return lec_set_error(LEC_ERR_ARG, "lec_rowstats: cube needs nt>=1, nl>=2, ny>=2, nx>=2");
     if (a->t_begin < 0 || a->t_count < 1 || a->t_begin + a->t_count > a->nt) return lec_set_error(LEC_ERR_ARG, "lec_rowstats: [t_begin, t_begin+t_count) outside the cube");
-    if (a->n_box != 1 && a->n_box != a->t_count) return lec_set_error(LEC_ERR_ARG, "lec_rowstats: n_box must be 1 or t_count");
+    if (a->box_per_step != 0 && a->box_per_step != 1) return lec_set_error(LEC_ERR_ARG, "lec_rowstats: box_per_step must be 0 or 1");
+    if (a->n_box != (a->box_per_step ? a->t_count : 1)) return lec_set_error(LEC_ERR_ARG, "lec_rowstats: n_box must be 1 (fixed box) or t_count (box_per_step)");
+    if (a->reserved0) return lec_set_error(LEC_ERR_ARG, "lec_rowstats: reserved0 must be 0");
     if (a->nxb_max < 2 || a->nyb_max < 2 || a->nxb_max > a->nx || a->nyb_max > a->ny) return lec_set_error(LEC_ERR_ARG, "lec_rowstats: box extents must be 2..nx by 2..ny points");
     if (!a->lon_uniform && (!a->wlon_d || !a->glon_d)) return lec_set_error(LEC_ERR_ARG, "lec_rowstats: non-uniform longitudes need wlon_d and glon_d");
     if (a->with_q) {
         if (!a->lattab_d || !a->levtab_d) return lec_set_error(LEC_ERR_ARG, "lec_rowstats: with_q needs lattab_d and levtab_d");
         if (!a->dTdt_d && !a->tcoef_d) return lec_set_error(LEC_ERR_ARG, "lec_rowstats: with_q needs dTdt_d or tcoef_d");
         if (!a->dTdt_d && a->nt < 2) return lec_set_error(LEC_ERR_ARG, "lec_rowstats: dT/dt from the cube needs nt >= 2");
+    }
+    const lec_tuning& tu = a->tuning;
+    if (tu.kernel < LEC_KERNEL_AUTO || tu.kernel > LEC_KERNEL_BOX_TILE) return lec_set_error(LEC_ERR_ARG, "lec_rowstats: tuning.kernel is not an enum lec_kernel value");
+    if (tu.order != LEC_ORDER_AUTO && tu.order != LEC_ORDER_MEMORY && tu.order != LEC_ORDER_XCD_LAT && tu.order != LEC_ORDER_XCD_TILED)
+        return lec_set_error(LEC_ERR_ARG, "lec_rowstats: tuning.order is not an enum lec_order value");
+    if (tu.tile_t < 0 || tu.tile_j < 0) return lec_set_error(LEC_ERR_ARG, "lec_rowstats: tuning.tile_t / tile_j must be >= 0 (0 = default)");
+    if (tu.f32_vec != 0 && tu.f32_vec != 2) return lec_set_error(LEC_ERR_ARG, "lec_rowstats: tuning.f32_vec must be 0 or 2");
+    if (tu.reserved[0] || tu.reserved[1]) return lec_set_error(LEC_ERR_ARG, "lec_rowstats: tuning.reserved must be 0");
+    int bt = 2, bk = 1, bj = 2;
+    if (tu.block_shape) {
+        bt = tu.block_shape / 100; bk = (tu.block_shape / 10) % 10; bj = tu.block_shape % 10;
+        if (tu.block_shape < 0 || bt < 1 || bt > 2 || bk < 1 || bk > 2 || bj < 1 || bj > 2 || bt * bk * bj < 2)
+            return lec_set_error(LEC_ERR_ARG, "lec_rowstats: tuning.block_shape must be 100 bt + 10 bk + bj with bt, bk, bj in {1, 2} and at least two waves");
     }
     const size_t esz = a->dtype == LEC_F32 ? 4 : 8;
     const int vecw = (int)(16 / esz);
@@ -341,7 +354,7 @@ extern "C" int lec_rowstats(const lec_rowstats_args* a) {
         if ((uintptr_t)c % 16) aligned = false;
         if ((uintptr_t)c % 8) aligned8 = false;
     }
-    if (a->nxb_max > lec_max_row(a->dtype, a->dtype == LEC_F32 ? aligned8 : aligned)) return lec_set_error(LEC_ERR_UNSUPPORTED, "lec_rowstats: box row longer than lec_max_row()");
+    if (a->nxb_max > lec_max_row(a->dtype, a->dtype == LEC_F32 ? aligned8 : aligned, tu.kernel)) return lec_set_error(LEC_ERR_UNSUPPORTED, "lec_rowstats: box row longer than lec_max_row()");
     const long long nrows = (long long)a->t_count * a->nl * a->nyb_max;
     if (nrows > 0x7fffffffLL) return lec_set_error(LEC_ERR_UNSUPPORTED, "lec_rowstats: more than 2^31-1 rows in one call");
 
@@ -349,55 +362,70 @@ extern "C" int lec_rowstats(const lec_rowstats_args* a) {
     p.T = a->tair_d; p.U = a->u_d; p.V = a->v_d; p.W = a->omega_d; p.P = a->geopt_d; p.DT = a->dTdt_d;
     p.nt = a->nt; p.nl = a->nl; p.ny = a->ny; p.nx = a->nx;
     p.t_begin = a->t_begin; p.t_count = a->t_count;
-    p.n_box = a->n_box; p.nxb_max = a->nxb_max; p.nyb_max = a->nyb_max;
+    p.n_box = a->box_per_step ? 2 : 1;      // kernels index the box tables by time step iff n_box != 1
+    p.nxb_max = a->nxb_max; p.nyb_max = a->nyb_max;
     p.box = a->box_d; p.boxtab = a->boxtab_d; p.wlon = a->wlon_d; p.glon = a->glon_d;
     p.lattab = a->lattab_d; p.levtab = a->levtab_d; p.tcoef = a->tcoef_d;
     p.rows = a->rows_d;
+    p.ntrips = 0; p.jrows = 0; p.cpx = 0;
     hipStream_t st = (hipStream_t)a->stream;
     const bool uni = a->lon_uniform != 0;
     const int wq = !a->with_q ? 0 : (a->dTdt_d ? 2 : 1);      // Q: none / dT/dt from the cube's time axis / dT/dt cube
-    const bool two_sweep = kernel_is_two_sweep();
+    const bool fixed_time_stencil = (wq == 1 && !a->box_per_step);
 
-    // Workgroup -> row order (speed only; defaults from the round-1 A/B on MI355X, profiles/r01_notes.md).  Workgroups are dealt
-    // to the 8 XCDs round-robin, so blockIdx % 8 labels the XCD: order 2 gives every XCD a contiguous latitude chunk, walked
-    // latitude-fastest per (time, level); order 7 (all terms on one fixed box) walks tiles of tgroup time steps x jgroup
-    // latitudes at one level, levels next; order 0 is memory order.  LEC_ORDER / LEC_TG / LEC_JG override (experiments).
-    const bool fixed_time_stencil = (wq == 1 && a->n_box == 1);
+    // Kernel family.  AUTO (what is measured and shipped): per-time-step boxes (the moving framework) run on the box-tile
+    // kernel; all terms with dT/dt from the cube on ONE fixed box in fp64 storage on the row-block kernel (17.3-17.6 vs
+    // 17.5-17.9 ms per 64 steps for one wave per row; fp32 storage: no gain measured); everything else on one wave per row.
+    // The choice depends only on the kind of call, never on extents, so shards and chunks of one series use one family.
+    int kernel = tu.kernel;
+    const bool block_ok = fixed_time_stencil && a->geopt_d && a->t_count >= 2;
+    if (kernel == LEC_KERNEL_AUTO) {
+        if (a->box_per_step) kernel = LEC_KERNEL_BOX_TILE;
+        else if (block_ok && a->dtype == LEC_F64 && tu.order == LEC_ORDER_AUTO) kernel = LEC_KERNEL_ROW_BLOCK;
+        else kernel = LEC_KERNEL_ROW_SWEEP;
+    }
+    if (kernel == LEC_KERNEL_ROW_BLOCK && !block_ok) kernel = LEC_KERNEL_ROW_SWEEP;       // a one-step shard of a row-block series: same bits
+
+    // Workgroup -> row order (speed only; defaults from the A/B runs on MI355X, profiles/r01_notes.md).  Workgroups are dealt
+    // to the 8 XCDs round-robin, so blockIdx % 8 labels the XCD: XCD_LAT gives every XCD a contiguous latitude chunk, walked
+    // latitude-fastest per (time, level); XCD_TILED (all terms on one fixed box) walks tiles of tile_t time steps x tile_j
+    // latitudes at one level, levels next; MEMORY is memory order.
+    const bool two_sweep = kernel == LEC_KERNEL_TWO_SWEEP;
     p.order = (fixed_time_stencil && a->t_count >= 2 && !two_sweep) ? 7 : 2;
-    if (const char* eo = getenv("LEC_ORDER")) p.order = atoi(eo);
+    if (tu.order == LEC_ORDER_MEMORY) p.order = 0;
+    else if (tu.order != LEC_ORDER_AUTO) p.order = tu.order;
     if (p.order == 7 && (!fixed_time_stencil || two_sweep)) p.order = 2;
     p.jchunk = p.order ? (a->nyb_max + 7) / 8 : 0;
-    const char* etg = getenv("LEC_TG"); const char* ejg = getenv("LEC_JG");
     const int ntile = (a->t_count + 3) / 4;                       // time tiles of (almost) equal size, at most 4 steps each
-    p.tgroup = etg ? atoi(etg) : (a->t_count + ntile - 1) / ntile;
-    p.jgroup = ejg ? atoi(ejg) : 8;
+    p.tgroup = tu.tile_t ? tu.tile_t : (a->t_count + ntile - 1) / ntile;
+    p.jgroup = tu.tile_j ? tu.tile_j : 8;
     if (p.jgroup > (a->nyb_max + 7) / 8) p.jgroup = (a->nyb_max + 7) / 8;    // never wider than an XCD's latitude chunk
-    if (p.tgroup < 1) p.tgroup = 1;
-    if (p.jgroup < 1) p.jgroup = 1;
 
     int rc;
     if (two_sweep) {
-        // LEC_KERNEL=0: the two-sweep kernel of this file (deviation from the zonal mean, then products -- the reference's own
-        // order; Q per point), kept as an independent formulation for cross-checks
+        // the two-sweep kernel of this file (deviation from the zonal mean, then products -- the reference's own order; Q per
+        // point), kept as an independent formulation for cross-checks
         long long nblocks = p.order ? (long long)a->t_count * 8 * p.jchunk * a->nl : nrows;
         if (nblocks > 0x7fffffffLL) { p.order = 0; nblocks = nrows; }
         if (a->dtype == LEC_F64) rc = aligned ? launch_vec<double, 2>(p, uni, wq, (int)nblocks, st) : launch_vec<double, 1>(p, uni, wq, (int)nblocks, st);
         else                     rc = aligned ? launch_vec<float, 4>(p, uni, wq, (int)nblocks, st) : launch_vec<float, 1>(p, uni, wq, (int)nblocks, st);
+    } else if (kernel == LEC_KERNEL_BOX_TILE) {
+        // Q per point (modes 1 / 2): the time neighbours of a moving box sum over other boxes, so the cross-time covariance
+        // form of mode 3 does not apply
+        RowParams pt = p;
+        pt.tgroup = tu.tile_t;                              // time steps per tile group; 0 = the kernel's default (8)
+        rc = lec_launch_boxtile(pt, a->dtype, uni, wq, st);
     } else {
-        // Single-sweep kernels (default).  All terms with dT/dt from the cube on one fixed box (the headline configuration, mode
-        // 3): a row reads T(t+1) only and the time-derivative parts of [Q], [Q'T'] are completed from the records afterwards
-        // (lec_qtime_kernel).  With fp64 storage it runs on the row-block kernel, 2 time steps x 2 latitudes per workgroup
-        // (lec_rowblock.hip: 17.3-17.6 vs 17.5-17.9 ms per 64 steps); LEC_BLK=<bt><bk><bj> picks another block shape, LEC_BLK=0
-        // the one-wave-per-row kernel everywhere (bit-identical results; fp32 storage: no gain measured, not used).
+        // Single-sweep row kernels.  All terms with dT/dt from the cube on one fixed box (the headline configuration, mode 3): a
+        // row reads T(t+1) only and the time-derivative parts of [Q], [Q'T'] are completed from the records afterwards
+        // (lec_qtime_kernel).  The row-block and the one-wave-per-row kernel give bit-identical records.
         const int mode = fixed_time_stencil ? 3 : wq;
-        const char* eblk = getenv("LEC_BLK");
-        const int blk = eblk ? atoi(eblk) : (a->dtype == LEC_F64 ? 212 : 0);
-        const bool block_ok = blk > 0 && mode == 3 && a->geopt_d && a->t_count >= 2 && !getenv("LEC_ORDER");
-        if (!block_ok) rc = lec_launch_rowsweep(p, a->dtype, aligned, aligned8, uni, mode, st);
-        else {
+        if (kernel == LEC_KERNEL_ROW_BLOCK) {
             RowParams pb = p;
-            pb.order = 8; pb.tgroup = etg ? atoi(etg) : 2; pb.jgroup = ejg ? atoi(ejg) : 4;      // tile: 2 x 4 blocks at one level, levels next
-            rc = lec_launch_rowblock(pb, a->dtype, aligned, aligned8, uni, blk / 100, (blk / 10) % 10, blk % 10, st);
+            pb.order = 8; pb.tgroup = tu.tile_t ? tu.tile_t : 2; pb.jgroup = tu.tile_j ? tu.tile_j : 4;      // tile: 2 x 4 blocks at one level, levels next
+            rc = lec_launch_rowblock(pb, a->dtype, aligned, aligned8, uni, bt, bk, bj, st);
+        } else {
+            rc = lec_launch_rowsweep(p, a->dtype, aligned, aligned8, uni, mode, tu.f32_vec, st);
         }
         if (rc == LEC_OK && mode == 3) rc = lec_launch_qtime(p, st);
     }

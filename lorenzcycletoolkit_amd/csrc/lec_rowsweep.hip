@@ -16,7 +16,6 @@
 // Output: the same LEC_NSTAT row records as lec_rowstats.hip (stage 2 is unchanged).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 
 #include <type_traits>
 
@@ -293,11 +292,10 @@ int launch_vec(const RowParams& p, bool uniform, int mode, hipStream_t st) {
 // `aligned` = every cube base is 16-byte aligned and nx is a multiple of the 16-byte vector;
 // `aligned8` (fp32 only) = 8-byte aligned bases and even nx.  fp32 storage uses float4 vectors when it can
 // (four elements per lane and trip, operands kept as floats and converted at use, one element finished before the
-// next starts: 141 VGPRs, 3 waves/SIMD, 10.5 ms per 64 steps) and float2 otherwise (11.0 ms; LEC_F32VEC=2 forces it).
-int lec_launch_rowsweep(const lec::RowParams& p, int dtype, bool aligned, bool aligned8, bool uniform, int mode, hipStream_t st) {
+// next starts: 141 VGPRs, 3 waves/SIMD, 10.5 ms per 64 steps) and float2 otherwise (11.0 ms; tuning.f32_vec = 2 forces it).
+int lec_launch_rowsweep(const lec::RowParams& p, int dtype, bool aligned, bool aligned8, bool uniform, int mode, int f32_vec, hipStream_t st) {
     if (dtype == LEC_F64) return aligned ? launch_vec<double, 2>(p, uniform, mode, st) : launch_vec<double, 1>(p, uniform, mode, st);
-    const char* ev = getenv("LEC_F32VEC");
-    if (aligned && !(ev && atoi(ev) == 2)) return launch_vec<float, 4>(p, uniform, mode, st);
+    if (aligned && f32_vec != 2) return launch_vec<float, 4>(p, uniform, mode, st);
     return aligned8 ? launch_vec<float, 2>(p, uniform, mode, st) : launch_vec<float, 1>(p, uniform, mode, st);
 }
 

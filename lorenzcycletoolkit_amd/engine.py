@@ -40,6 +40,31 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+_KERNELS = {"auto": _lib.KERNEL_AUTO, "two_sweep": _lib.KERNEL_TWO_SWEEP, "row_sweep": _lib.KERNEL_ROW_SWEEP,
+            "row_block": _lib.KERNEL_ROW_BLOCK, "box_tile": _lib.KERNEL_BOX_TILE}
+_ORDERS = {"auto": _lib.ORDER_AUTO, "memory": _lib.ORDER_MEMORY, "xcd_lat": _lib.ORDER_XCD_LAT, "xcd_tiled": _lib.ORDER_XCD_TILED}
+
+
+def make_tuning(tuning: Optional[dict]) -> "_lib.Tuning":
+    """``lec_tuning`` from a dict with any of: kernel ("auto" | "two_sweep" | "row_sweep" | "row_block" | "box_tile"),
+    block_shape (e.g. 212), order ("auto" | "memory" | "xcd_lat" | "xcd_tiled"), tile_t, tile_j, f32_vec.
+    None / {} = the library's defaults (what is measured and shipped); the rest is for cross-checks and A/B runs."""
+    t = _lib.Tuning()
+    if not tuning:
+        return t
+    unknown = set(tuning) - {"kernel", "block_shape", "order", "tile_t", "tile_j", "f32_vec"}
+    if unknown:
+        raise ValueError(f"unknown tuning keys {sorted(unknown)}")
+    k, o = tuning.get("kernel", "auto"), tuning.get("order", "auto")
+    if k not in _KERNELS or o not in _ORDERS:
+        raise ValueError(f"tuning: kernel must be one of {sorted(_KERNELS)}, order one of {sorted(_ORDERS)}")
+    t.kernel, t.order = _KERNELS[k], _ORDERS[o]
+    t.block_shape = int(tuning.get("block_shape", 0))
+    t.tile_t, t.tile_j = int(tuning.get("tile_t", 0)), int(tuning.get("tile_j", 0))
+    t.f32_vec = int(tuning.get("f32_vec", 0))
+    return t
+
+
 class LECEngine:
     """One engine per (grid, device).
 
@@ -73,12 +98,12 @@ class LECEngine:
         """Nearest-grid-point inclusive box, as BoxData._set_domain_limits (box_data.py:115-131)."""
         return tables.box_indices(self.lat, self.lon, west, east, south, north)
 
-    def _box_tables(self, boxes):
-        key = tuple(int(v) for b in boxes for v in b)
+    def _box_tables(self, boxes, nyb_min: int = 0):
+        key = (int(nyb_min),) + tuple(int(v) for b in boxes for v in b)
         hit = self._box_cache.get(key)
         if hit is not None:
             return hit
-        bt = tables.build_box_tables(self.lat, self.lon, boxes)
+        bt = tables.build_box_tables(self.lat, self.lon, boxes, nyb_min=nyb_min)
         dev = {
             "box": self._up(bt.box, torch.int32), "boxtab": self._up(bt.boxtab), "wlon": self._up(bt.wlon),
             "glon": self._up(bt.glon), "lattab": self._up(bt.lattab), "boxtab2": self._up(bt.boxtab2),
@@ -96,11 +121,14 @@ class LECEngine:
                 t_count: Optional[int] = None, with_q: bool = True, phi_scale: float = 1.0,
                 keep_rows: bool = False, timing: Optional[list] = None,
                 drop_any_time: Optional[bool] = None,
-                merge_dropmask: Optional[Callable[[torch.Tensor], None]] = None) -> LECResult:
+                merge_dropmask: Optional[Callable[[torch.Tensor], None]] = None,
+                tuning: Optional[dict] = None, per_step_boxes: Optional[bool] = None) -> LECResult:
         """All LEC terms for time steps [t_begin, t_begin + t_count) of the cubes: ``rowstats`` then ``reduce``.
 
         ``boxes``: one (iw, ie, js, jn) quadruple (fixed framework) or one per processed time step
-        (moving framework).  ``time_s`` (seconds, length nt) gives dT/dt by np.gradient over the
+        (moving framework).  ``per_step_boxes``: True = the moving framework's semantics (default when more than one
+        box is given); say so explicitly for a ONE-step shard or chunk of a moving series, which would otherwise read
+        as a fixed box (same numbers to rounding, but another kernel family: not the same bits).  ``time_s`` (seconds, length nt) gives dT/dt by np.gradient over the
         cube's time axis unless a ``dTdt`` cube is supplied (moving framework).
         ``drop_any_time``: _handle_nans' dropna semantics -- True drops a level that stays NaN at any processed
         time step from every time step's integrals (what the fixed framework's [time, level] arrays do); default:
@@ -110,7 +138,9 @@ class LECEngine:
         stream around the stage-1 kernel (bench.py's roofline figure).
         """
         rows = self.rowstats(tair, u, v, omega, geopt, boxes, time_s=time_s, dTdt=dTdt, t_begin=t_begin, t_count=t_count,
-                             with_q=with_q, timing=timing)
+                             with_q=with_q, timing=timing, tuning=tuning, per_step_boxes=per_step_boxes)
+        if drop_any_time is None and per_step_boxes:
+            drop_any_time = False
         return self.reduce(rows, boxes, phi_scale=phi_scale, drop_any_time=drop_any_time, merge_dropmask=merge_dropmask,
                            keep_rows=keep_rows)
 
@@ -118,8 +148,10 @@ class LECEngine:
                  geopt: Optional[torch.Tensor], boxes: Sequence[Sequence[int]], *,
                  time_s=None, dTdt: Optional[torch.Tensor] = None, t_begin: int = 0,
                  t_count: Optional[int] = None, with_q: bool = True, timing: Optional[list] = None,
-                 rows_out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Stage 1 (``lec_rowstats``): row records [t_count, nl, nyb_max, 32] of time steps [t_begin, t_begin + t_count)."""
+                 rows_out: Optional[torch.Tensor] = None, tuning: Optional[dict] = None,
+                 per_step_boxes: Optional[bool] = None) -> torch.Tensor:
+        """Stage 1 (``lec_rowstats``): row records [t_count, nl, nyb_max, 32] of time steps [t_begin, t_begin + t_count).
+        ``tuning``: see ``make_tuning`` (kernel family / order / tile shape; default = the library's choice)."""
         if tair.dim() != 4:
             raise ValueError("fields must be [time, level, lat, lon]")
         nt, nl, ny, nx = tair.shape
@@ -137,9 +169,12 @@ class LECEngine:
         if t_count is None:
             t_count = nt - t_begin
         boxes = [tuple(int(x) for x in b) for b in (boxes if isinstance(boxes[0], (tuple, list, np.ndarray)) else [boxes])]
-        if len(boxes) not in (1, t_count):
+        if per_step_boxes is None:
+            per_step_boxes = len(boxes) != 1
+        if len(boxes) != (t_count if per_step_boxes else 1):
             raise ValueError("boxes: give one box, or one per processed time step")
-        bt, dev = self._box_tables(boxes)
+        # a slice of a longer series' record buffer (chunked processing): its row count is the tallest box of the whole series
+        bt, dev = self._box_tables(boxes, nyb_min=0 if rows_out is None else int(rows_out.shape[2]))
 
         tcoef = None
         if with_q and dTdt is None:
@@ -165,9 +200,9 @@ class LECEngine:
             dtype=_lib.LEC_F64 if tair.dtype == torch.float64 else _lib.LEC_F32, with_q=int(bool(with_q)),
             nt=nt, nl=nl, ny=ny, nx=nx, t_begin=t_begin, t_count=t_count,
             n_box=len(boxes), nxb_max=bt.nxb_max, nyb_max=bt.nyb_max, lon_uniform=int(bt.lon_uniform),
-            box_d=_ptr(dev["box"]), boxtab_d=_ptr(dev["boxtab"]), wlon_d=_ptr(dev["wlon"]), glon_d=_ptr(dev["glon"]),
+            box_per_step=int(bool(per_step_boxes)), reserved0=0, box_d=_ptr(dev["box"]), boxtab_d=_ptr(dev["boxtab"]), wlon_d=_ptr(dev["wlon"]), glon_d=_ptr(dev["glon"]),
             lattab_d=_ptr(dev["lattab"]), levtab_d=_ptr(self._levtab), tcoef_d=_ptr(tcoef),
-            rows_d=_ptr(rows), stream=stream)
+            rows_d=_ptr(rows), stream=stream, tuning=make_tuning(tuning))
         with torch.cuda.device(tair.device):
             if timing is not None:
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -193,7 +228,7 @@ class LECEngine:
         t_count, nl = int(rows.shape[0]), int(rows.shape[1])
         if len(boxes) not in (1, t_count):
             raise ValueError("boxes: give one box, or one per processed time step")
-        bt, dev = self._box_tables(boxes)
+        bt, dev = self._box_tables(boxes, nyb_min=int(rows.shape[2]))
         if rows.shape != (t_count, self.level.size, bt.nyb_max, _lib.LEC_NSTAT) or rows.dtype != torch.float64 or not rows.is_contiguous():
             raise ValueError("rows must be a contiguous fp64 [t_count, nl, nyb_max, 32] tensor")
         f64 = dict(dtype=torch.float64, device=rows.device)

@@ -80,8 +80,10 @@ class BoxTables:
     lon_uniform: bool
 
 
-def build_box_tables(lat_deg: np.ndarray, lon_deg: np.ndarray, boxes: Sequence[Sequence[int]]) -> BoxTables:
-    """Per-box tables for both stages.  ``boxes`` = inclusive index quadruples (iw, ie, js, jn)."""
+def build_box_tables(lat_deg: np.ndarray, lon_deg: np.ndarray, boxes: Sequence[Sequence[int]], nyb_min: int = 0) -> BoxTables:
+    """Per-box tables for both stages.  ``boxes`` = inclusive index quadruples (iw, ie, js, jn).
+    ``nyb_min``: pad the latitude extent of the tables (and of the row records) to at least this many rows -- chunks of one
+    series of moving boxes share one record buffer, whose row count is the tallest box of the whole series."""
     lat = np.asarray(lat_deg, dtype=np.float64)
     lon = np.asarray(lon_deg, dtype=np.float64)
     box = np.asarray(boxes, dtype=np.int32).reshape(-1, 4)
@@ -92,7 +94,9 @@ def build_box_tables(lat_deg: np.ndarray, lon_deg: np.ndarray, boxes: Sequence[S
     nyb = box[:, 3] - box[:, 2] + 1
     if np.any(nxb < 2) or np.any(nyb < 2):
         raise ValueError("every box needs at least 2 grid points along lat and lon")
-    nxm, nym = int(nxb.max()), int(nyb.max())
+    nxm, nym = int(nxb.max()), max(int(nyb.max()), int(nyb_min))
+    if nym > lat.size:
+        raise ValueError("nyb_min exceeds the grid")
     t = BoxTables(box=box, boxtab=np.zeros((nb, 4)), wlon=np.zeros((nb, nxm)), glon=np.zeros((nb, nxm, 3)),
                   lattab=np.zeros((nb, nym, 4)), boxtab2=np.zeros((nb, 4)), lattab2=np.zeros((nb, nym, 8)),
                   nxb_max=nxm, nyb_max=nym, lon_uniform=True)

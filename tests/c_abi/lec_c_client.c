@@ -43,7 +43,7 @@ int main(int argc, char** argv) {
     ra.tair_d = upload(f, cube); ra.u_d = upload(f, cube); ra.v_d = upload(f, cube); ra.omega_d = upload(f, cube); ra.geopt_d = upload(f, cube);
     ra.dtype = LEC_F64; ra.with_q = 1;
     ra.nt = nt; ra.nl = nl; ra.ny = ny; ra.nx = nx; ra.t_begin = 0; ra.t_count = nt;
-    ra.n_box = 1; ra.nxb_max = nxb; ra.nyb_max = nyb; ra.lon_uniform = uni;
+    ra.n_box = 1; ra.box_per_step = 0; ra.nxb_max = nxb; ra.nyb_max = nyb; ra.lon_uniform = uni;
     ra.box_d = (const int32_t*)upload(f, 4 * sizeof(int32_t));
     ra.boxtab_d = (const double*)upload(f, 4 * sizeof(double));
     ra.wlon_d = (const double*)upload(f, (size_t)nxb * sizeof(double));
@@ -68,6 +68,7 @@ int main(int argc, char** argv) {
     CHECK_HIP(hipMalloc((void**)&nanflag, (size_t)nt * sizeof(int32_t)));
     ra.rows_d = rows;
     ra.stream = NULL;                                  /* the default stream */
+    ra.tuning.kernel = LEC_KERNEL_AUTO;                /* all-zero tuning = the library's defaults; nothing is read from the environment */
     if (lec_rowstats(&ra) != LEC_OK) { fprintf(stderr, "lec_rowstats: %s\n", lec_last_error()); return 6; }
 
     lec_reduce_args rd;
@@ -83,6 +84,10 @@ int main(int argc, char** argv) {
     lec_rowstats_args bad = ra;
     bad.t_count = nt + 1;
     if (lec_rowstats(&bad) != LEC_ERR_ARG || strstr(lec_last_error(), "outside the cube") == NULL) { fprintf(stderr, "error path broken\n"); return 8; }
+
+    bad = ra;
+    bad.tuning.tile_t = -1;
+    if (lec_rowstats(&bad) != LEC_ERR_ARG || strstr(lec_last_error(), "tile_t") == NULL) { fprintf(stderr, "tuning validation broken\n"); return 9; }
 
     double* hs = (double*)malloc((size_t)nt * LEC_NSCALAR * sizeof(double));
     double* hl = (double*)malloc((size_t)nt * LEC_NLEVTAB * nl * sizeof(double));

@@ -1,4 +1,5 @@
-"""bench.py prints ONE JSON line with the keys the driver contract names (plus `roofline` and `cpu_baseline`)."""
+"""bench.py prints ONE JSON line with the keys the driver contract names (plus `roofline` and `cpu_baseline`), launches its own
+ranks for --gpus N, and refuses a --gpus it cannot honour."""
 import json
 import os
 import subprocess
@@ -9,13 +10,22 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--ny", "61", "--nx", "128", "--steps", "2", "--warmup", "1"]
+
+
+def _bench(extra, env=None, timeout=600):
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=e)
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    return r, lines
 
 
 def test_bench_json_contract():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--timesteps", "3", "--ny", "61", "--nx", "128", "--steps", "2", "--warmup", "1"],
-                       capture_output=True, text=True, timeout=300, cwd=ROOT)
+    r, lines = _bench(["--timesteps", "3", "--cpu-baseline", "quick"] + SMALL)
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
@@ -28,5 +38,43 @@ def test_bench_json_contract():
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and "traffic" in rf
+    ct = rf["conversion_terms"]          # BASELINE.json's target configuration rides in the same line
+    assert ct["achieved"] > 0 and abs(ct["frac"] - ct["achieved"] / 8000.0) < 1e-12 and ct["algorithmic_bytes_per_launch"] == 4 * 37 * 61 * 128 * 8 * 3
     cb = d["cpu_baseline"]
-    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["unit"] == "timesteps/s" and cb["sample"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["unit"] == "timesteps/s" and cb["sample"] and cb["host_cpu_count"] >= 1
+
+
+def test_bench_starts_its_own_ranks_and_counts_them():
+    """`python bench.py --gpus 2` with no launcher environment: the parent starts two rank processes (gloo rendezvous, both on
+    this box's one GPU -- RCCL itself needs a GPU per rank) and rank 0 reports n_gpus = 2, twice the global series."""
+    r, lines = _bench(["--gpus", "2", "--timesteps", "3", "--cpu-baseline", "none"] + SMALL, env={"LEC_DIST_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["world_size"] == 2 and d["config"]["timesteps_global"] == 6 and d["scaling"] == "weak"
+    assert d["config"]["backend"] == "gloo" and d["config"]["results_finite"] is True
+
+
+def test_bench_refuses_what_it_cannot_launch():
+    import torch
+    n = torch.cuda.device_count()
+    r, lines = _bench(["--gpus", str(n + 1), "--cpu-baseline", "none"] + SMALL)       # RCCL: one GPU per rank
+    assert r.returncode != 0 and not lines and "GPU" in r.stderr
+    r, lines = _bench(["--gpus", "2", "--cpu-baseline", "none"] + SMALL, env={"WORLD_SIZE": "1", "RANK": "0"})
+    assert r.returncode != 0 and not lines and "contradicts WORLD_SIZE" in r.stderr
+
+
+@pytest.mark.parametrize("extra", [[], ["--moving"]])
+def test_bench_strong_scaling_chunked_equals_resident(extra):
+    """--timesteps-global: the series is fixed and streamed through HBM in chunks with a one-step T halo; throughput is reported
+    with scaling "strong" and the chunked pass gives the resident pass's results (bit-identical records: same kernels)."""
+    size = [] if extra else ["--ny", "61", "--nx", "128"]
+    out = []
+    for chunk in ("3", "0"):
+        r, lines = _bench(["--timesteps-global", "8", "--chunk", chunk, "--cpu-baseline", "none", "--steps", "2", "--warmup", "1"] + size + extra)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out.append(json.loads(lines[0]))
+    a, b = out
+    assert a["scaling"] == b["scaling"] == "strong" and a["config"]["timesteps_global"] == 8 and a["n_gpus"] == 1
+    assert a["config"]["chunk"] == 3 and "chunk" not in b["config"] and a["config"]["results_finite"] and b["config"]["results_finite"]
+    assert a["value"] > 0 and a["config"]["wall_ms_per_step_incl_generation"] >= a["ms_per_step"]

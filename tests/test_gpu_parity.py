@@ -162,38 +162,99 @@ def test_synthetic_moving_variable_boxes():
     compare(res.scalars_dict(), res.levels_dict(), ref_s, ref_l, TOL, "moving variable boxes")
 
 
-@pytest.mark.parametrize("dtype", [np.float64, np.float32])
-def test_two_kernel_formulations_agree(monkeypatch, dtype):
-    """The default single-sweep kernel (sums about a shift, centred afterwards) and the two-sweep kernel
-    (deviation from the zonal mean, then products -- the reference's own order) are independent
-    formulations of the same row statistics."""
-    dom = synthetic_domain(4, 6, 14, 1000, seed=77, dtype=dtype)
-    limits = (dom.lon[3], dom.lon[-4], dom.lat[1], dom.lat[-2])
-    monkeypatch.setenv("LEC_KERNEL", "1")
-    a = run_fixed(dom, limits, keep_rows=True)
-    monkeypatch.setenv("LEC_KERNEL", "0")
-    b = run_fixed(dom, limits, keep_rows=True)
+def _rows_close(a, b, what, tol=1e-11):
     ra, rb = a.rows.cpu().numpy(), b.rows.cpu().numpy()
     for s in range(28):
         scale = np.max(np.abs(rb[..., s]))
-        assert np.max(np.abs(ra[..., s] - rb[..., s])) <= 1e-11 * max(scale, 1e-300), f"row statistic {s}"
-    assert torch.allclose(a.scalars, b.scalars, rtol=1e-10, atol=0)
+        assert np.max(np.abs(ra[..., s] - rb[..., s])) <= tol * max(scale, 1e-300), f"{what}: row statistic {s}"
+    assert torch.allclose(a.scalars, b.scalars, rtol=1e-10, atol=0), what
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_config5_shape_moving_boxes(dtype):
+    """BASELINE config 5's shape: a 0.25-degree track-extent crop (162 x 243), 37 levels, one 15 x 15 degree box (61 x 61
+    points) per time step along a track, dT/dt differentiated on the device over the series' time axis (what lec_moving does).
+    Engine (box-tile kernel) vs oracle; then the same series in shards and chunks: every piece is bit-identical to the whole."""
+    nt = 6
+    dom = synthetic_domain(nt, 37, 162, 243, seed=55, dtype=dtype, lat0=-57.75, lat1=-17.5, lon0=-80.25, lon1=-19.75, dt_s=3600.0)
+    clat = -37.5 + 12.0 * np.sin(2 * np.pi * np.arange(nt) / 5.0)
+    clon = -50.0 + 22.0 * np.cos(2 * np.pi * np.arange(nt) / 7.0)
+    limits = [(lo - 7.5, lo + 7.5, la - 7.5, la + 7.5) for la, lo in zip(clat, clon)]
+    eng = _engine(dom)
+    boxes = [eng.box_from_limits(*lim) for lim in limits]
+    assert all(b[1] - b[0] == 60 and b[3] - b[2] == 60 for b in boxes)
+    f = [_dev(a) for a in (dom.tair, dom.u, dom.v, dom.omega, dom.geopt)]
+    res = eng.compute(*f, boxes, time_s=dom.time_s, keep_rows=True)
+    torch.cuda.synchronize()
+    ref_s, ref_l = o.lec_moving(as_f64(dom), limits)
+    compare(res.scalars_dict(), res.levels_dict(), ref_s, ref_l, TOL, f"config-5 shape {np.dtype(dtype).name}")
+    # shards / chunks of the series (each sees the cube's time neighbours as its halo)
+    for a, b in ((0, 2), (2, 5), (5, 6)):
+        part = eng.compute(*f, boxes[a:b], time_s=dom.time_s, t_begin=a, t_count=b - a, keep_rows=True, per_step_boxes=True)
+        assert torch.equal(part.rows, res.rows[a:b]) and torch.equal(part.scalars, res.scalars[a:b]), (a, b)
+    # a chunk held as its own halo'd cube (what a time-sharded rank or a streamed chunk holds): same bits again
+    h0, h1 = 1, 5
+    g = [x[h0:h1].contiguous() for x in f]
+    part = eng.compute(*g, boxes[2:4], time_s=dom.time_s[h0:h1], t_begin=1, t_count=2, keep_rows=True)
+    assert torch.equal(part.rows, res.rows[2:4])
+    # the one-wave-per-row kernel is an independent formulation of the same records
+    sweep = eng.compute(*f, boxes, time_s=dom.time_s, keep_rows=True, tuning={"kernel": "row_sweep"})
+    _rows_close(res, sweep, "box tiles vs one wave per row, 61 x 61 boxes")
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_kernel_families_agree(dtype):
+    """Three independent formulations of the same row statistics, selected through ``lec_tuning.kernel`` (the
+    library reads no environment): the default single-sweep kernels (sums about a shift, lanes along longitude),
+    the two-sweep kernel (deviation from the zonal mean, then products -- the reference's own order) and the
+    box-tile kernel (one lane per latitude row, serial sums over longitude)."""
+    dom = synthetic_domain(4, 6, 14, 1000, seed=77, dtype=dtype)
+    limits = (dom.lon[3], dom.lon[-4], dom.lat[1], dom.lat[-2])
+    a = run_fixed(dom, limits, keep_rows=True)
+    b = run_fixed(dom, limits, keep_rows=True, tuning={"kernel": "two_sweep"})
+    c = run_fixed(dom, limits, keep_rows=True, tuning={"kernel": "box_tile"})
+    d = run_fixed(dom, limits, keep_rows=True, tuning={"kernel": "row_sweep", "order": "memory"})
+    _rows_close(a, b, "default vs two-sweep")
+    _rows_close(c, b, "box tiles vs two-sweep")
+    assert torch.equal(a.rows, d.rows) and torch.equal(a.scalars, d.scalars)     # block order is speed only
+
+
+@pytest.mark.parametrize("ny,nx,nonuni,dtype", [
+    (70, 23, False, np.float64),     # two row groups (the second one partial), two strips
+    (9, 16, False, np.float64),      # exactly one strip
+    (12, 17, False, np.float32),     # one point into the second strip
+    (130, 50, True, np.float64),     # three row groups, non-uniform longitudes
+    (5, 2, False, np.float64),       # the smallest row
+])
+def test_box_tile_kernel_shapes(ny, nx, nonuni, dtype):
+    """The box-tile kernel on boxes that exercise partial strips (16 columns) and partial row groups (64 rows),
+    with and without Q / a dT/dt cube, against the oracle and the one-wave-per-row kernel."""
+    dom = synthetic_domain(3, 4, ny + 3, nx + 4, seed=ny * nx, dtype=dtype, nonuniform_lon=nonuni)
+    limits = (dom.lon[1], dom.lon[nx], dom.lat[2], dom.lat[ny + 1])
+    res = run_fixed(dom, limits, tuning={"kernel": "box_tile"}, keep_rows=True)
+    ref_s, ref_l = o.lec_fixed(as_f64(o.crop_domain(dom, *limits)), *limits)
+    compare(res.scalars_dict(), res.levels_dict(), ref_s, ref_l, TOL, f"box tiles {ny}x{nx}")
+    sweep = run_fixed(dom, limits, tuning={"kernel": "row_sweep"}, keep_rows=True)
+    _rows_close(res, sweep, "box tiles vs one wave per row")
+    eng = _engine(dom)
+    box = eng.box_from_limits(*limits)
+    noq = [eng.compute(_dev(dom.tair), _dev(dom.u), _dev(dom.v), _dev(dom.omega), None, [box], with_q=False,
+                       keep_rows=True, tuning={"kernel": k}) for k in ("box_tile", "row_sweep")]
+    _rows_close(noq[0], noq[1], "no-Q box tiles vs one wave per row")
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("blk", ["212", "222", "122", "211", "121", "112"])
-def test_row_block_kernel_is_bit_identical_to_one_wave_per_row(monkeypatch, dtype, blk):
+def test_row_block_kernel_is_bit_identical_to_one_wave_per_row(dtype, blk):
     """The row-block kernel (default for all terms on a fixed box: block mates exchange T through LDS) must give
     the very same row records as the one-wave-per-row kernel; odd extents exercise partial blocks, the shard
     exercises halo time steps on both sides."""
     dom = synthetic_domain(7, 5, 13, 600, seed=21, dtype=dtype)
     limits = (dom.lon[3], dom.lon[-4], dom.lat[1], dom.lat[-2])
-    monkeypatch.setenv("LEC_F32VEC", "2")       # the row-block kernel walks float2 vectors; same lane-to-element map for both
+    # the row-block kernel walks float2 vectors: f32_vec = 2 gives the one-wave-per-row kernel the same lane-to-element map
     for kw in ({}, {"t_begin": 1, "t_count": 5}):
-        monkeypatch.setenv("LEC_BLK", "0")
-        a = run_fixed(dom, limits, keep_rows=True, **kw)
-        monkeypatch.setenv("LEC_BLK", blk)
-        b = run_fixed(dom, limits, keep_rows=True, **kw)
+        a = run_fixed(dom, limits, keep_rows=True, tuning={"kernel": "row_sweep", "f32_vec": 2}, **kw)
+        b = run_fixed(dom, limits, keep_rows=True, tuning={"kernel": "row_block", "block_shape": int(blk)}, **kw)
         assert torch.equal(a.rows, b.rows), f"rows differ for block shape {blk} {kw}"
         assert torch.equal(a.scalars, b.scalars)
 
@@ -278,18 +339,28 @@ def test_nan_at_top_level_drops_that_level_for_every_time_step():
 # ---------------------------------------------------------------------------------------------
 # argument checking mirrors the reference's error behaviour
 # ---------------------------------------------------------------------------------------------
-def test_long_rows_and_the_two_sweep_limit(monkeypatch):
+def test_long_rows_and_the_two_sweep_limit():
     """The default kernel walks a row in trips, so long rows just take more trips; the two-sweep cross-check
     kernel holds the row in registers and refuses rows beyond lec_max_row() (no silent truncation)."""
     from lorenzcycletoolkit_amd import _lib
     dom = synthetic_domain(2, 3, 4, 6000, seed=1)
     limits = (dom.lon[1], dom.lon[-2], dom.lat[0], dom.lat[-1])
-    monkeypatch.setenv("LEC_KERNEL", "1")
     check_fixed(dom, limits, what="6000-point rows")
-    monkeypatch.setenv("LEC_KERNEL", "0")
-    assert _lib.load().lec_max_row(_lib.LEC_F64, 1) < 5000
+    assert _lib.load().lec_max_row(_lib.LEC_F64, 1, _lib.KERNEL_TWO_SWEEP) < 5000
+    assert _lib.load().lec_max_row(_lib.LEC_F64, 1, _lib.KERNEL_AUTO) >= 6000
     with pytest.raises(_lib.LecLibraryError, match="longer than lec_max_row"):
-        run_fixed(dom, limits)
+        run_fixed(dom, limits, tuning={"kernel": "two_sweep"})
+
+
+def test_tuning_is_validated():
+    """Bad tuning values are refused with LEC_ERR_ARG (ValueError), never silently clamped."""
+    dom = synthetic_domain(3, 4, 8, 64, seed=2)
+    limits = (dom.lon[1], dom.lon[-2], dom.lat[1], dom.lat[-2])
+    for bad in ({"tile_t": -1}, {"tile_j": -3}, {"block_shape": 111}, {"block_shape": 312}, {"f32_vec": 3}):
+        with pytest.raises(ValueError):
+            run_fixed(dom, limits, tuning=bad)
+    with pytest.raises(ValueError):
+        run_fixed(dom, limits, tuning={"kernel": "fastest"})
 
 
 def test_errors():

@@ -90,12 +90,13 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert getattr(lib, name) is not None
     assert lib.lec_version() == _lib.LEC_ABI_VERSION
-    assert lib.lec_max_row(_lib.LEC_F64, 1) >= 1440 and lib.lec_max_row(_lib.LEC_F32, 1) >= 1440
+    assert lib.lec_max_row(_lib.LEC_F64, 1, 0) >= 1440 and lib.lec_max_row(_lib.LEC_F32, 1, _lib.KERNEL_TWO_SWEEP) >= 1440
 
 
 def test_struct_sizes_match_header_layout():
-    # 6 pointers + 12 int32 + 7 pointers + 2 pointers ; 1 pointer + 4 int32 + 4 pointers + double + 2 int32 + 7 pointers
-    assert ctypes.sizeof(_lib.RowstatsArgs) == 6 * 8 + 12 * 4 + 9 * 8
+    # 6 pointers + 14 int32 + 7 pointers + 2 pointers + lec_tuning (8 int32) ; 1 pointer + 4 int32 + 4 pointers + double + 2 int32 + 7 pointers
+    assert ctypes.sizeof(_lib.Tuning) == 8 * 4
+    assert ctypes.sizeof(_lib.RowstatsArgs) == 6 * 8 + 14 * 4 + 9 * 8 + 8 * 4
     assert ctypes.sizeof(_lib.ReduceArgs) == 8 + 4 * 4 + 4 * 8 + 8 + 2 * 4 + 8 + 6 * 8
     # lec_ingest_args: pointer + 2 int32 + 4 int32 + 3 int32 (+4 padding) + 3 pointers + 2 int32 + 4 doubles + 2 int32 + 2 pointers
     assert ctypes.sizeof(_lib.IngestArgs) == 8 + 9 * 4 + 4 + 3 * 8 + 2 * 4 + 4 * 8 + 2 * 4 + 2 * 8
