@@ -77,6 +77,28 @@ __global__ void __launch_bounds__(64) lec_area_means_kernel(const RedParams p) {
     }
 }
 
+// BAz's bottom-top term before the area mean, one latitude row:  [2 w'T'] T* + [w] T*^2   (boundary_terms.py:165-168)
+__device__ __forceinline__ double baz3_row(const RedParams& p, const double* am_t, int tl, int k, int jb) {
+    const double* r = p.rows + ((size_t)(tl * p.nl + k) * p.nyb_max + jb) * LEC_NSTAT;
+    const double Ts = r[LEC_S_MT] - am_t[8 * k + 0];
+    return (2 * r[LEC_S_WT]) * Ts + r[LEC_S_MW] * (Ts * Ts);
+}
+
+// The reference repairs THIS term per latitude, before the area mean and before the division by sigma
+// (term3 = self._handle_nans(term3) on a [time, level, lat] array, boundary_terms.py:169): a NaN at (level, lat) is replaced by
+// the linear interpolation in p between the nearest valid levels of the same latitude (interior gaps only, no
+// extrapolation); what stays NaN makes the level's area mean NaN, and the level is then dropped (lec_vertical_kernel).
+__device__ double baz3_repaired(const RedParams& p, const double* am_t, int tl, int k, int jb) {
+    int lo = k - 1, hi = k + 1;
+    double yl = 0.0, yr = 0.0;
+    for (; lo >= 0; --lo) { yl = baz3_row(p, am_t, tl, lo, jb); if (!isnan(yl)) break; }
+    for (; hi < p.nl; ++hi) { yr = baz3_row(p, am_t, tl, hi, jb); if (!isnan(yr)) break; }
+    if (lo < 0 || hi >= p.nl) return nan("");
+    const double xl = p.levtab2[4 * lo], xr = p.levtab2[4 * hi];
+    const double slope = (yr - yl) / (xr - xl);
+    return slope * (p.levtab2[4 * k] - xl) + yl;
+}
+
 // grid (nl, t_count), block 64
 __global__ void __launch_bounds__(64) lec_level_terms_kernel(const RedParams p) {
     const int k = blockIdx.x, tl = blockIdx.y, lane = threadIdx.x;
@@ -168,7 +190,9 @@ __global__ void __launch_bounds__(64) lec_level_terms_kernel(const RedParams p) 
         }
 
         // bottom-top pieces, area means (boundary_terms.py:165-176,214-221,264-271,312-318,358-363,401-413)
-        acc[V_B3 + 0] += cw * ((2 * sWT) * Ts + mW * (Ts * Ts));
+        double x3 = (2 * sWT) * Ts + mW * (Ts * Ts);
+        if (isnan(x3)) x3 = baz3_repaired(p, am, tl, k, jb);        // per latitude, before the area mean (the reference's order)
+        acc[V_B3 + 0] += cw * x3;
         acc[V_B3 + 1] += cw * r[LEC_S_WTT];
         acc[V_B3 + 2] += cw * r[LEC_S_KW];
         acc[V_B3 + 3] += cw * r[LEC_S_EW];
@@ -214,6 +238,8 @@ enum {
 
 // Builds function `f` of level for time step `tl` into row[0..nl) and applies the interpolation half of
 // _handle_nans (energy_contents.py:190-208): linear in p across interior gaps, no extrapolation.
+// BAz's bottom-top term (F_B3) is the exception: the reference interpolates it per latitude before the area mean
+// (lec_level_terms_kernel has done that) and only DROPS the levels that are still NaN (boundary_terms.py:169-176).
 // Returns the number of NaN levels found before the repair.
 __device__ int build_level_function(const RedParams& p, int tl, int f, double* row) {
     const int nl = p.nl;
@@ -240,7 +266,7 @@ __device__ int build_level_function(const RedParams& p, int tl, int f, double* r
         row[k] = x;
         nnan += isnan(x) ? 1 : 0;
     }
-    if (nnan) {
+    if (nnan && f != F_B3) {
         int last_ok = -1;
         for (int k = 0; k < nl; ++k) {
             if (!isnan(row[k])) { last_ok = k; continue; }

@@ -112,6 +112,19 @@ def interpolate_and_drop_nan_levels(f: np.ndarray, p: np.ndarray):
     return f, p
 
 
+def handle_nans_table(f: np.ndarray, p: np.ndarray) -> np.ndarray:
+    """What ``_handle_nans`` leaves of a [time, level] function, on the full level axis: repaired values where it
+    interpolated, NaN where it dropped the level.  The reference saves its main per-level tables AFTER ``_handle_nans``
+    (e.g. energy_contents.py:104-105, conversion_terms.py:131-132); a dropped level is simply missing from the row it
+    appends there, which this fixed-width form shows as NaN."""
+    fc, pc = interpolate_and_drop_nan_levels(f, p)
+    if len(pc) == len(p):
+        return fc
+    out = np.full(np.shape(f), np.nan, dtype=fc.dtype)
+    out[:, np.isin(p, pc)] = fc
+    return out
+
+
 # --------------------------------------------------------------------------------------
 # Box pre-reduction  (box_data.py, calc_averages.py, thermodynamics.py)
 # --------------------------------------------------------------------------------------
@@ -261,6 +274,8 @@ def energy_contents(b: Box):
         "Kz": _int_p(lv["Kz"], b.level) / (2 * G),
         "Ke": _int_p(lv["Ke"], b.level) / (2 * G),
     }
+    for name in ("Az", "Ae", "Kz", "Ke"):        # saved after _handle_nans (energy_contents.py:104-105 ...)
+        lv[name] = handle_nans_table(lv[name], b.level)
     return out, lv
 
 
@@ -312,6 +327,8 @@ def conversion_terms(b: Box):
         "Ck": _int_p(lv["Ck"], b.level) / G,
         "Ce": _int_p(lv["Ce"], b.level),
     }
+    for name in ("Cz", "Ca", "Ck", "Ce"):        # the sums are saved after _handle_nans, the pieces before (conversion_terms.py:117-132 ...)
+        lv[name] = handle_nans_table(lv[name], b.level)
     return out, lv
 
 
@@ -397,6 +414,8 @@ def generation_terms(b: Box):
     lv["Gz"] = area_average(f["Q_AE"] * f["tair_AE"], b.rlats, b.coslats) / (CP_D * s)
     lv["Ge"] = area_average(f["Q_ZE"] * f["tair_ZE"], b.rlats, b.coslats, b.xlength, b.rlons) / (CP_D * s)
     out = {"Gz": _int_p(lv["Gz"], b.level), "Ge": _int_p(lv["Ge"], b.level)}
+    for name in ("Gz", "Ge"):                    # generation_and_dissipation_terms.py:127-128,144-145
+        lv[name] = handle_nans_table(lv[name], b.level)
     return out, lv
 
 

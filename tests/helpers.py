@@ -40,8 +40,16 @@ def as_f64(dom: o.Domain) -> o.Domain:
 
 
 def scale_err(a, r):
+    """max |a - r| relative to the scale of r; NaNs must sit at the same places (else inf)."""
     a = np.asarray(a, dtype=np.float64)
     r = np.asarray(r, dtype=np.float64)
+    na, nr = np.isnan(a), np.isnan(r)
+    if na.any() or nr.any():
+        if not np.array_equal(na, nr):
+            return float("inf")
+        a, r = a[~na], r[~nr]
+        if a.size == 0:
+            return 0.0
     den = np.max(np.abs(r))
     return float(np.max(np.abs(a - r)) / den) if den > 0 else float(np.max(np.abs(a - r)))
 

@@ -311,6 +311,65 @@ def test_nan_levels_are_repaired_like_handle_nans():
         assert scale_err(got[name], ref_s[name]) <= 1e-8, name
 
 
+def test_static_stability_clamp():
+    """sigma = {[g T / cp - (p g / Rd) dT/dp]} is clamped to >= 0.03 (thermodynamics.py:62-70; the reference says this is
+    what keeps Az / Ca stable).  A block of levels with T ~ p^0.35 (steeper than the adiabat p^(2/7)) has sigma < 0 there:
+    the clamp decides Az, Ae, Ca, BAz, BAe, Gz, Ge on those levels."""
+    dom = synthetic_domain(4, 13, 12, 96, seed=31)
+    for k in range(4, 9):
+        dom.tair[:, k] = (300.0 * (dom.level[k] / 1e5) ** 0.35 + (dom.tair[:, k] - dom.tair[:, k].mean())).astype(dom.tair.dtype)
+    limits = (dom.lon[1], dom.lon[-2], dom.lat[1], dom.lat[-2])
+    box = o.make_box(dom, *limits)
+    clamped = box.sigma_AA == 0.03
+    assert clamped.any() and not clamped.all(), "the test data must drive some (time, level) onto the clamp and leave others free"
+    check_fixed(dom, limits, what="sigma clamp")
+
+
+@pytest.mark.parametrize("case", ["bottom_T_and_omega", "interior_omega_rows", "repair_reaches_the_boundary", "interior_T_patch",
+                                  "column_to_the_ground"])
+def test_nans_in_T_and_omega_follow_handle_nans(case):
+    """Below-ground style NaNs in T and omega (not only in the winds): every one of the 16 terms and every level table against
+    the oracle.  `interior_omega_rows` is the case where the reference's ORDER matters: BAz's bottom-top term is repaired per
+    latitude before the area mean and divided by sigma afterwards (boundary_terms.py:165-176)."""
+    dom = synthetic_domain(5, 8, 12, 64, seed=41)
+    nl = dom.level.size
+    if case == "bottom_T_and_omega":          # a patch of the lowest level at two time steps: nothing below to interpolate from -> level dropped
+        dom.tair[1:3, nl - 1, 3:6, 10:20] = np.nan
+        dom.omega[1:3, nl - 1, 3:6, 10:20] = np.nan
+    elif case == "interior_omega_rows":       # omega only, an interior level, some latitude rows, one time step
+        dom.omega[2, 4, 4:7, 5:9] = np.nan
+    elif case == "repair_reaches_the_boundary":
+        # the lowest level is NaN at some latitudes (-> dropped), the level above it at OTHER latitudes: there the per-latitude
+        # repair interpolates between its neighbours (the lowest level is valid at those latitudes) and the repaired level becomes
+        # the bottom of BAz's bottom-top difference -- repairing after the area mean gives another BAz (20 % off in that term)
+        dom.omega[2, nl - 2, 4:7, 5:9] = np.nan
+        dom.omega[2, nl - 1, 8:10, 20:24] = np.nan
+    elif case == "interior_T_patch":          # T at an interior level: [T] and {[T]} are NaN there, the level is interpolated
+        dom.tair[3, 3, 5, 30] = np.nan
+    else:                                     # a column that is NaN from level 5 to the ground at a few points, every time step
+        for f in (dom.tair, dom.omega, dom.u, dom.v, dom.geopt):
+            f[:, 5:, 2:4, 40:44] = np.nan
+    limits = (dom.lon[1], dom.lon[-2], dom.lat[1], dom.lat[-2])
+    res = run_fixed(dom, limits)
+    assert int(res.nanflag.max()) > 0
+    with np.errstate(invalid="ignore"):
+        ref_s, ref_l = o.lec_fixed(dom, *limits)
+    worst = compare(res.scalars_dict(), res.levels_dict(), ref_s, ref_l, 1e-9, f"NaN case {case}")
+    got = res.scalars_dict()
+    assert all(np.isfinite(got[k]).all() for k in SCALARS), "every integrated term survives: levels were repaired or dropped"
+    print(case, max(worst.values()))
+
+
+def test_polar_rows_off_the_pole():
+    """A latitude axis that comes within 1/8 degree of the pole without touching it: [u] / cos(phi), tan(phi) and
+    dx ~ cos(phi) are large but finite in the reference, and the engine must follow them."""
+    dom = synthetic_domain(3, 5, 64, 128, seed=51, lat0=-89.875, lat1=-74.125, lon0=-180.0, lon1=-148.25)
+    limits = (dom.lon[0], dom.lon[-1], dom.lat[0], dom.lat[-1])
+    check_fixed(dom, limits, tol=1e-8, what="polar rows")
+    domn = synthetic_domain(3, 5, 64, 128, seed=52, lat0=74.125, lat1=89.875, lon0=100.0, lon1=131.75)
+    check_fixed(domn, (domn.lon[0], domn.lon[-1], domn.lat[0], domn.lat[-1]), tol=1e-8, what="polar rows north")
+
+
 def test_nan_at_top_level_drops_that_level_for_every_time_step():
     """xarray's dropna(dim=level) works on the whole [time, level] array: a top level that is NaN at ONE time
     step (nothing above it to interpolate from) leaves the pressure integrals of ALL time steps
