@@ -184,11 +184,13 @@ typedef struct lec_reduce_args {
  * cropped to the analysis domain, in SI units.
  *
  *   value = decode(src[t][kmap[k]][jmap[j]][imap[i]])            source element, byte-swapped if asked
- *   packed (has_packing):  v = (double)value * scale_factor + add_offset   (product rounded, then the sum: what
- *                          the reference's xarray decode does on float64 data), arithmetic in fp64
- *   not packed:            v = value, arithmetic in the source's own precision (the reference keeps file dtype)
  *   fill:                  value == fill_value (compared before scaling) -> NaN
- *   out = v * unit_scale   rounded to out_dtype
+ *   decode_dtype LEC_F64:  v = (double)value; packed: v = v * scale_factor; v = v + add_offset      (two roundings, fp64)
+ *   decode_dtype LEC_F32:  v = (float)value;  packed: v = (float)((double)v * scale_factor); v = (float)((double)v + add_offset)
+ *                          -- the reference's pinned xarray 2024.2.0 decodes int16 data to float32 when the variable has a
+ *                          fill value or no add_offset, and keeps float32 data float32 (float64 attributes: each operation
+ *                          is computed in fp64 and rounded to float32); the caller picks the dtype by those rules
+ *   out = v * unit_scale   in decode_dtype, stored as out_dtype
  */
 typedef struct lec_ingest_args {
     const void* src_d;          /* device copy of the raw variable bytes for nt time steps */
@@ -201,8 +203,8 @@ typedef struct lec_ingest_args {
     const int32_t* imap_d;      /* [nx] output longitude -> source longitude */
     int32_t has_packing, has_fill;
     double scale_factor, add_offset, fill_value, unit_scale;
-    int32_t out_dtype;          /* LEC_F64 or LEC_F32 */
-    int32_t reserved0;
+    int32_t out_dtype;          /* LEC_F64 or LEC_F32: storage of the output cube (>= decode_dtype; widening is exact) */
+    int32_t decode_dtype;       /* LEC_F64 or LEC_F32: the precision the reference's decode gives this variable (see below) */
     void* out_d;                /* [nt][nl][ny][nx] */
     void* stream;
 } lec_ingest_args;

@@ -72,7 +72,7 @@ class IngestArgs(C.Structure):
         ("kmap_d", C.c_void_p), ("jmap_d", C.c_void_p), ("imap_d", C.c_void_p),
         ("has_packing", C.c_int32), ("has_fill", C.c_int32),
         ("scale_factor", C.c_double), ("add_offset", C.c_double), ("fill_value", C.c_double), ("unit_scale", C.c_double),
-        ("out_dtype", C.c_int32), ("reserved0", C.c_int32),
+        ("out_dtype", C.c_int32), ("decode_dtype", C.c_int32),
         ("out_d", C.c_void_p), ("stream", C.c_void_p),
     ]
 

@@ -18,7 +18,7 @@ struct IngestParams {
     const void* src; void* out;
     int nt, nl_in, ny_in, nx_in, nl, ny, nx;
     const int* kmap; const int* jmap; const int* imap;
-    int swap, has_packing, has_fill;
+    int swap, has_packing, has_fill, decode_f32;
     double scale, offset, fill, unit;
 };
 
@@ -52,13 +52,16 @@ __global__ void __launch_bounds__(256) lec_ingest_kernel(const IngestParams p) {
         const TSRC raw = load_elem(src + p.imap[i], swap);
         const bool is_fill = p.has_fill && ((double)raw == p.fill);
         TOUT o;
-        if (p.has_packing || sizeof(TSRC) == 8 || sizeof(TSRC) == 2) {
+        if (!p.decode_f32) {
             double v = (double)raw;
             if (p.has_packing) { v = v * p.scale; v = v + p.offset; }
             v = v * p.unit;
             o = (TOUT)v;
-        } else {                                     // unpacked float32 source: the reference stays in float32
+        } else {
+            // the reference's decode in float32 (xarray 2024.2.0 on NumPy 2: float32 data, float64 attributes -- every
+            // operation is computed in float64 and rounded back to float32 by the in-place store)
             float v = (float)raw;
+            if (p.has_packing) { v = (float)((double)v * p.scale); v = (float)((double)v + p.offset); }
             v = v * (float)p.unit;
             o = (TOUT)v;
         }
@@ -88,7 +91,9 @@ extern "C" int lec_ingest(const lec_ingest_args* a) {
     p.src = a->src_d; p.out = a->out_d;
     p.nt = a->nt; p.nl_in = a->nl_in; p.ny_in = a->ny_in; p.nx_in = a->nx_in; p.nl = a->nl; p.ny = a->ny; p.nx = a->nx;
     p.kmap = a->kmap_d; p.jmap = a->jmap_d; p.imap = a->imap_d;
-    p.swap = a->swap_bytes; p.has_packing = a->has_packing; p.has_fill = a->has_fill;
+    if (a->decode_dtype != LEC_F64 && a->decode_dtype != LEC_F32) return lec_set_error(LEC_ERR_ARG, "lec_ingest: decode_dtype must be LEC_F64 or LEC_F32");
+    if (a->decode_dtype == LEC_F32 && a->src_dtype == LEC_F64) return lec_set_error(LEC_ERR_ARG, "lec_ingest: float64 data do not decode to float32");
+    p.swap = a->swap_bytes; p.has_packing = a->has_packing; p.has_fill = a->has_fill; p.decode_f32 = a->decode_dtype == LEC_F32;
     p.scale = a->scale_factor; p.offset = a->add_offset; p.fill = a->fill_value; p.unit = a->unit_scale;
     hipStream_t st = (hipStream_t)a->stream;
     if (a->src_dtype == LEC_I16) launch<int16_t>(p, a->out_dtype, rows, st);

@@ -226,34 +226,75 @@ def _open_nc(path: str, variable_list_df: pd.DataFrame, mmap: bool):
 
 
 def _packing(v):
-    """CF packing attributes of a variable: (scale_factor, add_offset, fill value) with None for absent ones."""
+    """CF packing attributes of a variable: (scale_factor, add_offset, fill value) with None for absent ones.
+    ``_FillValue`` and ``missing_value`` both mark missing data (xarray's CFMaskCoder masks either); files that give two
+    different values are refused rather than half-handled."""
     scale, offset = v.attr("scale_factor"), v.attr("add_offset")
-    fill = v.attr("_FillValue")
-    if fill is None:
-        fill = v.attr("missing_value")
+    fill, miss = v.attr("_FillValue"), v.attr("missing_value")
+    if fill is not None and miss is not None and float(fill) != float(miss) and not (np.isnan(float(fill)) or np.isnan(float(miss))):
+        raise ValueError("variable has different _FillValue and missing_value attributes; give it one fill value")
+    if fill is None or (isinstance(fill, float) and np.isnan(fill)):
+        fill = miss
+    if fill is not None and np.isnan(float(fill)):
+        fill = None                                  # a NaN fill value masks nothing that is not NaN already
     return (None if scale is None else float(scale), None if offset is None else float(offset),
             None if fill is None else float(fill))
 
 
+def decode_dtypes(src_dtype, scale, offset, fill):
+    """(dtype after masking, dtype after unpacking) of a file variable, as the reference's pinned xarray 2024.2.0 decodes it
+    (requirements.txt:88; the data reach BoxData in exactly this dtype and the reference computes in it):
+
+    * CFMaskCoder.decode -> dtypes.maybe_promote: integers become float32 (itemsize <= 2) or float64 when a fill value is
+      present, floats keep their dtype;
+    * then CFScaleOffsetCoder.decode -> _choose_float_dtype(masked dtype, has add_offset): float32 (and float16) stay
+      float32; integers of <= 2 bytes WITHOUT an add_offset become float32; everything else float64.
+
+    So int16 data with scale_factor + add_offset + _FillValue (ERA5) are float32 in the reference; without a fill value they
+    are float64; a scale_factor alone gives float32."""
+    d = np.dtype(src_dtype).newbyteorder("=")
+    if fill is not None and d.kind in "iu":
+        d = np.dtype(np.float32 if d.itemsize <= 2 else np.float64)
+    masked = d
+    if scale is not None or offset is not None:
+        if d.kind == "f" and d.itemsize <= 4:
+            d = np.dtype(np.float32)
+        elif d.kind in "iu" and d.itemsize <= 2 and offset is None:
+            d = np.dtype(np.float32)
+        else:
+            d = np.dtype(np.float64)
+    elif d.kind in "iu":
+        d = np.dtype(np.float32 if d.itemsize <= 2 else np.float64)      # the engine needs floating-point cubes
+    return masked, d
+
+
+def decode_values(raw: np.ndarray, scale, offset, fill) -> np.ndarray:
+    """Native-byte-order file values -> decoded values, in the dtype and with the roundings of the reference's decode
+    (see decode_dtypes): mask first, then ``data = data.astype(dtype); data *= scale_factor; data += add_offset`` with the
+    attributes as float64 scalars (NumPy >= 2: a float32 array times a float64 scalar is computed in float64 and rounded
+    back to float32 by the in-place store, once per operation)."""
+    masked, out = decode_dtypes(raw.dtype, scale, offset, fill)
+    a = raw
+    if fill is not None:
+        a = np.where(raw == fill, np.nan, raw.astype(masked)) if masked.kind == "f" else raw
+    if scale is not None or offset is not None:
+        a = a.astype(out, copy=True)
+        if scale is not None:
+            a *= np.float64(scale)
+        if offset is not None:
+            a += np.float64(offset)
+    return np.asarray(a, dtype=out)
+
+
 def open_dataset(path: str, variable_list_df: pd.DataFrame) -> LECDataset:
-    """Host-side decode of the whole file: raw values equal to the fill value become NaN, CF-packed variables
-    decode to float64 as ``raw * scale_factor + add_offset`` (xarray 2024.2 decodes int16 data that has an
-    add_offset to float64), other variables keep the file's dtype."""
+    """Host-side decode of the whole file with the semantics of ``xr.open_dataset`` (decode_values)."""
     nc, names, geo_role, lat, lon, lev, time, level_units, want = _open_nc(path, variable_list_df, mmap=False)
     variables = {}
     for role in FIELD_ROLES + (geo_role,):
         v = nc.variables[names[role]]
         raw = v.values()
         scale, offset, fill = _packing(v)
-        a = raw
-        if scale is not None or offset is not None:
-            a = raw.astype(np.float64)
-            if scale is not None:
-                a *= scale
-            if offset is not None:
-                a += offset
-        if fill is not None and np.issubdtype(a.dtype, np.floating):
-            a = np.where(raw == fill, np.nan, a)
+        a = decode_values(raw, scale, offset, fill)
         if set(v.dimensions) != set(want):
             raise ValueError(f"{names[role]} has dimensions {v.dimensions}, expected {want}")
         variables[names[role]] = np.transpose(a, [v.dimensions.index(d) for d in want])
@@ -441,19 +482,10 @@ def gather_on_host(var: RawVariable, plan: IngestPlan) -> np.ndarray:
     """The analysis-domain cube of one raw variable, decoded -- what lec_ingest does on the GPU, one time step at a time
     on the host, so that only the selected time steps and the cropped domain are ever read from a large file."""
     out = None
-    packed = var.scale_factor is not None or var.add_offset is not None
     for n, ft in enumerate(plan.tsel):
         raw = np.asarray(var.data[int(ft)])[plan.kmap][:, plan.jmap][:, :, plan.imap]
         raw = raw.astype(raw.dtype.newbyteorder("="))
-        a = raw
-        if packed:
-            a = raw.astype(np.float64)
-            if var.scale_factor is not None:
-                a *= var.scale_factor
-            if var.add_offset is not None:
-                a += var.add_offset
-        if var.fill_value is not None and np.issubdtype(a.dtype, np.floating):
-            a = np.where(raw == var.fill_value, np.nan, a)
+        a = decode_values(raw, var.scale_factor, var.add_offset, var.fill_value)
         if out is None:
             out = np.empty((len(plan.tsel),) + a.shape, dtype=a.dtype)
         out[n] = a

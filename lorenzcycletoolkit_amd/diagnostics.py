@@ -68,11 +68,14 @@ def box_positions(zeta, hgt, wspd, lat_deg, lon_deg, limits, track_row=None, use
         zval = float(zeta[j0, i0])
     else:
         zval = float(np.nanmin(z) if south else np.nanmax(z))
-    hval = float(track_row["min_hgt_850"]) if have("min_hgt_850") else float(h.min())
-    wval = float(track_row["max_wind_850"]) if have("max_wind_850") else float(w.max())
+    # xarray's .min() / .max() skip NaN (below-ground points at 850 hPa): so do these, values and positions alike
+    hval = float(track_row["min_hgt_850"]) if have("min_hgt_850") else float(np.nanmin(h))
+    wval = float(track_row["max_wind_850"]) if have("max_wind_850") else float(np.nanmax(w))
 
     def where(a, use_min):
-        idx = np.unravel_index(a.argmin() if use_min else a.argmax(), a.shape)
+        if np.isnan(a).all():
+            return float("nan"), float("nan")
+        idx = np.unravel_index(np.nanargmin(a) if use_min else np.nanargmax(a), a.shape)
         return float(lat[jj][idx[0]]), float(lon[ii][idx[1]])
 
     zlat, zlon = where(z, lat[jj].min() < 0)
@@ -89,12 +92,15 @@ def track_diagnostics(data, variable_list_df, limits_per_step, track=None, use_t
     """All time steps: u, v, geopotential height at 85000 Pa -> list of position dicts."""
     k850 = int(np.flatnonzero(data.level == 85000.0)[0])
     name = lambda role: str(variable_list_df.loc[role]["Variable"])
-    u = data.variables[name("Eastward Wind Component")][:, k850]
-    v = data.variables[name("Northward Wind Component")][:, k850]
-    if "Geopotential Height" in variable_list_df.index:
-        hgt = data.variables[name("Geopotential Height")][:, k850].astype(np.float64)
+    if hasattr(data, "level_slice"):          # streamed data set: three level slices decoded from the mapped file
+        get = lambda role: data.level_slice(role, 85000.0)
     else:
-        hgt = data.variables[name("Geopotential")][:, k850].astype(np.float64) / G       # -> gpm
+        get = lambda role: data.variables[name(role)][:, k850]
+    u, v = get("Eastward Wind Component"), get("Northward Wind Component")
+    if "Geopotential Height" in variable_list_df.index:
+        hgt = get("Geopotential Height").astype(np.float64)
+    else:
+        hgt = get("Geopotential").astype(np.float64) / G       # -> gpm
     zeta = vorticity(u, v, data.lat, data.lon)
     wspd = wind_speed(u, v)
     out = []

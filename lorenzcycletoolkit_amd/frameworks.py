@@ -64,19 +64,21 @@ class BoxData:
         dev = _device(args)
         self.engine = LECEngine(data.lat, data.lon, data.level, device=dev)
         limits = boxes_limits if boxes_limits is not None else [(western_limit, eastern_limit, southern_limit, northern_limit)]
+        self.per_step_boxes = boxes_limits is not None
         self.boxes = [self.engine.box_from_limits(*lim) for lim in limits]
         iw, ie, js, jn = self.boxes[0]
         self.western_limit, self.eastern_limit = float(data.lon[iw]), float(data.lon[ie])
         self.southern_limit, self.northern_limit = float(data.lat[js]), float(data.lat[jn])
 
-        from .ingest import StreamedDataset, lec_fixed_streamed
+        from .ingest import StreamedDataset, lec_streamed
         if isinstance(data, StreamedDataset):
-            # device ingest: the file bytes are streamed, decoded, sorted and cropped on the GPU (ingest.py)
-            if boxes_limits is not None or dTdt is not None:
-                raise NotImplementedError("the device ingest serves the fixed framework")
+            # device ingest: the file bytes are streamed, decoded, sorted and cropped on the GPU (ingest.py); in the moving
+            # framework dT/dt is differentiated on the device over the (track-selected) time axis
+            if dTdt is not None:
+                raise NotImplementedError("the device ingest differentiates T in time itself; do not pass a dTdt cube")
             self.ingest_stats = {}
-            self.result: LECResult = lec_fixed_streamed(data.raw, data.plan, variable_list_df, limits[0], device=dev,
-                                                        chunk_steps=data.chunk_steps, stats=self.ingest_stats)
+            self.result: LECResult = lec_streamed(data.raw, data.plan, variable_list_df, limits, per_step_boxes=boxes_limits is not None,
+                                                  device=dev, chunk_steps=data.chunk_steps, stats=self.ingest_stats)
         else:
             self.result = self._compute_resident(data, variable_list_df, dev, dTdt)
         torch.cuda.synchronize(dev)
@@ -88,17 +90,24 @@ class BoxData:
         """Host-prepared cubes, uploaded whole."""
         geo_role = "Geopotential" if "Geopotential" in variable_list_df.index else "Geopotential Height"
         roles = ["Air Temperature", "Eastward Wind Component", "Northward Wind Component", "Omega Velocity", geo_role]
-        cubes = []
+        arrays = []
         for role in roles:
             a = data.variables[str(variable_list_df.loc[role]["Variable"])]
+            if a.dtype.kind != "f":                     # an unpacked integer variable: xarray would compute with it as it is
+                a = a.astype(np.float32 if a.dtype.itemsize <= 2 else np.float64)
             scale = ds.field_scale(variable_list_df, role)
             if role != geo_role and scale != 1.0:
                 a = a * a.dtype.type(scale)
-            cubes.append(torch.as_tensor(np.ascontiguousarray(a)).to(dev))
+            arrays.append(a)
+        # a file may mix dtypes (float32 T, u, v with an int16-packed z that decodes to float64): the engine wants one storage
+        # dtype, the widest of them -- widening is exact, and all arithmetic is fp64 anyway (xarray would promote pairwise)
+        common = np.result_type(*[a.dtype for a in arrays])
+        cubes = [torch.as_tensor(np.ascontiguousarray(a, dtype=common)).to(dev) for a in arrays]
         phi_scale = ds.field_scale(variable_list_df, geo_role)
         dTdt_dev = None if dTdt is None else torch.as_tensor(np.ascontiguousarray(dTdt, dtype=cubes[0].cpu().numpy().dtype)).to(dev)
         return self.engine.compute(cubes[0], cubes[1], cubes[2], cubes[3], cubes[4], self.boxes,
-                                   time_s=data.time_s if dTdt is None else None, dTdt=dTdt_dev, phi_scale=phi_scale)
+                                   time_s=data.time_s if dTdt is None else None, dTdt=dTdt_dev, phi_scale=phi_scale,
+                                   per_step_boxes=self.per_step_boxes)
 
 
 class _Terms:
@@ -129,7 +138,7 @@ class _Terms:
         for t in tables:
             self._save_vertical_levels(t)
         s = self.box_obj.scalars[name]
-        return s if self.method == "fixed" else s
+        return s
 
 
 class EnergyContents(_Terms):

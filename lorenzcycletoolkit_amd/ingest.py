@@ -10,7 +10,9 @@ the whole series.  Chunks are double-buffered: the copy of chunk c+1 (copy strea
 chunk c (compute stream).  Results are bit-identical to the resident path (``LECEngine.compute`` on the
 host-prepared cubes): stage 1 is per row, and every chunk carries the one-step halo of T that dT/dt needs.
 
-Fixed (Eulerian) framework only: a moving box reads a small crop per step, which the resident path handles.
+Both frameworks: one fixed box for the whole series, or one box per time step along a track (the analysis domain is then
+the track-extent crop of slice_domain, select_area.py:297-313, and dT/dt is differentiated over the track-selected times on
+the device, as lorenzcycletoolkit.py:184-186 does on the host).
 """
 from __future__ import annotations
 
@@ -44,6 +46,14 @@ class StreamedDataset:
     plan: IngestPlan
     chunk_steps: int = 8
 
+    def level_slice(self, role: str, level_pa: float) -> np.ndarray:
+        """[time, lat, lon] of one role at one level, decoded on the host from the mapped file (the 850-hPa track diagnostics
+        need three such slices: 3 / (5 * levels) of the data)."""
+        k = int(np.flatnonzero(self.plan.level == level_pa)[0])
+        sub = ds.IngestPlan(self.plan.tsel, self.plan.kmap[k:k + 1], self.plan.jmap, self.plan.imap, self.plan.lat, self.plan.lon,
+                            self.plan.level[k:k + 1], self.plan.time)
+        return ds.gather_on_host(self.raw.variables[self.raw.names[role]], sub)[:, 0]
+
     lat = property(lambda self: self.plan.lat)
     lon = property(lambda self: self.plan.lon)
     level = property(lambda self: self.plan.level)
@@ -57,8 +67,8 @@ def prepare_streamed(args, varlist: str = "inputs/namelist", app_logger=None, ch
     the index maps; no field data is read here."""
     if getattr(args, "cdsapi", False):
         raise NotImplementedError("--cdsapi downloads need network access and are out of scope")
-    if not getattr(args, "fixed", False):
-        raise NotImplementedError("the device ingest serves the fixed framework (-f)")
+    if not (getattr(args, "fixed", False) or getattr(args, "track", False)):
+        raise NotImplementedError("the device ingest serves the fixed (-f) and the track (-t) frameworks")
     df = ds.read_namelist(varlist, app_logger)
     raw = ds.open_raw(args.infile, df)
     return StreamedDataset(raw, make_plan(raw, args, app_logger), chunk_steps)
@@ -145,20 +155,72 @@ class _Stager:
         self.raw_dev[slot][a:b].copy_(self.pinned[slot][a:b], non_blocking=True)
 
 
-def lec_fixed_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, box_limits, *, device="cuda:0",
-                       chunk_steps: int = 8, with_q: bool = True, stats: Optional[dict] = None) -> LECResult:
-    """All LEC terms of the fixed framework for the whole series, streamed from the memory-mapped file.
+def _lec_code(dtype: np.dtype) -> int:
+    return _lib.LEC_F64 if np.dtype(dtype) == np.float64 else _lib.LEC_F32
 
-    ``box_limits``: (west, east, south, north) in degrees, as inputs/box_limits.  ``chunk_steps`` time steps are
-    resident per pipeline slot (two slots).  ``stats`` receives counters: bytes moved, chunks, dtype.
+
+def storage_dtypes(rvars) -> tuple:
+    """Per-variable decode dtype (the reference's xarray decode rules, dataset.decode_dtypes) and the one storage dtype of the
+    cubes: the widest of them (widening is exact; the engine wants one dtype, and all arithmetic is fp64 anyway)."""
+    dec = {r: ds.decode_dtypes(v.data.dtype, v.scale_factor, v.add_offset, v.fill_value)[1] for r, v in rvars.items()}
+    return dec, np.result_type(*dec.values())
+
+
+def _ingest_call(lib, v: ds.RawVariable, src_ptr: int, nt: int, geom, maps, unit: float, decode_dtype, out_dtype, out_ptr: int, stream):
+    nl_in, ny_in, nx_in, nl, ny, nx = geom
+    kmap, jmap, imap = maps
+    ga = _lib.IngestArgs(
+        src_d=C.c_void_p(src_ptr), src_dtype=_src_code(v.data.dtype), swap_bytes=int(_swapped(v.data.dtype)),
+        nt=nt, nl_in=nl_in, ny_in=ny_in, nx_in=nx_in, nl=nl, ny=ny, nx=nx,
+        kmap_d=C.c_void_p(kmap.data_ptr()), jmap_d=C.c_void_p(jmap.data_ptr()), imap_d=C.c_void_p(imap.data_ptr()),
+        has_packing=int(v.scale_factor is not None or v.add_offset is not None), has_fill=int(v.fill_value is not None),
+        scale_factor=1.0 if v.scale_factor is None else v.scale_factor, add_offset=0.0 if v.add_offset is None else v.add_offset,
+        fill_value=0.0 if v.fill_value is None else v.fill_value, unit_scale=float(unit),
+        out_dtype=_lec_code(out_dtype), decode_dtype=_lec_code(decode_dtype),
+        out_d=C.c_void_p(out_ptr), stream=C.c_void_p(stream.cuda_stream))
+    _lib.check(lib.lec_ingest(C.byref(ga)), "lec_ingest")
+
+
+def device_cube(var: ds.RawVariable, plan: IngestPlan, device="cuda:0", unit: float = 1.0, out_dtype=None) -> torch.Tensor:
+    """One variable of the analysis domain, [time, level, lat, lon] on the device, through the same staging + ``lec_ingest``
+    path the streamed frameworks use (all time steps at once: for tests and small domains)."""
+    lib = _lib.load()
+    dev = torch.device(device)
+    nt, nl, ny, nx = len(plan.tsel), plan.level.size, plan.lat.size, plan.lon.size
+    decode = ds.decode_dtypes(var.data.dtype, var.scale_factor, var.add_offset, var.fill_value)[1]
+    out_dtype = np.dtype(decode if out_dtype is None else out_dtype)
+    j0, j1 = int(plan.jmap.min()), int(plan.jmap.max())
+    file_levels = np.sort(plan.kmap)
+    st = _Stager(var, nt, dev, file_levels, j0, j1, slots=1)
+    st.stage(0, plan.tsel, 0)
+    st.upload(0, 0, nt)
+    up = lambda a: torch.as_tensor(a, dtype=torch.int32).to(dev)
+    maps = (up(np.searchsorted(file_levels, plan.kmap)), up(plan.jmap - j0), up(plan.imap))
+    out = torch.empty((nt, nl, ny, nx), dtype=torch.float64 if out_dtype == np.float64 else torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _ingest_call(lib, var, st.raw_dev[0].data_ptr(), nt, (nl, j1 - j0 + 1, int(var.data.shape[3]), nl, ny, nx), maps, unit,
+                     decode, out_dtype, out.data_ptr(), torch.cuda.current_stream(dev))
+    torch.cuda.synchronize(dev)
+    return out
+
+
+def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_limits, *, per_step_boxes: bool = False,
+                 device="cuda:0", chunk_steps: int = 8, with_q: bool = True, stats: Optional[dict] = None) -> LECResult:
+    """All LEC terms for the whole series, streamed from the memory-mapped file.
+
+    ``boxes_limits``: one (west, east, south, north) in degrees (fixed framework, as inputs/box_limits) or one per time step
+    (``per_step_boxes``: the moving framework; dT/dt is differentiated over the plan's time axis on the device).
+    ``chunk_steps`` time steps are resident per pipeline slot (two slots).  ``stats`` receives counters: bytes moved, chunks, dtype.
     """
     lib = _lib.load()
     dev = torch.device(device)
     if dev.type != "cuda":
         raise _lib.LecLibraryError("the device ingest needs a GPU: there is no CPU path")
     engine = LECEngine(plan.lat, plan.lon, plan.level, device=dev)
-    box = engine.box_from_limits(*box_limits)
     nt, nl, ny, nx = len(plan.tsel), plan.level.size, plan.lat.size, plan.lon.size
+    boxes = [engine.box_from_limits(*lim) for lim in boxes_limits]
+    if len(boxes) != (nt if per_step_boxes else 1):
+        raise ValueError("boxes_limits: one box, or one per time step with per_step_boxes")
     if with_q and nt < 2:
         raise ValueError("dT/dt by finite differences needs at least 2 time steps")
     chunk_steps = max(1, min(int(chunk_steps), nt))
@@ -166,9 +228,8 @@ def lec_fixed_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, b
     roles = list(_ROLE_KEYS) + [geo_role]
     keys = {**_ROLE_KEYS, geo_role: "geopt"}
     rvars = {r: raw.variables[raw.names[r]] for r in roles}
-    packed_any = any(v.scale_factor is not None or v.add_offset is not None for v in rvars.values())
-    all_f32 = all(v.data.dtype.kind == "f" and v.data.dtype.itemsize == 4 for v in rvars.values())
-    out_dtype = torch.float32 if (all_f32 and not packed_any) else torch.float64      # the file's precision, fp64 for packed data
+    decode, common = storage_dtypes(rvars)
+    out_dtype = torch.float64 if common == np.float64 else torch.float32
     slots = 2
     span = chunk_steps + 2                                                # own steps + the one-step halo of T either side
     # staged sub-cube of every file time step: the kept levels (already in output order) x the latitude band of the domain
@@ -178,8 +239,8 @@ def lec_fixed_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, b
     stagers = {r: _Stager(rvars[r], span, dev, file_levels, j0, j1, slots) for r in roles}
     cubes = [{keys[r]: torch.empty((span, nl, ny, nx), dtype=out_dtype, device=dev) for r in roles} for _ in range(slots)]
     up = lambda a: torch.as_tensor(a, dtype=torch.int32).to(dev)
-    kmap, jmap, imap = up(np.searchsorted(file_levels, plan.kmap)), up(plan.jmap - j0), up(plan.imap)   # maps into the staged sub-cube
-    bt, _ = engine._box_tables([box])
+    maps = (up(np.searchsorted(file_levels, plan.kmap)), up(plan.jmap - j0), up(plan.imap))   # maps into the staged sub-cube
+    bt, _ = engine._box_tables(boxes)
     rows = torch.empty((nt, nl, bt.nyb_max, _lib.LEC_NSTAT), dtype=torch.float64, device=dev)
     time_s = plan.time_s
     phi_scale = ds.field_scale(variable_list_df, geo_role)
@@ -215,30 +276,23 @@ def lec_fixed_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, b
         compute.wait_event(copied[slot])
         with torch.cuda.device(dev):
             for r in roles:
-                v, st = rvars[r], stagers[r]
                 a, b = span_of(r)
                 unit = 1.0 if r == geo_role else ds.field_scale(variable_list_df, r)
-                ga = _lib.IngestArgs(
-                    src_d=C.c_void_p(st.raw_dev[slot][a].data_ptr()), src_dtype=_src_code(v.data.dtype),
-                    swap_bytes=int(_swapped(v.data.dtype)), nt=b - a, nl_in=nl_in, ny_in=ny_in, nx_in=nx_in,
-                    nl=nl, ny=ny, nx=nx, kmap_d=C.c_void_p(kmap.data_ptr()), jmap_d=C.c_void_p(jmap.data_ptr()),
-                    imap_d=C.c_void_p(imap.data_ptr()),
-                    has_packing=int(v.scale_factor is not None or v.add_offset is not None),
-                    has_fill=int(v.fill_value is not None),
-                    scale_factor=1.0 if v.scale_factor is None else v.scale_factor,
-                    add_offset=0.0 if v.add_offset is None else v.add_offset,
-                    fill_value=0.0 if v.fill_value is None else v.fill_value, unit_scale=float(unit),
-                    out_dtype=_lib.LEC_F64 if out_dtype == torch.float64 else _lib.LEC_F32, reserved0=0,
-                    out_d=C.c_void_p(cubes[slot][keys[r]][a].data_ptr()), stream=C.c_void_p(compute.cuda_stream))
-                _lib.check(lib.lec_ingest(C.byref(ga)), "lec_ingest")
+                _ingest_call(lib, rvars[r], stagers[r].raw_dev[slot][a].data_ptr(), b - a, (nl_in, ny_in, nx_in, nl, ny, nx), maps, unit,
+                             decode[r], common, cubes[slot][keys[r]][a].data_ptr(), compute)
             consumed[slot].record(compute)
         f = {k: t[: h1 - h0] for k, t in cubes[slot].items()}
-        engine.rowstats(f["tair"], f["u"], f["v"], f["omega"], f["geopt"], [box],
+        engine.rowstats(f["tair"], f["u"], f["v"], f["omega"], f["geopt"], boxes[c0:c1] if per_step_boxes else boxes,
                         time_s=time_s[h0:h1] if with_q else None, t_begin=c0 - h0, t_count=c1 - c0, with_q=with_q,
-                        rows_out=rows[c0:c1])
+                        rows_out=rows[c0:c1], per_step_boxes=per_step_boxes)
         used[slot] = True
-    res = engine.reduce(rows, [box], phi_scale=phi_scale)
+    res = engine.reduce(rows, boxes, phi_scale=phi_scale, drop_any_time=not per_step_boxes)
     if stats is not None:
         stats.update(bytes_moved=moved, host_staging_seconds=host_s, chunks=n_chunks, chunk_steps=chunk_steps, storage=str(out_dtype).replace("torch.", ""),
-                     box=tuple(int(x) for x in box), domain=(nt, nl, ny, nx))
+                     decode={keys[r]: str(d) for r, d in decode.items()}, box=tuple(int(x) for x in boxes[0]), domain=(nt, nl, ny, nx))
     return res
+
+
+def lec_fixed_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, box_limits, **kw) -> LECResult:
+    """The fixed framework on the streamed path: one box for the whole series (see lec_streamed)."""
+    return lec_streamed(raw, plan, variable_list_df, [box_limits], per_step_boxes=False, **kw)

@@ -71,9 +71,10 @@ def compare(engine_scalars, engine_levels, ref_scalars, ref_levels, tol, what=""
     return worst
 
 
-def write_packed_era5_style(path, nt=7):
+def write_packed_era5_style(path, nt=7, fill=True, offset=True):
     """ERA5-style file: int16 with scale_factor / add_offset / _FillValue, lon 0..357.5, lat N -> S, levels in hPa
-    from the surface up including 5 hPa (dropped by the >= 10 hPa filter)."""
+    from the surface up including 5 hPa (dropped by the >= 10 hPa filter).  ``fill`` / ``offset``: leave out the fill value
+    or the add_offset -- the reference's xarray 2024.2.0 decodes the three variants to float32 / float64 / float32."""
     from scipy.io import netcdf_file
     rng = np.random.default_rng(4)
     lon = np.arange(0.0, 360.0, 2.5)
@@ -97,13 +98,17 @@ def write_packed_era5_style(path, nt=7):
     }
     for name, a in fields.items():
         lo_, hi_ = a.min(), a.max()
-        scale = (hi_ - lo_) / 65000.0
-        offset = 0.5 * (hi_ + lo_)
-        q = np.clip(np.round((a - offset) / scale), -32000, 32000).astype(np.int16)
-        if name == "v":
+        off = 0.5 * (hi_ + lo_) if offset else 0.0
+        scale = (hi_ - lo_) / 65000.0 if offset else max(abs(hi_), abs(lo_)) / 32000.0
+        q = np.clip(np.round((a - off) / scale), -32000, 32000).astype(np.int16)
+        if name == "v" and fill:
             q[2, 7, :, :] = -32767          # 50 hPa = the top kept level, one time step: dropped for the whole series
-            q[4, 3, 10, 20] = -32767        # an interior point: that level is repaired by interpolation at that step
+            q[4 % nt, 3, 10, 20] = -32767   # an interior point: that level is repaired by interpolation at that step
         v = f.createVariable(name, "h", ("time", "level", "latitude", "longitude"))
         v[:] = q
-        v.scale_factor = float(scale); v.add_offset = float(offset); v._FillValue = np.int16(-32767)
+        v.scale_factor = float(scale)
+        if offset:
+            v.add_offset = float(off)
+        if fill:
+            v._FillValue = np.int16(-32767)
     f.close()

@@ -159,12 +159,14 @@ def test_era5_style_fixed_and_track_cli(workdir, golden_dir):
     out = workdir / "LEC_Results" / "testdata_ERA5_fixed"
     got = pd.read_csv(out / "testdata_ERA5_fixed_results.csv", index_col=0)
     assert len(got) == 6 and np.isfinite(got.values).all() and str(got.index[0]) == "2005-08-09 00:00:00"
-    df = ds.read_namelist("inputs/namelist")
-    host = ds.prepare_data(lorenzcycletoolkit.create_arg_parser().parse_args(["testdata_ERA5.nc", "-r", "-f"]), "inputs/namelist")
-    nm = lambda role: str(df.loc[role]["Variable"])
-    dom = o.Domain(*(host.variables[nm(r)].astype(np.float64) for r in ("Air Temperature", "Eastward Wind Component", "Northward Wind Component",
-                                                                       "Omega Velocity", "Geopotential")),
-                   host.lat.astype(np.float64), host.lon.astype(np.float64), host.level, host.time_s)     # (the file's coordinates are float32)
+    # the oracle's OWN preparation of the file (oracle/cf_decode.py: xarray 2024.2.0's decode, process_data, slice_domain), not the
+    # package's: int16 + add_offset + _FillValue decode to float32 there; the engine computes in fp64 from those float32 values
+    from oracle import cf_decode as cf
+    from tests.helpers import as_f64
+    names = {"tair": "T", "u": "U", "v": "V", "omega": "W", "geo": "Z", "lat": "latitude", "lon": "longitude", "level": "level", "time": "time"}
+    prepared = cf.prepare("testdata_ERA5.nc", names, fixed_limits=(-60.0, -30.0, -42.5, -17.5))
+    assert prepared.tair.dtype == np.float32
+    dom = as_f64(prepared)
     ref, _ = o.lec_fixed(dom, -60.0, -30.0, -42.5, -17.5)
     for c in ("Az", "Ae", "Kz", "Ke", "Cz", "Ca", "Ck", "Ce", "BAz", "BAe", "BKz", "BKe", "Gz", "Ge"):
         r = np.asarray(ref[c], dtype=np.float64)
@@ -176,4 +178,19 @@ def test_era5_style_fixed_and_track_cli(workdir, golden_dir):
     assert args.track and args.plots
     tr = pd.read_csv(workdir / "LEC_Results" / "testdata_ERA5_track" / "testdata_ERA5_track_results.csv", index_col=0)
     assert len(tr) == 5 and np.isfinite(tr[["Az", "Ae", "Kz", "Ke", "Cz", "Ca", "Ck", "Ce", "Gz", "Ge"]].values).all()
-    assert (workdir / "LEC_Results" / "testdata_ERA5_track" / "testdata_ERA5_track_trackfile").exists()
+    tdir = workdir / "LEC_Results" / "testdata_ERA5_track"
+    assert (tdir / "testdata_ERA5_track_trackfile").exists()
+    # numbers: the oracle's moving framework on the oracle's preparation of the file (track-time selection, track-extent crop)
+    trk = pd.read_csv(workdir / "inputs" / "track", sep=";")
+    times = pd.to_datetime(trk["time"], format="%Y-%m-%d-%H%M").values.astype("datetime64[ns]")
+    domt = as_f64(cf.prepare("testdata_ERA5.nc", names, track=(times, trk["Lat"].values, trk["Lon"].values)))
+    limits = [(lo - 7.5, lo + 7.5, la - 7.5, la + 7.5) for la, lo in zip(trk["Lat"], trk["Lon"])]
+    mref, _ = o.lec_moving(domt, limits)
+    for c in ("Az", "Ae", "Kz", "Ke", "Cz", "Ca", "Ck", "Ce", "BAz", "BAe", "BKz", "BKe", "BΦZ", "BΦE", "Gz", "Ge"):
+        r = np.asarray(mref[c], dtype=np.float64)
+        assert np.max(np.abs(tr[c].values - r)) <= 1e-9 * np.max(np.abs(r)), c
+    # the same run with the data streamed to the GPU (per-step boxes over chunked ingest): byte-identical outputs
+    before = {f: (tdir / f).read_bytes() for f in ("testdata_ERA5_track_results.csv", "testdata_ERA5_track_trackfile")}
+    _main(["testdata_ERA5.nc", "-r", "-t", "--device-ingest"])
+    for f, b in before.items():
+        assert (tdir / f).read_bytes() == b, f

@@ -65,7 +65,7 @@ def test_packed_int16_file_streamed_equals_resident(workdir, chunk_steps):
     limits = (-60.0, 20.0, -45.0, 30.0)      # crosses the Greenwich meridian: needs the longitude wrap + sort
     (workdir / "inputs" / "box_limits").write_text("min_lon;-60\nmax_lon;20\nmin_lat;-45\nmax_lat;30\n")
     a, b, stats = _both_paths(path, "inputs/namelist", limits, chunk_steps)
-    assert stats["storage"] == "float64" and stats["domain"][1] == 8          # 5 hPa dropped
+    assert stats["storage"] == "float32" and stats["domain"][1] == 8          # int16 + fill value: float32 in the reference's xarray; 5 hPa dropped
     assert int(a.nanflag.max()) > 0                                            # the fill values reached _handle_nans
     assert torch.equal(a.scalars, b.scalars)
     assert np.array_equal(a.levels.cpu().numpy(), b.levels.cpu().numpy(), equal_nan=True)     # NaN levels stay NaN in the tables
@@ -75,8 +75,8 @@ def test_packed_int16_file_streamed_equals_resident(workdir, chunk_steps):
     assert stats["bytes_moved"] <= 1.6 * full_bytes * (8 / 9) * (band / 49)    # int16 over PCIe (+ T halo), not fp64, not the whole globe
 
 
-@pytest.mark.parametrize("name,storage", [("packed_chunked_tracked.nc", "float64"), ("float_chunked_latest.nc", "float32"),
-                                          ("packed_chunked_earliest.nc", "float64")])
+@pytest.mark.parametrize("name,storage", [("packed_chunked_tracked.nc", "float32"), ("float_chunked_latest.nc", "float32"),
+                                          ("packed_chunked_earliest.nc", "float32")])
 def test_netcdf4_file_streamed_equals_resident(workdir, name, storage):
     """NetCDF-4 / HDF5 input (hdf5_lite): chunks are inflated on the host per time step, then take the same device path."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -92,3 +92,58 @@ def test_netcdf4_file_streamed_equals_resident(workdir, name, storage):
     assert torch.equal(a.scalars, b.scalars)
     assert np.array_equal(a.levels.cpu().numpy(), b.levels.cpu().numpy(), equal_nan=True)
     assert torch.isfinite(a.scalars[:, :4]).all()
+
+
+ERA5_NAMES = {"tair": "t", "u": "u", "v": "v", "omega": "w", "geo": "z", "lat": "latitude", "lon": "longitude", "level": "level", "time": "time"}
+ERA5_NAMELIST = (";Variable;Units\nAir Temperature;t;K\nGeopotential;z;m**2/s**2\nOmega Velocity;w;Pa/s\n"
+                 "Eastward Wind Component;u;m/s\nNorthward Wind Component;v;m/s\nLongitude;longitude\nLatitude;latitude\n"
+                 "Time;time\nVertical Level;level\n")
+
+
+@pytest.mark.parametrize("fill,offset,want", [(True, True, torch.float32), (False, True, torch.float64), (False, False, torch.float32)])
+def test_lec_ingest_cube_equals_the_oracle_decode(workdir, fill, offset, want):
+    """``lec_ingest`` pinned independently of the package's own host decoder: the cube it writes for every variable of an
+    ERA5-style int16 file (0..360 longitudes, N -> S latitudes, hPa levels incl. 5 hPa, fill values) must equal, bit for bit
+    and NaN for NaN, the ORACLE's restatement of the reference's decode + process_data + slice_domain (oracle/cf_decode.py:
+    xarray 2024.2.0's mask / scale-offset coders with their dtype rules) -- float32 or float64 as that decode gives it."""
+    from oracle import cf_decode as cf
+    path = str(workdir / "packed.nc")
+    _write_packed(path, nt=5, fill=fill, offset=offset)
+    (workdir / "inputs" / "namelist").write_text(ERA5_NAMELIST)
+    (workdir / "inputs" / "box_limits").write_text("min_lon;-60\nmax_lon;20\nmin_lat;-45\nmax_lat;30\n")
+    args = argparse.Namespace(fixed=True, track=False, trackfile=None)
+    df = ds.read_namelist("inputs/namelist")
+    raw = ds.open_raw(path, df)
+    plan = ingest.make_plan(raw, args)
+    ref = cf.prepare(path, ERA5_NAMES, fixed_limits=(-60, 20, -45, 30))
+    assert np.array_equal(plan.lat, ref.lat) and np.array_equal(plan.lon, ref.lon) and np.array_equal(plan.level, ref.level)
+    assert np.array_equal(plan.time_s, ref.time_s)
+    for role, name in (("tair", "t"), ("u", "u"), ("v", "v"), ("omega", "w"), ("geopt", "z")):
+        cube = ingest.device_cube(raw.variables[name], plan)
+        want_np = getattr(ref, role)
+        assert cube.dtype == want and str(want_np.dtype) == str(want).replace("torch.", ""), (role, cube.dtype, want_np.dtype)
+        assert np.array_equal(cube.cpu().numpy(), want_np, equal_nan=True), role
+        wide = ingest.device_cube(raw.variables[name], plan, out_dtype=np.float64)        # storage may be wider than the decode: exact
+        assert wide.dtype == torch.float64 and np.array_equal(wide.cpu().numpy(), want_np.astype(np.float64), equal_nan=True)
+    assert bool(np.isnan(ref.v).any()) == fill
+    raw.close()
+
+
+def test_moving_framework_streamed_equals_resident(workdir, golden_dir):
+    """The semi-Lagrangian framework on the streamed path: per-time-step boxes over chunked ingest, dT/dt differentiated on the
+    device over the track-selected times (select_area.py:297-313, lec_moving_framework.py:639-730) -- the same bits as the
+    host-prepared resident path, whatever the chunking."""
+    shutil.copy(os.path.join(golden_dir, "inputs", "track_testdata_NCEP-R2"), workdir / "inputs" / "track")
+    infile = os.path.join(golden_dir, "testdata_NCEP-R2.nc")
+    args = argparse.Namespace(fixed=False, track=True, trackfile="inputs/track", residuals=True, infile=infile, cdsapi=False)
+    df = ds.read_namelist("inputs/namelist")
+    host = ds.prepare_data(args, "inputs/namelist")
+    track = ds.read_track("inputs/track")
+    limits = [(lo - 7.5, lo + 7.5, la - 7.5, la + 7.5) for la, lo in zip(track["Lat"], track["Lon"])]
+    a = BoxData(host, df, args=args, boxes_limits=limits).result
+    for chunk in (1, 2, 8):
+        st = ingest.prepare_streamed(args, "inputs/namelist", chunk_steps=chunk)
+        b = BoxData(st, df, args=args, boxes_limits=limits).result
+        st.raw.close()
+        assert torch.equal(a.scalars, b.scalars) and torch.equal(a.levels, b.levels), chunk
+    assert torch.isfinite(a.scalars).all()

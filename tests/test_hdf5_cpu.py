@@ -93,7 +93,9 @@ def test_prepare_data_from_hdf5(workdir, name):
         h = hdf5_lite.H5File(args.infile)
         scale, offset = h.variables["t"].attrs["scale_factor"], h.variables["t"].attrs["add_offset"]
         h.close()
-        assert T.dtype == np.float64 and T[2, k_out, 0, i_out] == q[2, 3, j, i] * scale + offset
+        # int16 + scale_factor + add_offset + _FillValue: float32 in the reference's xarray 2024.2.0 (each step computed in fp64, stored in float32)
+        want = np.float32(np.float64(np.float32(np.float64(np.float32(q[2, 3, j, i])) * scale)) + offset)
+        assert T.dtype == np.float32 and T[2, k_out, 0, i_out] == want
         assert np.isnan(data.variables["v"][1, -1]).all()        # the fill values of the 1000 hPa level
     else:
         assert T.dtype == np.float32 and T[2, k_out, 0, i_out] == np.float32(f["t"][2, 3, j, i])

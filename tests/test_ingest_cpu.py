@@ -21,17 +21,13 @@ def workdir(tmp_path, golden_dir, monkeypatch):
 
 
 def _emulate_lec_ingest(var: ds.RawVariable, plan: ingest.IngestPlan) -> np.ndarray:
-    """What lec_ingest_kernel computes (include/lec_hip.h), in NumPy."""
+    """What lec_ingest has to produce (include/lec_hip.h): the plan's gather of the file values, decoded as the reference's
+    xarray does -- by the ORACLE's restatement of that decode (oracle/cf_decode.py), not by the package's own decoder."""
+    from oracle import cf_decode as cf
     raw = np.asarray(var.data)[plan.tsel][:, plan.kmap][:, :, plan.jmap][:, :, :, plan.imap]
-    raw = raw.astype(raw.dtype.newbyteorder("="))
-    out = raw
-    if var.scale_factor is not None or var.add_offset is not None:
-        out = raw.astype(np.float64)
-        out = out * (1.0 if var.scale_factor is None else var.scale_factor)
-        out = out + (0.0 if var.add_offset is None else var.add_offset)
-    if var.fill_value is not None:
-        out = np.where(raw == var.fill_value, np.nan, out.astype(np.float64) if out.dtype.kind == "i" else out)
-    return out
+    attrs = {k: v for k, v in (("scale_factor", var.scale_factor), ("add_offset", var.add_offset), ("_FillValue", var.fill_value))
+             if v is not None}
+    return cf.decode_cf_variable(raw, attrs)
 
 
 def _compare(infile, args):
