@@ -20,24 +20,28 @@ from lorenzcycletoolkit_amd.frameworks import lec_fixed, lec_moving
 
 
 def create_arg_parser():
-    """Reference lorenzcycletoolkit.py:50-129 (identical flags and defaults)."""
-    parser = argparse.ArgumentParser(description="Lorenz Energy Cycle (LEC) program.")
-    parser.add_argument("infile", help="Input .nc file with temperature, geopotential/geopotential height, and wind components data.")
-    parser.add_argument("-r", "--residuals", action="store_true", help="Compute the Dissipation and Generation terms as residuals.")
+    """The reference's command line (lorenzcycletoolkit.py:50-129 there): the same flags, defaults and mutual exclusions -- the
+    flag table is the drop-in contract; the help texts are this program's own."""
+    parser = argparse.ArgumentParser(description="Lorenz Energy Cycle of a limited area, computed on an AMD GPU (MI355X HIP engine).")
+    parser.add_argument("infile", help="NetCDF file (classic or NetCDF-4) holding T, u, v, omega and geopotential (or geopotential height) "
+                        "on isobaric levels; variable names come from inputs/namelist")
+    parser.add_argument("-r", "--residuals", action="store_true", help="close the budgets with residual terms (RGz, RKz, RGe, RKe) instead of "
+                        "friction-based dissipation; the only mode the reference completes")
     group = parser.add_mutually_exclusive_group(required=True)
-    group.add_argument("-f", "--fixed", action="store_true", help="Compute the energetics for a fixed domain specified by the 'box_limits' file.")
-    group.add_argument("-t", "--track", action="store_true", help="Define the domain using a track file.")
-    group.add_argument("-c", "--choose", action="store_true", help="Interactively select the domain for each time step.")
-    parser.add_argument("-z", "--zeta", action="store_true", help="Use the vorticity from the track file instead of computing it at 850 hPa.")
-    parser.add_argument("-m", "--mpas", action="store_true", help="Specify this flag if working with MPAS-A data processed with MPAS-BR routines.")
-    parser.add_argument("-p", "--plots", action="store_true", help="Generate plots.")
-    parser.add_argument("-v", "--verbosity", action="store_true", help="Logger level set to debug mode.")
-    parser.add_argument("--cdsapi", action="store_true", help="Use CDS API for downloading data (experimental).")
-    parser.add_argument("--time-resolution", type=int, default=3, help="Temporal resolution in hours for CDS API data download (default: 3).")
-    parser.add_argument("--trackfile", type=str, default="inputs/track", help="Specify a custom track file. Default is 'inputs/track'.")
-    parser.add_argument("--box_limits", type=str, default="inputs/box_limits", help="Specify a custom box limits file. Default is 'inputs/box_limits'.")
-    parser.add_argument("--device-ingest", action="store_true", help="(MI355X engine, with -f) stream the file bytes to the GPU and decode / sort / crop them there instead of preparing the data on the host.")
-    parser.add_argument("-o", "--outname", type=str, help="Specify an output name for the results.")
+    group.add_argument("-f", "--fixed", action="store_true", help="Eulerian framework: one box for the whole series, read from the box-limits file")
+    group.add_argument("-t", "--track", action="store_true", help="semi-Lagrangian framework: one box per time step, centred on the track file's positions")
+    group.add_argument("-c", "--choose", action="store_true", help="pick each time step's box on a map (needs a GUI: not available in this build)")
+    parser.add_argument("-z", "--zeta", action="store_true", help="with -t: report the 850-hPa vorticity at the track position rather than the box extremum")
+    parser.add_argument("-m", "--mpas", action="store_true", help="input comes from MPAS-A post-processed with MPAS-BR")
+    parser.add_argument("-p", "--plots", action="store_true", help="accepted for compatibility; figures are made by the reference's plot scripts from the CSVs")
+    parser.add_argument("-v", "--verbosity", action="store_true", help="log at DEBUG level")
+    parser.add_argument("--cdsapi", action="store_true", help="download ERA5 through the CDS API first (needs network access: not available in this build)")
+    parser.add_argument("--time-resolution", type=int, default=3, help="hours between downloaded analyses with --cdsapi (default: 3)")
+    parser.add_argument("--trackfile", type=str, default="inputs/track", help="track file for -t (default: inputs/track)")
+    parser.add_argument("--box_limits", type=str, default="inputs/box_limits", help="box-limits file for -f (default: inputs/box_limits)")
+    parser.add_argument("--device-ingest", action="store_true", help="stream the file's bytes to the GPU in chunks and decode / sort / crop them "
+                        "there, instead of preparing the whole data set on the host (same results, bit for bit)")
+    parser.add_argument("-o", "--outname", type=str, help="name of the results CSV (fixed framework)")
     return parser
 
 

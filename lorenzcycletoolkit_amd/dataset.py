@@ -24,7 +24,8 @@ REQUIRED_ROLES = ["Air Temperature", "Omega Velocity", "Eastward Wind Component"
 # factor to SI for the units the preset namelists use (pint did this in the reference: box_data.py:297-310)
 _UNIT_SCALE = {
     "K": 1.0, "kelvin": 1.0, "m/s": 1.0, "m s-1": 1.0, "m s**-1": 1.0, "Pa/s": 1.0, "Pa s-1": 1.0, "Pa s**-1": 1.0,
-    "hPa/s": 100.0, "m**2/s**2": 1.0, "m2/s2": 1.0, "m**2 s**-2": 1.0, "m": 1.0, "gpm": 1.0, "dam": 10.0,
+    "hPa/s": 100.0, "m**2/s**2": 1.0, "m2/s2": 1.0, "m**2 s**-2": 1.0, "meter ** 2 / second ** 2": 1.0, "m": 1.0, "gpm": 1.0,
+    "dam": 10.0, "meter": 1.0, "kelvin": 1.0, "meter / second": 1.0, "pascal / second": 1.0,
 }
 _LEVEL_SCALE = {"pa": 1.0, "hpa": 100.0, "mb": 100.0, "mbar": 100.0, "millibar": 100.0, "millibars": 100.0}
 

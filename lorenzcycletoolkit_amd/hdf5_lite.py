@@ -6,7 +6,7 @@ gridded data:
 * the root group as a symbol table (v1 B-tree + local heap), as compact link messages, or as dense link storage
   (v2 B-tree name index + fractal heap);
 * datasets: contiguous, compact, and chunked (layout v3 with a v1 B-tree; layout v4 single-chunk / implicit /
-  fixed-array / extensible-array / v2-B-tree indexes), filters deflate + shuffle (+ fletcher32, ignored);
+  fixed-array / extensible-array / v2-B-tree indexes), filters deflate + shuffle + fletcher32 (verified);
 * datatypes: integers and IEEE floats of 1-8 bytes in either byte order, fixed- and variable-length strings,
   object references (for DIMENSION_LIST);
 * attributes in the object header or in dense storage.
@@ -724,7 +724,7 @@ class H5File:
                     data_block(self._addr(q + i * self.O), nel)
         return out[:want]
 
-    def _read_chunk(self, var: H5Variable, addr: int, size: int, mask: int) -> np.ndarray:
+    def _read_chunk(self, var: "H5Variable", addr: int, size: int, mask: int) -> np.ndarray:
         raw = bytes(self._m[addr + self.base: addr + self.base + size])
         for i, (fid, cd) in reversed(list(enumerate(var._filters))):
             if mask & (1 << i):
@@ -735,8 +735,10 @@ class H5File:
                 es = cd[0] if cd else var.dtype.itemsize
                 n = len(raw) // es
                 raw = np.frombuffer(raw, dtype=np.uint8)[: n * es].reshape(es, n).T.tobytes()
-            elif fid == 3:                             # fletcher32: checksum at the end
-                raw = raw[:-4]
+            elif fid == 3:                             # fletcher32: the payload's checksum follows it (4 bytes, little-endian)
+                raw, stored = raw[:-4], int.from_bytes(raw[-4:], "little")
+                if stored not in _fletcher32(raw):
+                    raise Hdf5Error(f"fletcher32 checksum mismatch in a chunk of '{var.name}' at file offset {addr + self.base}: the file is corrupt")
             else:
                 raise Hdf5Error(f"HDF5 filter {fid} not supported (deflate, shuffle and fletcher32 are)")
         return np.frombuffer(raw, dtype=var.dtype)
@@ -773,8 +775,11 @@ class H5File:
         by_t = var._cache["by_t"]
         first = (lo0 // chunk[0]) * chunk[0]
         need = [item for o0 in range(first, hi0, chunk[0]) for item in by_t.get(o0, ())]
-        missing = [(offs, loc) for offs, loc in need if ("chunk", offs) not in var._cache]
-        if len(var._cache) + len(missing) > 256:               # bounded chunk cache (time-step reads revisit chunks that span steps)
+        if t is None:                                          # a whole-variable read is used once: nothing to keep (the cache would hold
+            missing, keep = need, False                        # the variable a second time)
+        else:
+            missing, keep = [(offs, loc) for offs, loc in need if ("chunk", offs) not in var._cache], True
+        if keep and len(var._cache) + len(missing) > 256:               # bounded chunk cache (time-step reads revisit chunks that span steps)
             for k in [k for k in var._cache if isinstance(k, tuple) and k and k[0] == "chunk"]:
                 del var._cache[k]
             missing = need
@@ -783,10 +788,12 @@ class H5File:
             results = list(_inflate_pool().map(inflate, missing))          # zlib releases the GIL
         else:
             results = [inflate(item) for item in missing]
-        for offs, data in results:
-            var._cache[("chunk", offs)] = data
+        fresh = dict(results)
+        if keep:
+            for offs, data in results:
+                var._cache[("chunk", offs)] = data
         for offs, _loc in need:
-            data = var._cache[("chunk", offs)]
+            data = fresh[offs] if offs in fresh else var._cache[("chunk", offs)]
             src, dst = [], []
             for d in range(len(shape)):
                 a0 = max(offs[d], lo0 if d == 0 else 0)
@@ -795,6 +802,25 @@ class H5File:
                 dst.append(slice(a0 - (lo0 if d == 0 else 0), a1 - (lo0 if d == 0 else 0)))
             out[tuple(dst)] = data[tuple(src)]
         return out if t is None else out[0]
+
+
+def _fletcher32(data: bytes):
+    """HDF5's H5_checksum_fletcher32 of `data` (16-bit big-endian words, ones'-complement sums) and its byte-swapped twin,
+    which the library also accepts on read (H5Zfletcher32.c: files written by 1.6.2 on little-endian hosts)."""
+    n = len(data) // 2
+    w = np.frombuffer(data, dtype=">u2", count=n).astype(np.uint64)
+    if len(data) % 2:
+        w = np.append(w, np.uint64(data[-1] << 8))
+    fold = lambda x: 0 if x == 0 else (x - 1) % 65535 + 1
+    s1 = s2 = 0
+    for a in range(0, w.size, 1 << 20):               # blocks keep the weighted sums far inside 64 bits
+        blk = w[a: a + (1 << 20)]
+        m = blk.size
+        s2 += s1 * m + int((blk * np.arange(m, 0, -1, dtype=np.uint64)).sum())
+        s1 += int(blk.sum())
+    c = (fold(s2) << 16) | fold(s1)
+    swapped = ((c & 0x00FF00FF) << 8) | ((c >> 8) & 0x00FF00FF)
+    return (c, swapped)
 
 
 _POOL = None

@@ -110,3 +110,29 @@ def test_open_dataset_rejects_unknown_containers(workdir):
         ds.open_dataset("y.nc", ds.read_namelist("inputs/namelist"))
     with pytest.raises(FileNotFoundError):
         ds.open_dataset("missing.nc", ds.read_namelist("inputs/namelist"))
+
+
+def test_shipped_input_presets_follow_the_contract(tmp_path, monkeypatch):
+    """./inputs carries the preset namelists / box limits / tracks of the drop-in contract; a run copies one to
+    inputs/namelist exactly as the reference's tests do (shutil.copy('inputs/namelist_NCEP-R2', 'inputs/namelist'))."""
+    import shutil
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shutil.copytree(os.path.join(root, "inputs"), tmp_path / "inputs")
+    monkeypatch.chdir(tmp_path)
+    presets = sorted(f for f in os.listdir("inputs") if f.startswith("namelist_"))
+    assert presets == ["namelist_ERA5", "namelist_ERA5-cdsapi", "namelist_ERA5-copernicus", "namelist_ERA5-copernicus-new",
+                       "namelist_MPAS-A", "namelist_NCEP-R1", "namelist_NCEP-R2"]
+    for name in presets:
+        shutil.copy(os.path.join("inputs", name), "inputs/namelist")
+        df = ds.read_namelist("inputs/namelist")
+        geo = "Geopotential" if "Geopotential" in df.index else "Geopotential Height"
+        for role in ("Air Temperature", "Omega Velocity", "Eastward Wind Component", "Northward Wind Component", geo):
+            assert ds.field_scale(df, role) > 0                       # the preset's units are understood
+    assert ds.read_box_limits("inputs/box_limits") == (-60.0, -30.0, -42.5, -17.5)
+    assert ds.read_box_limits("inputs/box_limits-testcase") == (-53.0, -44.0, -31.0, -24.0)
+    for name, n in (("track_testdata_NCEP-R2", 5), ("track_testdata_ERA5", 5)):
+        tr = ds.read_track(os.path.join("inputs", name))
+        assert len(tr) == n and list(tr.columns) == ["Lat", "Lon"]
+    # the fixtures the tests use are these very files
+    for name in ("namelist_NCEP-R2", "namelist_ERA5", "box_limits_Reg1", "track_testdata_NCEP-R2", "track_testdata_ERA5"):
+        assert open(os.path.join("inputs", name)).read().split() == open(os.path.join(root, "tests", "golden", "inputs", name)).read().split()

@@ -130,3 +130,28 @@ def test_structural_errors_are_reported(tmp_path):
     with pytest.raises(hdf5_lite.Hdf5Error, match="not an HDF5"):
         hdf5_lite.H5File(str(notes))
     assert hdf5_lite.is_hdf5(os.path.join(FIX, "float_chunked_latest.nc")) and not hdf5_lite.is_hdf5(str(notes))
+
+
+def test_fletcher32_checksums_are_verified(tmp_path):
+    """The fixtures written with fletcher32=True pass (so the checksum is computed the way the HDF5 library does); one flipped
+    payload byte is refused, not decoded (the checksum used to be stripped unverified)."""
+    import shutil
+    src = os.path.join(FIX, "packed_unlimited_latest.nc")
+    h = hdf5_lite.H5File(src)
+    v = h.variables["t"]
+    assert 3 in [fid for fid, _ in v._filters]
+    good = v.read()
+    (offs, (addr, size, mask)) = sorted(h._chunks(v).items())[0]
+    h.close()
+    bad = tmp_path / "corrupt.nc"
+    shutil.copy(src, bad)
+    with open(bad, "r+b") as f:
+        f.seek(addr + size // 2)
+        b = f.read(1)
+        f.seek(addr + size // 2)
+        f.write(bytes([b[0] ^ 0x10]))
+    h = hdf5_lite.H5File(str(bad))
+    with pytest.raises(hdf5_lite.Hdf5Error, match="checksum|decompress|invalid|incorrect"):
+        h.variables["t"].read()
+    h.close()
+    assert good.size > 0
