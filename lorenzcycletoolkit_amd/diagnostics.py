@@ -2,9 +2,11 @@
 tools.py:95-128 of the reference): relative vorticity, wind speed, and the position of the vorticity
 extremum / height minimum / wind maximum inside each time step's box, written to ``*_trackfile``.
 
-Not part of the LEC hot path: a few (time, lat, lon) slices on the host.  Parity UNPINNED (SURVEY.md
+Not part of the LEC hot path: a few (time, lat, lon) slices on the host.  Parity UNPINNED against MetPy (SURVEY.md
 section 8c): the reference calls MetPy's ``vorticity`` / ``wind_speed`` and its only sample trackfile
-has these columns empty.  Vorticity here is the spherical form zeta = dv/dx - du/dy + (u/Re) tan(phi) with
+has these columns empty; the formulas here are checked against an independent restatement (oracle/track_diagnostics.py,
+tests/test_diagnostics_cpu.py), and the box / extremum logic against the reference's own get_position.  One deliberate
+difference: extremum POSITIONS skip NaN like the values do (the reference's argmin / argmax land on a NaN cell).  Vorticity here is the spherical form zeta = dv/dx - du/dy + (u/Re) tan(phi) with
 dx = Re cos(phi) d(lambda), dy = Re d(phi) and MetPy-style three-point derivatives (second order, also at
 the edges); MetPy's default geodesic uses the WGS84 ellipsoid, so values can differ by a few 1e-3 relative.
 """
