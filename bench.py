@@ -49,7 +49,7 @@ def parse_args(argv=None):
     ap.add_argument("--timesteps-global", type=int, default=0, help="strong scaling: length of the global series, sharded over the GPUs "
                     "(BASELINE configs 4 / 5: 2048 / 4096)")
     ap.add_argument("--chunk", type=int, default=0, help="strong scaling: time steps generated + processed at a time per GPU; 0 = the whole "
-                    "shard if it fits in HBM, else 32")
+                    "shard if it fits in HBM, else as many steps as half of the free HBM holds")
     ap.add_argument("--storage", choices=["f64", "f32"], default="f64", help="storage dtype of the field cubes")
     ap.add_argument("--no-q", action="store_true", help="conversion-terms configuration: T,u,v,omega only (no Q, no Phi)")
     ap.add_argument("--cpu-baseline", choices=["full", "quick", "none"], default="full",
@@ -239,8 +239,8 @@ def run_rank(args):
     step_bytes = 5 * nl * lat.size * lon.size * esz
     free_b, _total_b = torch.cuda.mem_get_info(device)
     chunk = args.chunk
-    if chunk <= 0:
-        chunk = T_local if (T_local + 2) * step_bytes * 1.25 < 0.8 * free_b else 32
+    if chunk <= 0:          # the whole shard if it fits (fields + generation temporaries), else as many steps as half of the free HBM holds
+        chunk = T_local if (T_local + 2) * step_bytes * 1.25 < 0.8 * free_b else int(0.5 * free_b / (1.25 * step_bytes)) - 2
     chunk = max(1, min(chunk, T_local))
     chunks = [(a, min(a + chunk, t1)) for a in range(t0, t1, chunk)]
     resident = len(chunks) == 1
