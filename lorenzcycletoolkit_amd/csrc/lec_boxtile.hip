@@ -1,31 +1,32 @@
 // lec_boxtile.hip -- stage 1 for short rows: per-time-step boxes of the moving (semi-Lagrangian) framework.
 //
-// A moving box is ~61 x 61 points per (time, level).  With one wave per 61-point row (lec_rowsweep.hip) the fixed per-row
-// work -- a 20-statistic cross-lane reduction through LDS, the row epilogue, ~450 scalar instructions of row set-up -- is 20 x
-// the useful arithmetic (~1100 instructions per row; 29 % of the HBM roofline in round 1).  Here a 256-thread workgroup owns
-// 16 box rows of one time step and walks a chunk of levels; one PASS = 16 rows x 64 columns of one level:
+// A moving box is ~61 x 61 points per (time, level).  With one wave per 61-point row per level (lec_rowsweep.hip) the fixed
+// per-row work -- a 20-statistic cross-lane reduction, the row epilogue, ~450 scalar instructions of row set-up -- is 20 x the
+// useful arithmetic (~1100 instructions per row; 29 % of the HBM roofline in round 1).  Here ONE WAVE (a 64-thread workgroup: no
+// barriers anywhere) owns four box rows of one time step and walks a chunk of levels; one PASS = 4 rows x 64 columns of one level:
 //
 //   load layout    lanes along longitude, WHOLE BOX ROWS per wave instruction (61 lanes x 8 B = 488 contiguous bytes): the
 //                  access shape the memory system serves best for this pattern (tools/probes/probe_boxread.hip: 4.75 TB/s,
-//                  against 3.0 TB/s for 128-byte column strips and 5.3 TB/s for a contiguous stream).  Wave w owns rows
-//                  4w .. 4w+3 of the pass.  Everything a point's diabatic-heating residual needs is in that lane's registers
-//                  (T at j+-1 are the wave's neighbouring rows, T at i+-1 come from the adjacent lanes by DPP, T at k+-1 from a
-//                  three-level register window that slides down the levels: every T row is loaded ONCE per level chunk), so
-//                  f = Q / cp is formed here, with wave-uniform (scalar) row coefficients;
-//   LDS transpose  only the six shifted values a .. f of a point go to LDS (row stride = 4 mod 32 words, one pad word per
-//                  16 columns: conflict-free both ways).  With uniform longitudes the trapezoid's end points and the lanes
+//                  against 3.0 TB/s for 128-byte column strips and 5.3 TB/s for a contiguous stream).  Everything a point's
+//                  diabatic-heating residual needs is in that lane's registers (T at j+-1 are the wave's neighbouring rows, T at
+//                  i+-1 come from the adjacent lanes by DPP, T at k+-1 from a three-level register window that slides down the
+//                  levels: every T row is loaded ONCE per level chunk), so f = Q / cp is formed here, with wave-uniform row
+//                  coefficients.  The loads of pass p+1 are in flight while pass p is reduced;
+//   LDS transpose  only the six shifted values a .. f of a point go to LDS (row stride = 16 mod 32 words, one pad word per
+//                  4 columns: conflict-free both ways).  With uniform longitudes the trapezoid's end points and the lanes
 //                  outside the box are written as zeros -- they add nothing to any of the 20 monomial sums -- and the two end
 //                  points reach the row's finishing lane through a small side array, so the inner loop is unweighted;
-//   compute layout lane (r, g) of wave w owns row r and columns 16 g + 4 w + (0..3): six LDS reads and the 20 shifted sums
-//                  per point, serially over longitude;
-//   pass end       the four column groups of a row sit in one quad: two DPP quad_perm adds per sum (VALU only, fixed order);
-//                  the four waves' partial sums meet in LDS and 16 lanes of one wave finish the pass's 16 rows, one row per
-//                  lane (end-point terms, scaling, centred statistics) while the other waves already work on the next level.
+//   compute layout lane (r, g) owns row r and columns 4 g + (0..3): six LDS reads and the 20 shifted sums per point;
+//   reduction      the 16 partial sums of a row and statistic meet in LDS (the tiles are dead by then): every lane stores its
+//                  20 partials, lane (row, s) adds the 16 of its row in a fixed order -- ~80 instructions instead of ~240 for a
+//                  DPP butterfly over 16 lanes;
+//   epilogue       every four levels 16 lanes finish 4 levels x 4 rows, one record per lane (end-point terms, scaling, centred
+//                  statistics from the shifted sums).
 //
-// The loads of pass p+1 are in flight while pass p is computed.  Results are deterministic and depend only on the box of the
-// time step (passes, column groups and wave partials are cut in box-relative rows / columns), so sharding / chunking a series
-// changes no bit.  Any box size works: rows wider than 64 columns take several column chunks per level (no level window
-// then: same arithmetic, T neighbours loaded per pass), row blocks of 16 cover any height.
+// Results are deterministic and depend only on the box of the time step (rows, column groups and the summation order are cut in
+// box-relative rows / columns), so sharding / chunking a series changes no bit.  Any box size works: rows wider than 64 columns
+// take several column chunks per level (no level window then: same arithmetic, T neighbours loaded per pass), four-row blocks
+// cover any height.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -44,34 +45,23 @@ using namespace lec;
 
 namespace {
 
-constexpr int kRB = 16;              // rows per pass
+constexpr int kWR = 4;               // box rows per wave = per pass
 constexpr int kCW = 64;              // columns per pass (one wave-wide row segment)
-constexpr int kSF = 68;              // tile row stride in doubles: 64 columns + one pad per 16, = 4 (mod 32)
-constexpr int kTile = kRB * kSF;
+constexpr int kS4 = 80;              // tile row stride in doubles: 64 columns + one pad per 4, = 16 (mod 32)
+constexpr int kTile = kWR * kS4;
 constexpr int kSide = 16;            // per-row side values: 5 shifts, f of the first point, a..f of the last point, T u v at the east column
-constexpr int kLevelChunk = 10;      // levels per workgroup (the T window's prologue is paid once per chunk)
+#ifndef LEC_BT_LEVELS
+#define LEC_BT_LEVELS 10
+#endif
+constexpr int kLevelChunk = LEC_BT_LEVELS;      // levels per wave (the T window's prologue is paid once per chunk)
+constexpr int kLB = 4;               // levels whose rows are finished together (16 lanes: 4 levels x 4 rows)
+constexpr int kPS = 65;              // stride between the statistics of the partial-sum array (odd: conflict-free both ways)
 
 template <bool UNIFORM, int MODE> constexpr int n_tiles() { return (MODE == 0 ? 5 : 6) + (UNIFORM ? 0 : 1); }
-template <bool UNIFORM, int MODE> constexpr int lds_doubles() { return n_tiles<UNIFORM, MODE>() * kTile + 4 * kNA * kRB + 2 * kRB * kSide; }
+template <bool UNIFORM, int MODE> constexpr int lds_doubles() { return n_tiles<UNIFORM, MODE>() * kTile + kLB * kWR * (kNA + kSide); }
+static_assert(kNA * kPS <= 5 * kTile, "the partial sums must fit the (dead) tiles they alias");
 
-__device__ __forceinline__ int pos(int c) { return c + (c >> 4); }      // LDS column of tile column c (one pad per 16 columns)
-
-template <int CTRL>
-__device__ __forceinline__ double quad_swap(double v) {      // every lane of a quad is a valid source: no "old" value to set up
-    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, false);
-    return __hiloint2double(hi, lo);
-}
-// sums over the four lanes of every quad, the same bits in every lane: (x0 + x1) + (x2 + x3); two phases over all values so
-// that independent DPP moves fill each other's hazard slots
-template <int N>
-__device__ __forceinline__ void quad_sums(double (&v)[N]) {
-#pragma clang fp contract(off)
-#pragma unroll
-    for (int s = 0; s < N; ++s) v[s] = v[s] + quad_swap<0xB1>(v[s]);      // quad_perm [1, 0, 3, 2]
-#pragma unroll
-    for (int s = 0; s < N; ++s) v[s] = v[s] + quad_swap<0x4E>(v[s]);      // quad_perm [2, 3, 0, 1]
-}
+__device__ __forceinline__ int pos4(int c) { return c + (c >> 2); }     // LDS column of tile column c (one pad per 4 columns)
 
 // value of lane `src` (wave-uniform) in every lane
 __device__ __forceinline__ double lane_value(double v, int src) {
@@ -105,44 +95,48 @@ __device__ __forceinline__ void finish_lane(const double (&tot)[kNA], double cT,
 }
 
 // MODE 0: T, u, v, omega (Phi if present), no Q;  1: dT/dt = ta T(t-1) + tb T(t) + tc T(t+1) per point;  2: dT/dt cube.
-// WINDOW: rows fit one column chunk, so a workgroup walks its level chunk with T(k-1), T(k), T(k+1) sliding through registers;
+// WINDOW: rows fit one column chunk, so a wave walks its level chunk with T(k-1), T(k), T(k+1) sliding through registers;
 // otherwise every pass loads its own T neighbours (wide boxes; same arithmetic, same bits).
 template <typename TIN, bool UNIFORM, int MODE, bool WINDOW>
-__global__ void __launch_bounds__(256, 2) lec_boxtile_kernel(const RowParams p) {
+__global__ void __launch_bounds__(64, 2) lec_boxtile_kernel(const RowParams p) {
     constexpr bool WITH_Q = MODE != 0;
     constexpr int NT = n_tiles<UNIFORM, MODE>();
+#ifdef LEC_BT_PAD       // measurement builds: extra LDS per wave to cap the resident waves
+    __shared__ double sm[lds_doubles<UNIFORM, MODE>() + LEC_BT_PAD];
+#else
     __shared__ double sm[lds_doubles<UNIFORM, MODE>()];
-    double* const comb = sm + NT * kTile;                 // [4 waves][kNA][16 rows]: partial sums of a pass
-    double* const side = comb + 4 * kNA * kRB;            // [2][16 rows][kSide], double-buffered by level parity
+#endif
+    double* const part = sm;                              // [kNA][kPS]: the lanes' partial sums of a level (aliases the tiles: they are dead by then)
+    double* const stash = sm + NT * kTile;                // [kLB levels][kWR rows][kNA]: row totals waiting for their finishing lane
+    double* const side = stash + kLB * kWR * kNA;         // [kLB levels][kWR rows][kSide]
 
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63;
+    const int lane = threadIdx.x;
 
-    // block -> (time step, level chunk, row block).  Every XCD (blockIdx % 8, speed only) owns a contiguous chunk of time steps
-    // and walks it in groups of tgroup steps: time step fastest, then row block, then level chunk, so the workgroups resident
-    // on an XCD are neighbours in time: the T rows at t+-1 are rows a sibling workgroup loads as its own (L2)
-    const int n_rb = (p.nyb_max + kRB - 1) / kRB;
+    // block -> (time step, level chunk, row block of 4).  Every XCD (blockIdx % 8, speed only) owns a contiguous chunk of time steps
+    // and walks it in groups of tgroup steps: row block fastest (neighbouring blocks share their halo rows), then time step, then
+    // level chunk, so the waves resident on an XCD are neighbours in latitude and time: the T rows at j+-1 (halo) and t+-1 are rows
+    // a sibling loads as its own (L2)
+    const int n_rb = (p.nyb_max + kWR - 1) / kWR;
     const int n_kc = (p.nl + kLevelChunk - 1) / kLevelChunk;
     const int xcd = blockIdx.x & 7;
     int q0 = blockIdx.x >> 3;
-    const int ti = q0 % p.tgroup; q0 /= p.tgroup;
     const int rbi = q0 % n_rb; q0 /= n_rb;
+    const int ti = q0 % p.tgroup; q0 /= p.tgroup;
     const int kc = q0 % n_kc;
     const int tin = (q0 / n_kc) * p.tgroup + ti;          // step inside the XCD's chunk (jchunk = time steps per XCD here)
     const int tl = xcd * p.jchunk + tin;
-    if (tin >= p.jchunk || tl >= p.t_count) return;      // whole workgroup
+    if (tin >= p.jchunk || tl >= p.t_count) return;
 
     const int bi = (p.n_box == 1) ? 0 : tl;
     const int iw = p.box[4 * bi + 0], ie = p.box[4 * bi + 1], js = p.box[4 * bi + 2], jn = p.box[4 * bi + 3];
     const int nxb = ie - iw + 1, nyb = jn - js + 1;
-    const int jb0 = rbi * kRB;
+    const int jb0 = rbi * kWR;
     const int k0 = kc * kLevelChunk, k1 = min(k0 + kLevelChunk, p.nl);
     if (jb0 >= nyb) {       // a row block that holds only padding rows of a box lower than nyb_max
-        const int nrow = min(kRB, p.nyb_max - jb0);
+        const int nrow = min(kWR, p.nyb_max - jb0);
         for (int k = k0; k < k1; ++k) {
             double* rec = p.rows + ((size_t)(tl * p.nl + k) * p.nyb_max + jb0) * LEC_NSTAT;
-            for (int e = tid; e < nrow * LEC_NSTAT; e += 256) rec[e] = 0.0;
+            for (int e = lane; e < nrow * LEC_NSTAT; e += 64) rec[e] = 0.0;
         }
         return;
     }
@@ -164,18 +158,18 @@ __global__ void __launch_bounds__(256, 2) lec_boxtile_kernel(const RowParams p) 
     if (MODE == 1) { const double* tcf = p.tcoef + (size_t)t * 3; ta = tcf[0]; tb = tcf[1]; tc = tcf[2]; }
     // Row / level coefficients are wave-uniform, but inside the pass loop (which stores row records) the compiler would fetch them
     // with VECTOR loads followed by s_waitcnt vmcnt(0) -- draining the prefetched rows every time.  So they are loaded once, here,
-    // spread over the lanes, and picked with v_readlane inside the loop:
+    // spread over the lanes, and picked with v_readlane:
     //   latv: lane 4 i + j = coefficient j (d/dlat a, b, c; 1/dx) of the wave's row i;  levv: lane 3 kk + j = static-stability
     //   coefficient j of level k0 + kk
     double latv = 0.0, levv = 0.0;
     if (WITH_Q) {
-        const int jrow = min(jb0 + 4 * wave + ((lane >> 2) & 3), nyb - 1);
+        const int jrow = min(jb0 + ((lane >> 2) & 3), nyb - 1);
         latv = p.lattab[((size_t)bi * p.nyb_max + jrow) * 4 + (lane & 3)];
         levv = p.levtab[(size_t)min(k0 + lane / 3, p.nl - 1) * 3 + lane % 3];
     }
-    double lga[4], lgb[4], lgc[4], lidx[4];               // the wave's four rows (the same for every level): wave-uniform
+    double lga[kWR], lgb[kWR], lgc[kWR], lidx[kWR];       // the wave's rows (the same for every level): wave-uniform
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < kWR; ++i) {
         lga[i] = lane_value(latv, 4 * i); lgb[i] = lane_value(latv, 4 * i + 1); lgc[i] = lane_value(latv, 4 * i + 2);
         lidx[i] = lane_value(latv, 4 * i + 3);
     }
@@ -186,23 +180,23 @@ __global__ void __launch_bounds__(256, 2) lec_boxtile_kernel(const RowParams p) 
     const int ncc = WINDOW ? 1 : (nxb + kCW - 1) / kCW;   // column chunks per row
     const int npass = (k1 - k0) * ncc;
 
-    // element offsets (inside a level plane) of the wave's rows: rows -1 .. 4 relative to 4 w, clamped into the box
-    unsigned roff[6];
+    // element offsets (inside a level plane) of the wave's rows: rows -1 .. 4 relative to its first, clamped into the box
+    unsigned roff[kWR + 2];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) roff[i] = (unsigned)__builtin_amdgcn_readfirstlane((js + min(max(jb0 + 4 * wave + i - 1, 0), nyb - 1)) * p.nx);
+    for (int i = 0; i < kWR + 2; ++i) roff[i] = (unsigned)__builtin_amdgcn_readfirstlane((js + min(max(jb0 + i - 1, 0), nyb - 1)) * p.nx);
 
     // ---- registers of the load layout.  T window: Tn = level k+1 (rows -1 .. 4), Tc = level k, Tm = level k-1 (rows 0 .. 3);
     // En / Ec: T at the columns just outside the chunk (lanes 0..31: c0 - 1, lanes 32..63: c0 + 64) of the centre rows at k+1 / k
-    TIN Tn[6], Tc[6], Tm[4], En[4] = {}, Ec[4] = {}, rU[4], rV[4], rW[4], rP[4], rD0[4], rD1[4];
+    TIN Tn[kWR + 2], Tc[kWR + 2], Tm[kWR], En[kWR] = {}, Ec[kWR] = {}, rU[kWR], rV[kWR], rW[kWR], rP[kWR], rD0[kWR], rD1[kWR];
     double rWl = 0.0, rG[3] = {0.0, 0.0, 0.0};            // non-uniform longitudes: the lane's trapezoid weight and d/dlon coefficients
     if (LEC_BT_ABLATE & 2) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) { Tn[i] = (TIN)(281 + lane + i); Tc[i] = (TIN)(280 + lane + i); }
+        for (int i = 0; i < kWR + 2; ++i) { Tn[i] = (TIN)(281 + lane + i); Tc[i] = (TIN)(280 + lane + i); }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { Tm[i] = (TIN)(279 + lane); En[i] = Ec[i] = (TIN)280; rU[i] = (TIN)lane; rV[i] = (TIN)i; rW[i] = (TIN)0.1; rP[i] = (TIN)(lane * i); rD0[i] = rD1[i] = (TIN)(281 + lane); }
+        for (int i = 0; i < kWR; ++i) { Tm[i] = (TIN)(279 + lane); En[i] = Ec[i] = (TIN)280; rU[i] = (TIN)lane; rV[i] = (TIN)i; rW[i] = (TIN)0.1; rP[i] = (TIN)(lane * i); rD0[i] = rD1[i] = (TIN)(281 + lane); }
     }
     auto lev = [&](int k) -> size_t { return (size_t)min(max(k, 0), p.nl - 1) * plane; };
-    // wave-uniform row pointer + the lane's 32-bit element offset: "global_load v, v_off, s[base]" (no 64-bit address per lane)
+    // wave-uniform row pointer + the lane's 32-bit element offset
     auto ld = [](const TIN* __restrict__ row, unsigned off) -> TIN {
         return *reinterpret_cast<const TIN*>(reinterpret_cast<const char*>(row) + off * (unsigned)sizeof(TIN));
     };
@@ -223,24 +217,24 @@ __global__ void __launch_bounds__(256, 2) lec_boxtile_kernel(const RowParams p) 
         if (WITH_Q) {
             const size_t lp = lev(k + 1);
 #pragma unroll
-            for (int i = 0; i < 6; ++i) Tn[i] = ld(gT + lp + roff[i], col);
+            for (int i = 0; i < kWR + 2; ++i) Tn[i] = ld(gT + lp + roff[i], col);
             if (!WINDOW) {      // one column chunk: the columns just outside it are outside the box and never used (one-sided ends)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) En[i] = ld(gT + lp + roff[i + 1], ecol);
+                for (int i = 0; i < kWR; ++i) En[i] = ld(gT + lp + roff[i + 1], ecol);
             }
             if (fresh) {
                 const size_t lm = lev(k - 1);
 #pragma unroll
-                for (int i = 0; i < 6; ++i) Tc[i] = ld(gT + lk + roff[i], col);
+                for (int i = 0; i < kWR + 2; ++i) Tc[i] = ld(gT + lk + roff[i], col);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { Tm[i] = ld(gT + lm + roff[i + 1], col); if (!WINDOW) Ec[i] = ld(gT + lk + roff[i + 1], ecol); }
+                for (int i = 0; i < kWR; ++i) { Tm[i] = ld(gT + lm + roff[i + 1], col); if (!WINDOW) Ec[i] = ld(gT + lk + roff[i + 1], ecol); }
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) Tc[i + 1] = ld(gT + lk + roff[i + 1], col);
+            for (int i = 0; i < kWR; ++i) Tc[i + 1] = ld(gT + lk + roff[i + 1], col);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < kWR; ++i) {
             const size_t o = lk + roff[i + 1];
             rU[i] = ldnt(gU + o, col);
             rV[i] = ldnt(gV + o, col);
@@ -253,22 +247,19 @@ __global__ void __launch_bounds__(256, 2) lec_boxtile_kernel(const RowParams p) 
         }
     };
 
-    // ---- compute-layout roles: lane -> (row r of the pass, column group g)
-    const int cr = lane >> 2, cg = lane & 3;
+    // ---- compute-layout roles: lane -> (row ci of the wave's four, column group cg of sixteen)
+    const int ci = lane >> 4, cg = lane & 15;
     double acc[kNA];
 #pragma unroll
     for (int s = 0; s < kNA; ++s) acc[s] = 0.0;
-    double cT[4], cU[4], cV[4], cW[4], cP[4];              // shifts of the wave's four rows: the row's first box element
+    double cT[kWR], cU[kWR], cV[kWR], cW[kWR], cP[kWR];    // shifts of the wave's rows: the row's first box element
 
     issue_loads(k0, 0, true);
-    if (WINDOW) {
-        for (int e = tid; e < NT * kTile; e += 256) sm[e] = 0.0;
-        __syncthreads();
-    }
     for (int ps = 0; ps < npass; ++ps) {
         const int kk = ps / ncc, cc = ps - kk * ncc, k = k0 + kk, c0 = cc * kCW;
-        double* const sd = side + (kk & 1) * kRB * kSide;        // by level parity: a row's side values are gathered over its column chunks
-        // ================= load layout: one point per lane, rows 4w .. 4w+3 =================
+        const int slot = kk % kLB;
+        double* const sd = side + slot * kWR * kSide;
+        // ================= load layout: one point per lane, the wave's four rows =================
         {
 #pragma clang fp contract(off)
             const int e = c0 + lane;
@@ -281,8 +272,7 @@ __global__ void __launch_bounds__(256, 2) lec_boxtile_kernel(const RowParams p) 
             const double wgt = UNIFORM ? 0.0 : (inside ? rWl : 0.0);
             const double g0 = rG[0], g1 = rG[1], g2 = rG[2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = 4 * wave + i;                    // row of the pass
+            for (int i = 0; i < kWR; ++i) {
                 const double T = (double)Tc[i + 1], U = (double)rU[i], V = (double)rV[i], W = (double)rW[i];
                 const double P = (WITH_Q || has_p) ? (has_p ? (double)rP[i] : 0.0) : 0.0;
                 if (cc == 0) {                                 // the row's first box element is lane 0 of the first chunk
@@ -307,27 +297,16 @@ __global__ void __launch_bounds__(256, 2) lec_boxtile_kernel(const RowParams p) 
                     f = fma(-W, sS, fma(V, sP_, dTdt + adv));
                 }
                 const double a = T - cT[i], b = U - cU[i], c = V - cV[i], d = W - cW[i], ee = P - cP[i];
-                const int dst = r * kSF + pos(lane);
-                if (WINDOW) {
-                    // one column chunk: the lanes that contribute nothing are the same in every pass; their tile entries were
-                    // zeroed once before the loop and are never written
-                    if (!zero) {
-                        sm[0 * kTile + dst] = a; sm[1 * kTile + dst] = b; sm[2 * kTile + dst] = c; sm[3 * kTile + dst] = d;
-                        sm[4 * kTile + dst] = ee;
-                        if (WITH_Q) sm[5 * kTile + dst] = f;
-                        if (!UNIFORM) sm[(NT - 1) * kTile + dst] = wgt;
-                    }
-                } else {
-                    sm[0 * kTile + dst] = zero ? 0.0 : a;
-                    sm[1 * kTile + dst] = zero ? 0.0 : b;
-                    sm[2 * kTile + dst] = zero ? 0.0 : c;
-                    sm[3 * kTile + dst] = zero ? 0.0 : d;
-                    sm[4 * kTile + dst] = zero ? 0.0 : ee;
-                    if (WITH_Q) sm[5 * kTile + dst] = zero ? 0.0 : f;
-                    if (!UNIFORM) sm[(NT - 1) * kTile + dst] = wgt;
-                }
+                const int dst = i * kS4 + pos4(lane);
+                sm[0 * kTile + dst] = zero ? 0.0 : a;
+                sm[1 * kTile + dst] = zero ? 0.0 : b;
+                sm[2 * kTile + dst] = zero ? 0.0 : c;
+                sm[3 * kTile + dst] = zero ? 0.0 : d;
+                sm[4 * kTile + dst] = zero ? 0.0 : ee;
+                if (WITH_Q) sm[5 * kTile + dst] = zero ? 0.0 : f;
+                if (!UNIFORM) sm[(NT - 1) * kTile + dst] = wgt;
                 // the row's side values for its finishing lane
-                double* sr = sd + r * kSide;
+                double* sr = sd + i * kSide;
                 if (cc == 0 && lane == 0) { sr[0] = cT[i]; sr[1] = cU[i]; sr[2] = cV[i]; sr[3] = cW[i]; sr[4] = cP[i]; sr[5] = f; }
                 if (has_last && lane == llast) {
                     sr[6] = a; sr[7] = b; sr[8] = c; sr[9] = d; sr[10] = ee; sr[11] = f;
@@ -336,22 +315,22 @@ __global__ void __launch_bounds__(256, 2) lec_boxtile_kernel(const RowParams p) 
             }
             if (WITH_Q && WINDOW) {       // slide the window one level down
 #pragma unroll
-                for (int i = 0; i < 4; ++i) Tm[i] = Tc[i + 1];
+                for (int i = 0; i < kWR; ++i) Tm[i] = Tc[i + 1];
 #pragma unroll
-                for (int i = 0; i < 6; ++i) Tc[i] = Tn[i];
+                for (int i = 0; i < kWR + 2; ++i) Tc[i] = Tn[i];
             }
         }
-        __syncthreads();
+        row_sync<64>();                    // one wave: its LDS operations are processed in order; only the compiler must not reorder them
         if (ps + 1 < npass) {              // in flight while this pass is reduced
             const int kn = (ps + 1) / ncc, cn = (ps + 1) - kn * ncc;
             issue_loads(k0 + kn, cn * kCW, !WINDOW);
         }
-        // ================= compute layout: lane (cr, cg), columns 16 cg + 4 wave + q =================
+        // ================= compute layout: lane (ci, cg), columns 4 cg + q =================
         if (!(LEC_BT_ABLATE & 1)) {
 #pragma clang fp contract(off)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int src = cr * kSF + 17 * cg + 4 * wave + q;      // = row * stride + pos(16 cg + 4 wave + q)
+                const int src = ci * kS4 + 5 * cg + q;      // = row * stride + pos4(4 cg + q)
                 const double a = sm[0 * kTile + src], b = sm[1 * kTile + src], c = sm[2 * kTile + src], d = sm[3 * kTile + src];
                 const double ee = sm[4 * kTile + src];
                 const double f = WITH_Q ? sm[5 * kTile + src] : 0.0;
@@ -359,37 +338,43 @@ __global__ void __launch_bounds__(256, 2) lec_boxtile_kernel(const RowParams p) 
                 else accum20<false>(acc, sm[(NT - 1) * kTile + src], a, b, c, d, ee, f);
             }
         }
-        const bool row_done = cc == ncc - 1;
-        if (row_done && !(LEC_BT_ABLATE & 8)) {      // the level's rows are complete: the four column groups of a row sit in one quad
-            quad_sums(acc);
-            if (cg == 0) {
-#pragma unroll
-                for (int s = 0; s < kNA; ++s) comb[(wave * kNA + s) * kRB + cr] = acc[s];
-            }
-#pragma unroll
-            for (int s = 0; s < kNA; ++s) acc[s] = 0.0;
-        }
-        __syncthreads();
-        // the four waves' partial sums of the pass, added in a fixed order; one row per lane: 16 lanes of one wave finish the
-        // pass's rows while the other waves already work on the next pass
-        if (row_done && wave == (kk & 3) && lane < kRB && !(LEC_BT_ABLATE & 4)) {
+        const bool row_done = (cc == ncc - 1);
+        if (row_done && !(LEC_BT_ABLATE & 8)) {
+            // the level's rows are complete: 16 partial sums per row and statistic -> one total, through LDS (the tiles are dead):
+            // every lane stores its 20 partials, then lane (row, s) adds the 16 of its row in a fixed order (stride 65: no bank
+            // conflicts either way)
 #pragma clang fp contract(off)
-            const int jb = jb0 + lane;
-            if (jb < p.nyb_max) {
-                dbl2_t* __restrict__ out = reinterpret_cast<dbl2_t*>(p.rows + ((size_t)(tl * p.nl + k) * p.nyb_max + jb) * LEC_NSTAT);
+            row_sync<64>();
+#pragma unroll
+            for (int s = 0; s < kNA; ++s) { part[s * kPS + lane] = acc[s]; acc[s] = 0.0; }
+            row_sync<64>();
+            const double* p0 = part + cg * kPS + ci * 16;               // statistic cg of row ci
+            const double* p1 = part + (min(cg, 3) + 16) * kPS + ci * 16; // statistic 16 + cg (cg < 4)
+            double t0 = p0[0], t1 = p1[0];
+#pragma unroll
+            for (int g = 1; g < 16; ++g) { t0 += p0[g]; t1 += p1[g]; }
+            double* st = stash + (slot * kWR + ci) * kNA;
+            st[cg] = t0;
+            if (cg < 4) st[16 + cg] = t1;
+            row_sync<64>();
+        }
+        // ---- up to kLB finished levels x 4 rows: one (level, row) per lane finishes its record
+        if (row_done && (slot == kLB - 1 || k == k1 - 1) && !(LEC_BT_ABLATE & 4)) {
+#pragma clang fp contract(off)
+            const int lv = lane >> 2, r = lane & 3;
+            const int jb = jb0 + r;
+            if (lv <= slot && jb < p.nyb_max) {
+                const int kout = k - slot + lv;
+                dbl2_t* __restrict__ out = reinterpret_cast<dbl2_t*>(p.rows + ((size_t)(tl * p.nl + kout) * p.nyb_max + jb) * LEC_NSTAT);
                 double o[LEC_NSTAT];
 #pragma unroll
                 for (int s = 0; s < LEC_NSTAT; ++s) o[s] = 0.0;
                 if (jb < nyb) {
-                    const double* sr = sd + lane * kSide;
+                    const double* sr = side + (lv * kWR + r) * kSide;
+                    const double* st = stash + (lv * kWR + r) * kNA;
                     double tot[kNA];
 #pragma unroll
-                    for (int s = 0; s < kNA; ++s) {
-                        double a = comb[s * kRB + lane];
-#pragma unroll
-                        for (int w2 = 1; w2 < 4; ++w2) a += comb[(w2 * kNA + s) * kRB + lane];
-                        tot[s] = a;
-                    }
+                    for (int s = 0; s < kNA; ++s) tot[s] = st[s];
                     double scale = inv_xlen;
                     if (UNIFORM) {
                         // the trapezoid's end points, weight 1/2 each: the first point has a = b = c = d = e = 0 (it is the shift),
@@ -414,13 +399,14 @@ __global__ void __launch_bounds__(256, 2) lec_boxtile_kernel(const RowParams p) 
 #pragma unroll
                 for (int s = 0; s < LEC_NSTAT / 2; ++s) { dbl2_t v2; v2.x = o[2 * s]; v2.y = o[2 * s + 1]; out[s] = v2; }
             }
+            row_sync<64>();
         }
     }
 }
 
 template <typename TIN>
 int launch_tiles(RowParams p, bool uniform, int mode, hipStream_t st) {
-    const long long n_rb = (p.nyb_max + kRB - 1) / kRB, n_kc = (p.nl + kLevelChunk - 1) / kLevelChunk;
+    const long long n_rb = (p.nyb_max + kWR - 1) / kWR, n_kc = (p.nl + kLevelChunk - 1) / kLevelChunk;
     p.jchunk = (p.t_count + 7) / 8;                       // time steps per XCD
     if (p.tgroup < 1) p.tgroup = 8;
     if (p.tgroup > p.jchunk) p.tgroup = p.jchunk;
@@ -428,7 +414,7 @@ int launch_tiles(RowParams p, bool uniform, int mode, hipStream_t st) {
     const long long nblocks = 8LL * tgroups * p.tgroup * n_rb * n_kc;
     if (nblocks > 0x7fffffffLL) return LEC_ERR_UNSUPPORTED;
     if ((unsigned long long)p.ny * (unsigned long long)p.nx > 0xffffffffULL) return LEC_ERR_UNSUPPORTED;     // 32-bit offsets inside a plane
-    dim3 grid((unsigned)nblocks), block(256);
+    dim3 grid((unsigned)nblocks), block(64);
     const bool window = mode != 0 && p.nxb_max <= kCW;    // same arithmetic either way: only where the T neighbours come from differs
 #define LEC_TILE(U, M, W) hipLaunchKernelGGL((lec_boxtile_kernel<TIN, U, M, W>), grid, block, 0, st, p)
 #define LEC_TILE_W(U, M) do { if (window) LEC_TILE(U, M, true); else LEC_TILE(U, M, false); } while (0)
