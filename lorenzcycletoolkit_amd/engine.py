@@ -89,6 +89,7 @@ class LECEngine:
         self._levtab = self._up(levtab)
         self._levtab2 = self._up(levtab2)
         self._box_cache = {}
+        self._work = {}        # stage-2 workspaces by shape: am, levraw, dropmask (true scratch: never handed out)
 
     # -- helpers ---------------------------------------------------------------------------
     def _up(self, a: np.ndarray, dtype=torch.float64) -> torch.Tensor:
@@ -232,14 +233,21 @@ class LECEngine:
         if rows.shape != (t_count, self.level.size, bt.nyb_max, _lib.LEC_NSTAT) or rows.dtype != torch.float64 or not rows.is_contiguous():
             raise ValueError("rows must be a contiguous fp64 [t_count, nl, nyb_max, 32] tensor")
         f64 = dict(dtype=torch.float64, device=rows.device)
-        am = torch.empty((t_count, nl, 8), **f64)
-        levraw = torch.empty((t_count, nl, _lib.LEC_NLEVRAW), **f64)
+        # the two workspaces are scratch of this call only (stream-ordered: the next call on the stream may reuse them); the outputs
+        # are fresh tensors, they belong to the caller
+        wkey = (t_count, nl, str(rows.device))
+        if wkey not in self._work:
+            if len(self._work) > 4:
+                self._work.clear()
+            self._work[wkey] = (torch.empty((t_count, nl, 8), **f64), torch.empty((t_count, nl, _lib.LEC_NLEVRAW), **f64),
+                                torch.empty((_lib.LEC_NLEVFUN, nl), dtype=torch.int32, device=rows.device))
+        am, levraw, dropmask_ws = self._work[wkey]
         scalars = torch.empty((t_count, _lib.LEC_NSCALAR), **f64)
         levels = torch.empty((t_count, _lib.LEC_NLEVTAB, nl), **f64)
         nanflag = torch.empty((t_count,), dtype=torch.int32, device=rows.device)
         if drop_any_time is None:
             drop_any_time = len(boxes) == 1
-        dropmask = torch.empty((_lib.LEC_NLEVFUN, nl), dtype=torch.int32, device=rows.device) if drop_any_time else None
+        dropmask = dropmask_ws if drop_any_time else None
         stream = C.c_void_p(torch.cuda.current_stream(rows.device).cuda_stream)
         mode = 0 if not drop_any_time else (2 if merge_dropmask is not None else 1)
         rd = _lib.ReduceArgs(

@@ -147,3 +147,40 @@ def test_moving_framework_streamed_equals_resident(workdir, golden_dir):
         st.raw.close()
         assert torch.equal(a.scalars, b.scalars) and torch.equal(a.levels, b.levels), chunk
     assert torch.isfinite(a.scalars).all()
+
+
+def test_mixed_dtype_file_on_both_paths(workdir):
+    """A file that mixes dtypes -- float32 T, u, v, w with an int16-packed geopotential that has an add_offset but no fill value
+    (float64 in the reference's decode) -- used to fail in the resident path ('all field cubes must share ... dtype').
+    Both paths promote the five cubes to the widest dtype (exact) and agree bit for bit."""
+    from scipy.io import netcdf_file
+    rng = np.random.default_rng(9)
+    nt, lev, lat, lon = 4, np.array([1000.0, 850.0, 700.0, 500.0, 300.0]), np.linspace(-50, -20, 13), np.linspace(-70, -30, 17)
+    path = str(workdir / "mixed.nc")
+    f = netcdf_file(path, "w", version=2)
+    for n, s in (("time", nt), ("level", lev.size), ("lat", lat.size), ("lon", lon.size)):
+        f.createDimension(n, s)
+    tv = f.createVariable("time", "d", ("time",)); tv[:] = 6.0 * np.arange(nt); tv.units = "hours since 2001-01-01 00:00:00"
+    lv = f.createVariable("level", "d", ("level",)); lv[:] = lev; lv.units = "hPa"
+    f.createVariable("lat", "d", ("lat",))[:] = lat
+    f.createVariable("lon", "d", ("lon",))[:] = lon
+    p = lev[None, :, None, None] / 1000.0
+    shp = (nt, lev.size, lat.size, lon.size)
+    fields = {"t": 288 * p ** 0.19 + rng.standard_normal(shp), "u": 10 + 5 * rng.standard_normal(shp), "v": 3 * rng.standard_normal(shp),
+              "w": 0.1 * rng.standard_normal(shp)}
+    for name, a in fields.items():
+        f.createVariable(name, "f", ("time", "level", "lat", "lon"))[:] = a.astype(np.float32)
+    z = 9.80665 * 7000 * np.log(1 / p) + 80 * rng.standard_normal(shp)
+    scale, off = (z.max() - z.min()) / 65000.0, 0.5 * (z.max() + z.min())
+    zv = f.createVariable("z", "h", ("time", "level", "lat", "lon"))
+    zv[:] = np.clip(np.round((z - off) / scale), -32000, 32000).astype(np.int16)
+    zv.scale_factor = float(scale); zv.add_offset = float(off)
+    f.close()
+    (workdir / "inputs" / "namelist").write_text(
+        ";Variable;Units\\nAir Temperature;t;K\\nGeopotential;z;m**2/s**2\\nOmega Velocity;w;Pa/s\\n"
+        "Eastward Wind Component;u;m/s\\nNorthward Wind Component;v;m/s\\nLongitude;lon\\nLatitude;lat\\nTime;time\\nVertical Level;level\\n")
+    limits = (-65.0, -35.0, -45.0, -25.0)
+    (workdir / "inputs" / "box_limits").write_text("min_lon;-65\\nmax_lon;-35\\nmin_lat;-45\\nmax_lat;-25\\n")
+    a, b, stats = _both_paths(path, "inputs/namelist", limits, 2)
+    assert stats["storage"] == "float64" and stats["decode"]["tair"] == "float32" and stats["decode"]["geopt"] == "float64"
+    assert torch.equal(a.scalars, b.scalars) and torch.equal(a.levels, b.levels) and torch.isfinite(a.scalars).all()
