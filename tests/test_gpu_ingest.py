@@ -177,10 +177,10 @@ def test_mixed_dtype_file_on_both_paths(workdir):
     zv.scale_factor = float(scale); zv.add_offset = float(off)
     f.close()
     (workdir / "inputs" / "namelist").write_text(
-        ";Variable;Units\\nAir Temperature;t;K\\nGeopotential;z;m**2/s**2\\nOmega Velocity;w;Pa/s\\n"
-        "Eastward Wind Component;u;m/s\\nNorthward Wind Component;v;m/s\\nLongitude;lon\\nLatitude;lat\\nTime;time\\nVertical Level;level\\n")
+        ";Variable;Units\nAir Temperature;t;K\nGeopotential;z;m**2/s**2\nOmega Velocity;w;Pa/s\n"
+        "Eastward Wind Component;u;m/s\nNorthward Wind Component;v;m/s\nLongitude;lon\nLatitude;lat\nTime;time\nVertical Level;level\n")
     limits = (-65.0, -35.0, -45.0, -25.0)
-    (workdir / "inputs" / "box_limits").write_text("min_lon;-65\\nmax_lon;-35\\nmin_lat;-45\\nmax_lat;-25\\n")
+    (workdir / "inputs" / "box_limits").write_text("min_lon;-65\nmax_lon;-35\nmin_lat;-45\nmax_lat;-25\n")
     a, b, stats = _both_paths(path, "inputs/namelist", limits, 2)
     assert stats["storage"] == "float64" and stats["decode"]["tair"] == "float32" and stats["decode"]["geopt"] == "float64"
     assert torch.equal(a.scalars, b.scalars) and torch.equal(a.levels, b.levels) and torch.isfinite(a.scalars).all()
