@@ -30,6 +30,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/lec_hip.h"
 #include "lec_internal.h"
 #include "lec_rowcommon.h"
@@ -41,6 +43,9 @@ using namespace lec;
 // 8 = no quad reduction / hand-over, 16 = no load-layout arithmetic (values straight to LDS)
 #ifndef LEC_BT_ABLATE
 #define LEC_BT_ABLATE 0
+#endif
+#ifndef LEC_BT_QUNROLL      // unroll factor of the compute layout's column loop (register pressure against LDS-read latency)
+#define LEC_BT_QUNROLL 2
 #endif
 
 namespace {
@@ -187,13 +192,19 @@ __global__ void __launch_bounds__(64, 2) lec_boxtile_kernel(const RowParams p) {
 
     // ---- registers of the load layout.  T window: Tn = level k+1 (rows -1 .. 4), Tc = level k, Tm = level k-1 (rows 0 .. 3);
     // En / Ec: T at the columns just outside the chunk (lanes 0..31: c0 - 1, lanes 32..63: c0 + 64) of the centre rows at k+1 / k
-    TIN Tn[kWR + 2], Tc[kWR + 2], Tm[kWR], En[kWR] = {}, Ec[kWR] = {}, rU[kWR], rV[kWR], rW[kWR], rP[kWR], rD0[kWR], rD1[kWR];
+    // The streamed operands u, v, omega are prefetched TWO passes ahead (two register sets, picked by pass parity at compile time):
+    // the kernel is bound by how many loads a CU keeps in flight, and these 12 loads per pass do not depend on the window (Phi
+    // stays one pass ahead: a fourth double set would spill).
+    TIN Tn[kWR + 2], Tc[kWR + 2], Tm[kWR], En[kWR] = {}, Ec[kWR] = {}, sU[2][kWR], sV[2][kWR], sW[2][kWR], rP[kWR], rD0[kWR], rD1[kWR];
     double rWl = 0.0, rG[3] = {0.0, 0.0, 0.0};            // non-uniform longitudes: the lane's trapezoid weight and d/dlon coefficients
     if (LEC_BT_ABLATE & 2) {
 #pragma unroll
         for (int i = 0; i < kWR + 2; ++i) { Tn[i] = (TIN)(281 + lane + i); Tc[i] = (TIN)(280 + lane + i); }
 #pragma unroll
-        for (int i = 0; i < kWR; ++i) { Tm[i] = (TIN)(279 + lane); En[i] = Ec[i] = (TIN)280; rU[i] = (TIN)lane; rV[i] = (TIN)i; rW[i] = (TIN)0.1; rP[i] = (TIN)(lane * i); rD0[i] = rD1[i] = (TIN)(281 + lane); }
+        for (int i = 0; i < kWR; ++i) {
+            Tm[i] = (TIN)(279 + lane); En[i] = Ec[i] = (TIN)280; rD0[i] = rD1[i] = (TIN)(281 + lane);
+            sU[0][i] = sU[1][i] = (TIN)lane; sV[0][i] = sV[1][i] = (TIN)i; sW[0][i] = sW[1][i] = (TIN)0.1; rP[i] = (TIN)(lane * i);
+        }
     }
     auto lev = [&](int k) -> size_t { return (size_t)min(max(k, 0), p.nl - 1) * plane; };
     // wave-uniform row pointer + the lane's 32-bit element offset
@@ -236,14 +247,26 @@ __global__ void __launch_bounds__(64, 2) lec_boxtile_kernel(const RowParams p) {
 #pragma unroll
         for (int i = 0; i < kWR; ++i) {
             const size_t o = lk + roff[i + 1];
-            rU[i] = ldnt(gU + o, col);
-            rV[i] = ldnt(gV + o, col);
-            rW[i] = ldnt(gW + o, col);
             if (WITH_Q || has_p) rP[i] = ldnt(gP + o, col);
             if (WITH_Q) {
                 rD0[i] = ld(gD0 + o, col);
                 if (MODE == 1) rD1[i] = ld(gD1 + o, col);
             }
+        }
+    };
+    // u, v, omega of pass `ps` (level, column chunk) into register set SET
+    auto issue_stream = [&](auto set_tag, const int ps) {
+        constexpr int SET = decltype(set_tag)::value;
+        if (LEC_BT_ABLATE & 2) return;
+        const int kn = ps / ncc, c0 = (ps - kn * ncc) * kCW;
+        const unsigned col = (unsigned)min(c0 + lane, nxb - 1);
+        const size_t lk = lev(k0 + kn);
+#pragma unroll
+        for (int i = 0; i < kWR; ++i) {
+            const size_t o = lk + roff[i + 1];
+            sU[SET][i] = ldnt(gU + o, col);
+            sV[SET][i] = ldnt(gV + o, col);
+            sW[SET][i] = ldnt(gW + o, col);
         }
     };
 
@@ -255,7 +278,11 @@ __global__ void __launch_bounds__(64, 2) lec_boxtile_kernel(const RowParams p) {
     double cT[kWR], cU[kWR], cV[kWR], cW[kWR], cP[kWR];    // shifts of the wave's rows: the row's first box element
 
     issue_loads(k0, 0, true);
-    for (int ps = 0; ps < npass; ++ps) {
+    issue_stream(std::integral_constant<int, 0>{}, 0);
+    if (npass > 1) issue_stream(std::integral_constant<int, 1>{}, 1);
+    auto pass = [&](auto set_tag, const int ps) {
+        constexpr int SET = decltype(set_tag)::value;
+        const TIN (&rU)[kWR] = sU[SET]; const TIN (&rV)[kWR] = sV[SET]; const TIN (&rW)[kWR] = sW[SET];
         const int kk = ps / ncc, cc = ps - kk * ncc, k = k0 + kk, c0 = cc * kCW;
         const int slot = kk % kLB;
         double* const sd = side + slot * kWR * kSide;
@@ -321,14 +348,15 @@ __global__ void __launch_bounds__(64, 2) lec_boxtile_kernel(const RowParams p) {
             }
         }
         row_sync<64>();                    // one wave: its LDS operations are processed in order; only the compiler must not reorder them
-        if (ps + 1 < npass) {              // in flight while this pass is reduced
+        if (ps + 1 < npass) {              // in flight while this pass is reduced: the window rows and dT/dt operands of the next pass ...
             const int kn = (ps + 1) / ncc, cn = (ps + 1) - kn * ncc;
             issue_loads(k0 + kn, cn * kCW, !WINDOW);
         }
+        if (ps + 2 < npass) issue_stream(set_tag, ps + 2);      // ... and the streamed operands of the pass after it, into the set just consumed
         // ================= compute layout: lane (ci, cg), columns 4 cg + q =================
         if (!(LEC_BT_ABLATE & 1)) {
 #pragma clang fp contract(off)
-#pragma unroll
+#pragma unroll LEC_BT_QUNROLL
             for (int q = 0; q < 4; ++q) {
                 const int src = ci * kS4 + 5 * cg + q;      // = row * stride + pos4(4 cg + q)
                 const double a = sm[0 * kTile + src], b = sm[1 * kTile + src], c = sm[2 * kTile + src], d = sm[3 * kTile + src];
@@ -401,6 +429,10 @@ __global__ void __launch_bounds__(64, 2) lec_boxtile_kernel(const RowParams p) {
             }
             row_sync<64>();
         }
+    };
+    for (int ps = 0; ps < npass; ps += 2) {
+        pass(std::integral_constant<int, 0>{}, ps);
+        if (ps + 1 < npass) pass(std::integral_constant<int, 1>{}, ps + 1);
     }
 }
 
