@@ -202,6 +202,31 @@ def test_config5_shape_moving_boxes(dtype):
     _rows_close(res, sweep, "box tiles vs one wave per row, 61 x 61 boxes")
 
 
+@pytest.mark.parametrize("nonuni", [False, True])
+def test_moving_boxes_of_mixed_widths_shard_bit_identically(nonuni):
+    """A track whose boxes are 40 to 90 columns wide.  The box-tile kernel keeps the level window in registers only when every row of
+    the CALL fits one 64-column chunk; a shard that holds just the narrow boxes takes that instantiation, the whole series the other
+    one -- same arithmetic, so the records must agree bit for bit (as must the oracle, to rounding)."""
+    nt = 6
+    dom = synthetic_domain(nt, 7, 50, 120, seed=91, nonuniform_lon=nonuni, lon0=-80.0, lon1=-20.5)
+    widths = [40, 90, 50, 64, 65, 30]           # grid columns
+    j0 = [3, 5, 8, 10, 6, 2]
+    i0 = [5, 10, 20, 30, 12, 70]
+    boxes = [(i, i + w - 1, j, j + 20 + t) for t, (i, j, w) in enumerate(zip(i0, j0, widths))]
+    limits = [(dom.lon[b[0]], dom.lon[b[1]], dom.lat[b[2]], dom.lat[b[3]]) for b in boxes]
+    eng = _engine(dom)
+    assert [eng.box_from_limits(*lim) for lim in limits] == boxes
+    f = [_dev(a) for a in (dom.tair, dom.u, dom.v, dom.omega, dom.geopt)]
+    whole = eng.compute(*f, boxes, time_s=dom.time_s, keep_rows=True)
+    ref_s, ref_l = o.lec_moving(dom, limits)
+    compare(whole.scalars_dict(), whole.levels_dict(), ref_s, ref_l, TOL, "mixed widths")
+    for a, b in ((0, 1), (2, 4), (5, 6), (0, 3)):
+        part = eng.compute(*f, boxes[a:b], time_s=dom.time_s, t_begin=a, t_count=b - a, keep_rows=True, per_step_boxes=True)
+        ny = part.rows.shape[2]
+        assert torch.equal(part.rows, whole.rows[a:b, :, :ny]), (a, b)
+        assert torch.equal(part.scalars, whole.scalars[a:b]), (a, b)
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_kernel_families_agree(dtype):
     """Three independent formulations of the same row statistics, selected through ``lec_tuning.kernel`` (the
