@@ -192,18 +192,19 @@ __global__ void __launch_bounds__(64, 2) lec_boxtile_kernel(const RowParams p) {
 
     // ---- registers of the load layout.  T window: Tn = level k+1 (rows -1 .. 4), Tc = level k, Tm = level k-1 (rows 0 .. 3);
     // En / Ec: T at the columns just outside the chunk (lanes 0..31: c0 - 1, lanes 32..63: c0 + 64) of the centre rows at k+1 / k
-    // The streamed operands u, v, omega are prefetched TWO passes ahead (two register sets, picked by pass parity at compile time):
-    // the kernel is bound by how many loads a CU keeps in flight, and these 12 loads per pass do not depend on the window (Phi
-    // stays one pass ahead: a fourth double set would spill).
-    TIN Tn[kWR + 2], Tc[kWR + 2], Tm[kWR], En[kWR] = {}, Ec[kWR] = {}, sU[2][kWR], sV[2][kWR], sW[2][kWR], rP[kWR], rD0[kWR], rD1[kWR];
+    // The operands that do not depend on the level window are prefetched TWO passes ahead (two register sets, picked by pass parity at
+    // compile time): the kernel is bound by how many loads a CU keeps in flight.  u, v, omega always; Phi and the dT/dt operands too where
+    // the registers allow it (fp32 storage: 0.65 vs 0.69 ms; with fp64 storage their second set spills 108 B and costs 15 %).
+    constexpr bool DEEP_ALL = sizeof(TIN) == 4;
+    TIN Tn[kWR + 2], Tc[kWR + 2], Tm[kWR], En[kWR] = {}, Ec[kWR] = {}, sU[2][kWR], sV[2][kWR], sW[2][kWR], sP[2][kWR], sD0[2][kWR], sD1[2][kWR];
     double rWl = 0.0, rG[3] = {0.0, 0.0, 0.0};            // non-uniform longitudes: the lane's trapezoid weight and d/dlon coefficients
     if (LEC_BT_ABLATE & 2) {
 #pragma unroll
         for (int i = 0; i < kWR + 2; ++i) { Tn[i] = (TIN)(281 + lane + i); Tc[i] = (TIN)(280 + lane + i); }
 #pragma unroll
         for (int i = 0; i < kWR; ++i) {
-            Tm[i] = (TIN)(279 + lane); En[i] = Ec[i] = (TIN)280; rD0[i] = rD1[i] = (TIN)(281 + lane);
-            sU[0][i] = sU[1][i] = (TIN)lane; sV[0][i] = sV[1][i] = (TIN)i; sW[0][i] = sW[1][i] = (TIN)0.1; rP[i] = (TIN)(lane * i);
+            Tm[i] = (TIN)(279 + lane); En[i] = Ec[i] = (TIN)280; sD0[0][i] = sD0[1][i] = sD1[0][i] = sD1[1][i] = (TIN)(281 + lane);
+            sU[0][i] = sU[1][i] = (TIN)lane; sV[0][i] = sV[1][i] = (TIN)i; sW[0][i] = sW[1][i] = (TIN)0.1; sP[0][i] = sP[1][i] = (TIN)(lane * i);
         }
     }
     auto lev = [&](int k) -> size_t { return (size_t)min(max(k, 0), p.nl - 1) * plane; };
@@ -244,17 +245,19 @@ __global__ void __launch_bounds__(64, 2) lec_boxtile_kernel(const RowParams p) {
 #pragma unroll
             for (int i = 0; i < kWR; ++i) Tc[i + 1] = ld(gT + lk + roff[i + 1], col);
         }
+        if (!DEEP_ALL) {
 #pragma unroll
-        for (int i = 0; i < kWR; ++i) {
-            const size_t o = lk + roff[i + 1];
-            if (WITH_Q || has_p) rP[i] = ldnt(gP + o, col);
-            if (WITH_Q) {
-                rD0[i] = ld(gD0 + o, col);
-                if (MODE == 1) rD1[i] = ld(gD1 + o, col);
+            for (int i = 0; i < kWR; ++i) {
+                const size_t o = lk + roff[i + 1];
+                if (WITH_Q || has_p) sP[0][i] = ldnt(gP + o, col);
+                if (WITH_Q) {
+                    sD0[0][i] = ld(gD0 + o, col);
+                    if (MODE == 1) sD1[0][i] = ld(gD1 + o, col);
+                }
             }
         }
     };
-    // u, v, omega of pass `ps` (level, column chunk) into register set SET
+    // u, v, omega (and, DEEP_ALL, Phi and the dT/dt operands) of pass `ps` (level, column chunk) into register set SET
     auto issue_stream = [&](auto set_tag, const int ps) {
         constexpr int SET = decltype(set_tag)::value;
         if (LEC_BT_ABLATE & 2) return;
@@ -267,6 +270,13 @@ __global__ void __launch_bounds__(64, 2) lec_boxtile_kernel(const RowParams p) {
             sU[SET][i] = ldnt(gU + o, col);
             sV[SET][i] = ldnt(gV + o, col);
             sW[SET][i] = ldnt(gW + o, col);
+            if (DEEP_ALL) {
+                if (WITH_Q || has_p) sP[SET][i] = ldnt(gP + o, col);
+                if (WITH_Q) {
+                    sD0[SET][i] = ld(gD0 + o, col);
+                    if (MODE == 1) sD1[SET][i] = ld(gD1 + o, col);
+                }
+            }
         }
     };
 
@@ -282,7 +292,8 @@ __global__ void __launch_bounds__(64, 2) lec_boxtile_kernel(const RowParams p) {
     if (npass > 1) issue_stream(std::integral_constant<int, 1>{}, 1);
     auto pass = [&](auto set_tag, const int ps) {
         constexpr int SET = decltype(set_tag)::value;
-        const TIN (&rU)[kWR] = sU[SET]; const TIN (&rV)[kWR] = sV[SET]; const TIN (&rW)[kWR] = sW[SET];
+        const TIN (&rU)[kWR] = sU[SET]; const TIN (&rV)[kWR] = sV[SET]; const TIN (&rW)[kWR] = sW[SET]; const TIN (&rP)[kWR] = sP[DEEP_ALL ? SET : 0];
+        const TIN (&rD0)[kWR] = sD0[DEEP_ALL ? SET : 0]; const TIN (&rD1)[kWR] = sD1[DEEP_ALL ? SET : 0];
         const int kk = ps / ncc, cc = ps - kk * ncc, k = k0 + kk, c0 = cc * kCW;
         const int slot = kk % kLB;
         double* const sd = side + slot * kWR * kSide;
