@@ -405,10 +405,11 @@ __global__ void __launch_bounds__(64, 2) lec_boxtile_kernel(const RowParams p) {
             if (lv <= slot && jb < p.nyb_max) {
                 const int kout = k - slot + lv;
                 dbl2_t* __restrict__ out = reinterpret_cast<dbl2_t*>(p.rows + ((size_t)(tl * p.nl + kout) * p.nyb_max + jb) * LEC_NSTAT);
-                double o[LEC_NSTAT];
+                // (few values live at a time: the epilogue runs while two passes' loads are in flight in registers)
+                if (jb >= nyb) {                 // padding row of a box lower than nyb_max
 #pragma unroll
-                for (int s = 0; s < LEC_NSTAT; ++s) o[s] = 0.0;
-                if (jb < nyb) {
+                    for (int s = 0; s < LEC_NSTAT / 2; ++s) { dbl2_t z; z.x = 0.0; z.y = 0.0; out[s] = z; }
+                } else {
                     const double* sr = side + (lv * kWR + r) * kSide;
                     const double* st = stash + (lv * kWR + r) * kNA;
                     double tot[kNA];
@@ -418,13 +419,8 @@ __global__ void __launch_bounds__(64, 2) lec_boxtile_kernel(const RowParams p) {
                     if (UNIFORM) {
                         // the trapezoid's end points, weight 1/2 each: the first point has a = b = c = d = e = 0 (it is the shift),
                         // so only its f counts; the last point brings all 20 monomials
-                        double ends[kNA];
-#pragma unroll
-                        for (int s = 0; s < kNA; ++s) ends[s] = 0.0;
-                        accum20<true>(ends, 1.0, sr[6], sr[7], sr[8], sr[9], sr[10], sr[11]);
-                        ends[5] += sr[5];
-#pragma unroll
-                        for (int s = 0; s < kNA; ++s) tot[s] = fma(0.5, ends[s], tot[s]);
+                        accum20<false>(tot, 0.5, sr[6], sr[7], sr[8], sr[9], sr[10], sr[11]);
+                        tot[5] = fma(0.5, sr[5], tot[5]);
                         scale = h_rad * inv_xlen;
                     }
 #pragma unroll
@@ -432,11 +428,13 @@ __global__ void __launch_bounds__(64, 2) lec_boxtile_kernel(const RowParams p) {
                     double o22[22];
                     finish_lane(tot, sr[0], sr[1], sr[2], sr[3], sr[4], o22);
 #pragma unroll
-                    for (int s = 0; s < 22; ++s) o[s] = o22[s];
-                    o[LEC_S_TW] = sr[0]; o[LEC_S_TE] = sr[12]; o[LEC_S_UW] = sr[1]; o[LEC_S_UE] = sr[13]; o[LEC_S_VW] = sr[2]; o[LEC_S_VE] = sr[14];
+                    for (int s = 0; s < 11; ++s) { dbl2_t v2; v2.x = o22[2 * s]; v2.y = o22[2 * s + 1]; out[s] = v2; }
+                    dbl2_t e2;
+                    e2.x = sr[0]; e2.y = sr[12]; out[LEC_S_TW / 2] = e2;       // T, u, v at the west / east box column
+                    e2.x = sr[1]; e2.y = sr[13]; out[LEC_S_UW / 2] = e2;
+                    e2.x = sr[2]; e2.y = sr[14]; out[LEC_S_VW / 2] = e2;
+                    e2.x = 0.0; e2.y = 0.0; out[LEC_S_SPARE / 2] = e2; out[LEC_S_SPARE / 2 + 1] = e2;
                 }
-#pragma unroll
-                for (int s = 0; s < LEC_NSTAT / 2; ++s) { dbl2_t v2; v2.x = o[2 * s]; v2.y = o[2 * s + 1]; out[s] = v2; }
             }
             row_sync<64>();
         }
