@@ -367,7 +367,7 @@ def run_rank(args):
             except Exception:
                 traffic = None
         if args.moving:
-            kname = "lec_boxtile_kernel (one (time, level) box tile per workgroup, one lane per latitude row)"
+            kname = "lec_boxtile_kernel (one wave per four box rows x ten levels of a time step; six values per point transposed through LDS)"
         elif args.no_q or args.storage == "f32":
             kname = "lec_rowsweep_kernel (one wave per row)" + ("" if args.no_q else " + lec_qtime_kernel")
         else:

@@ -62,7 +62,7 @@ enum lec_kernel {
     LEC_KERNEL_TWO_SWEEP = 1,  /* lec_rowstats.hip: the reference's own order (deviation from the zonal mean, then products); rows <= lec_max_row() */
     LEC_KERNEL_ROW_SWEEP = 2,  /* lec_rowsweep.hip: one wave per row, one sweep */
     LEC_KERNEL_ROW_BLOCK = 3,  /* lec_rowblock.hip: blocks of neighbouring rows exchange T through LDS (all terms, one fixed box, dT/dt from the cube) */
-    LEC_KERNEL_BOX_TILE = 4    /* lec_boxtile.hip: a (time, level) box tile staged through LDS, one lane per latitude row */
+    LEC_KERNEL_BOX_TILE = 4    /* lec_boxtile.hip: one wave per four box rows walks the levels; six values per point transposed through LDS */
 };
 
 /* workgroup -> row order of the row kernels (speed only) */
@@ -78,7 +78,8 @@ typedef struct lec_tuning {
     int32_t kernel;        /* enum lec_kernel */
     int32_t block_shape;   /* LEC_KERNEL_ROW_BLOCK: 100 bt + 10 bk + bj waves (time x level x latitude, each 1 or 2); 0 = 212 */
     int32_t order;         /* enum lec_order */
-    int32_t tile_t, tile_j; /* tile extents of LEC_ORDER_XCD_TILED / of the row-block kernel (in blocks); 0 = default; must be >= 0 */
+    int32_t tile_t, tile_j; /* tile extents of LEC_ORDER_XCD_TILED / of the row-block kernel (in blocks); box tiles: tile_t = time steps per
+                               workgroup group; 0 = default; must be >= 0 */
     int32_t f32_vec;       /* fp32 storage, one wave per row: 0 = float4 trips when the cubes are 16-byte aligned, 2 = float2 trips */
     int32_t reserved[2];   /* must be 0 */
 } lec_tuning;
