@@ -202,6 +202,40 @@ def test_config5_shape_moving_boxes(dtype):
     _rows_close(res, sweep, "box tiles vs one wave per row, 61 x 61 boxes")
 
 
+def test_box_tile_kernel_random_geometries():
+    """Forty random geometries (box 2..150 columns x 2..90 rows anywhere in the grid, 2..23 levels, 1..5 time steps, uniform or not,
+    fp32 / fp64 storage, dT/dt from the time axis or from a cube, per-step boxes of different sizes): the box-tile kernel against
+    the one-wave-per-row kernel, record by record, and the padding rows of the lower boxes must be zero."""
+    rng = np.random.default_rng(2024)
+    for case in range(40):
+        nt, nl = int(rng.integers(1, 6)), int(rng.integers(2, 24))
+        ny, nx = int(rng.integers(8, 100)), int(rng.integers(8, 170))
+        dtype = np.float32 if rng.random() < 0.3 else np.float64
+        nonuni = bool(rng.random() < 0.3)
+        use_cube = bool(rng.random() < 0.4) or nt == 1
+        dom = synthetic_domain(nt, nl, ny, nx, seed=1000 + case, dtype=dtype, nonuniform_lon=nonuni)
+        boxes = []
+        for _ in range(nt):
+            wx, wy = int(rng.integers(2, min(nx, 150) + 1)), int(rng.integers(2, min(ny, 90) + 1))
+            iw, js = int(rng.integers(0, nx - wx + 1)), int(rng.integers(0, ny - wy + 1))
+            boxes.append((iw, iw + wx - 1, js, js + wy - 1))
+        eng = _engine(dom)
+        f = [_dev(a) for a in (dom.tair, dom.u, dom.v, dom.omega, dom.geopt)]
+        kw = dict(keep_rows=True, per_step_boxes=True)
+        if use_cube:
+            kw["dTdt"] = _dev(rng.standard_normal(dom.tair.shape).astype(dtype) * 1e-4)
+        else:
+            kw["time_s"] = dom.time_s
+        a = eng.compute(*f, boxes, tuning={"kernel": "box_tile"}, **kw)
+        b = eng.compute(*f, boxes, tuning={"kernel": "row_sweep"}, **kw)
+        _rows_close(a, b, f"case {case}: nt={nt} nl={nl} grid {ny}x{nx} boxes {boxes} {np.dtype(dtype).name} nonuni={nonuni} cube={use_cube}")
+        nyb_max = a.rows.shape[2]
+        for t, bx in enumerate(boxes):
+            nyb = bx[3] - bx[2] + 1
+            assert torch.all(a.rows[t, :, nyb:nyb_max] == 0), (case, t)
+        assert torch.isfinite(a.rows).all(), case
+
+
 @pytest.mark.parametrize("nonuni", [False, True])
 def test_moving_boxes_of_mixed_widths_shard_bit_identically(nonuni):
     """A track whose boxes are 40 to 90 columns wide.  The box-tile kernel keeps the level window in registers only when every row of
