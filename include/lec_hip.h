@@ -154,12 +154,12 @@ typedef struct lec_rowstats_args {
 #define LEC_MAX_LEVELS 160
 #define LEC_MAX_STEPS_PER_REDUCE 65535
 typedef struct lec_reduce_args {
-    const double* rows_d;       /* [t_count][nl][nyb_max][LEC_NSTAT] from lec_rowstats */
+    const double* rows_d;       /* [t_count][nl][nyb_max][LEC_NSTAT] from lec_rowstats; 16-byte aligned */
     int32_t t_count, nl;
     int32_t n_box, nyb_max;
     const int32_t* box_d;       /* [n_box][4] */
     const double* boxtab2_d;    /* [n_box][4]  c1 = -1/(Re xlen ylen), c2 = -1/(Re ylen), spare, spare */
-    const double* lattab2_d;    /* [n_box][nyb_max][8]  cos*wphi/ylen, wphi, cos, tan, d/dphi[rad] a,b,c, spare */
+    const double* lattab2_d;    /* [n_box][nyb_max][8]  cos*wphi/ylen, wphi, cos, tan, d/dphi[rad] a,b,c, spare; 16-byte aligned */
     const double* levtab2_d;    /* [nl][4]  p [Pa], d/dp a,b,c */
     double phi_scale;           /* multiplies the geopotential statistics (g when the file holds height) */
     int32_t drop_any_time;      /* _handle_nans' dropna(dim=level) on a [time, level] array (energy_contents.py:203-207), fixed framework:

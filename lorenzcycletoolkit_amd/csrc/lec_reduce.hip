@@ -15,11 +15,16 @@
 
 #include "../../include/lec_hip.h"
 #include "lec_internal.h"
+#include "lec_rowcommon.h"
 
 namespace {
+using lec::dbl2_t;
 
 constexpr double kG = LEC_G, kRe = LEC_RE, kRd = LEC_RD, kCp = LEC_CP_D;
 constexpr int kMaxNl = 160;
+constexpr int kStageRows = 66;     // lec_level_terms_kernel: latitude rows staged through LDS at a time (64 + one either side)
+constexpr int kPartStride = 65;    // partial sums of one statistic, one per lane (+1: conflict-free both ways)
+constexpr int kRecStride = LEC_NSTAT + 1, kLatStride = 9;      // LDS row strides (doubles): odd, so a lane per row is conflict-free
 
 enum {
     V_AZ = 0, V_AE, V_KZ, V_KE, V_CZ2, V_CE2, V_CA1, V_CA2, V_CK1, V_CK2, V_CK3, V_CK4, V_CK5, V_GZ, V_GE,
@@ -99,43 +104,77 @@ __device__ double baz3_repaired(const RedParams& p, const double* am_t, int tl, 
     return slope * (p.levtab2[4 * k] - xl) + yl;
 }
 
-// grid (nl, t_count), block 64
+// grid (nl, t_count), block 64.  A wave's life here is a chain of memory round trips (a few hundred arithmetic instructions between
+// them), so the kernel is arranged to have TWO: every global load -- the level's records, the latitude table, the records of the
+// levels above and below -- is addressed from the kernel arguments alone (the staging covers nyb_max rows; the rows below a lower box
+// are zero records) and issued before anything waits for the area means or the box height.
 __global__ void __launch_bounds__(64) lec_level_terms_kernel(const RedParams p) {
     const int k = blockIdx.x, tl = blockIdx.y, lane = threadIdx.x;
-    const int nl = p.nl;
+    const int nl = p.nl, nyb_max = p.nyb_max;
     const int bi = (p.n_box == 1) ? 0 : tl;
-    const int nyb = p.box[4 * bi + 3] - p.box[4 * bi + 2] + 1;
     const int km = k > 0 ? k - 1 : k, kp = k < nl - 1 ? k + 1 : k;
-    const double* am = p.am + (size_t)tl * nl * 8;
-    const double aT = am[8 * k + 0], aW = am[8 * k + 3], aP = am[8 * k + 4], aQ = am[8 * k + 5];
-    const double aTm = am[8 * km + 0], aTp = am[8 * kp + 0];
-    const double pk = p.levtab2[4 * k + 0], pa = p.levtab2[4 * k + 1], pb = p.levtab2[4 * k + 2], pc = p.levtab2[4 * k + 3];
-
-    // static stability (thermodynamics.py:55-70); the zonal/area mean commutes with the linear d/dp
-    double sig = kG * aT / kCp - (pk * kG / kRd) * (pa * aTm + pb * aT + pc * aTp);
-    sig = (sig > 0.03) ? sig : 0.03;
-
-    const size_t lstride = (size_t)p.nyb_max * LEC_NSTAT;
+    const size_t lstride = (size_t)nyb_max * LEC_NSTAT;
     const double* rec = p.rows + (size_t)(tl * nl + k) * lstride;
     const double* recm = p.rows + (size_t)(tl * nl + km) * lstride;
     const double* recp = p.rows + (size_t)(tl * nl + kp) * lstride;
-    const double* lt = p.lattab2 + (size_t)bi * p.nyb_max * 8;
+    const double* lt = p.lattab2 + (size_t)bi * nyb_max * 8;
     const double ps = p.phi_scale;
+
+    // The level's records (256 B each) and the latitude table are staged through LDS 64 rows (+ one row either side) at a time:
+    // 16-byte-per-lane loads of consecutive addresses instead of ~45 loads that each touch one 128-byte line per lane.  Row strides of
+    // 33 / 9 doubles keep the lane-per-row reads free of bank conflicts.  Same arithmetic and order as a direct read.
+    __shared__ double tile[kStageRows * kRecStride];
+    __shared__ double ltile[kStageRows * kLatStride];
+    constexpr int kIt2 = (kStageRows * (LEC_NSTAT / 2) + 63) / 64, kIt8 = (kStageRows * 4 + 63) / 64;
 
     double acc[V_COUNT];
 #pragma unroll
     for (int i = 0; i < V_COUNT; ++i) acc[i] = 0.0;
+    int nyb = 0;
+    double aT = 0, aW = 0, aP = 0, aQ = 0, aTm = 0, aTp = 0, pa = 0, pb = 0, pc = 0;
+    const double* am = p.am + (size_t)tl * nl * 8;
 
-    for (int jb = lane; jb < nyb; jb += 64) {
+    for (int j0 = 0; j0 < nyb_max; j0 += 64) {
+        const int jlo = j0 > 0 ? j0 - 1 : 0, jhi = min(j0 + 64, nyb_max - 1);
+        const int n2 = (jhi - jlo + 1) * (LEC_NSTAT / 2), n8 = (jhi - jlo + 1) * 4;
+        const dbl2_t* src = reinterpret_cast<const dbl2_t*>(rec + (size_t)jlo * LEC_NSTAT);
+        const dbl2_t* lsrc = reinterpret_cast<const dbl2_t*>(lt + (size_t)jlo * 8);
+        dbl2_t v2[kIt2], v8[kIt8];
+#pragma unroll
+        for (int it = 0; it < kIt2; ++it) v2[it] = src[min(it * 64 + lane, n2 - 1)];
+#pragma unroll
+        for (int it = 0; it < kIt8; ++it) v8[it] = lsrc[min(it * 64 + lane, n8 - 1)];
+        const int jb = j0 + lane, jbc = min(jb, nyb_max - 1);
+        static_assert(LEC_S_MT == 0 && LEC_S_MU == 1, "the two means read from the neighbouring levels are one 16-byte load");
+        const dbl2_t km2 = *reinterpret_cast<const dbl2_t*>(recm + (size_t)jbc * LEC_NSTAT);
+        const dbl2_t kp2 = *reinterpret_cast<const dbl2_t*>(recp + (size_t)jbc * LEC_NSTAT);
+        if (j0 == 0) {
+            nyb = p.box[4 * bi + 3] - p.box[4 * bi + 2] + 1;
+            aT = am[8 * k + 0]; aW = am[8 * k + 3]; aP = am[8 * k + 4]; aQ = am[8 * k + 5];
+            aTm = am[8 * km + 0]; aTp = am[8 * kp + 0];
+            pa = p.levtab2[4 * k + 1]; pb = p.levtab2[4 * k + 2]; pc = p.levtab2[4 * k + 3];
+        }
+        __syncthreads();                                     // the previous chunk has been consumed
+#pragma unroll
+        for (int it = 0; it < kIt2; ++it) {
+            const int i = it * 64 + lane;
+            if (i < n2) { double* d = tile + (i >> 4) * kRecStride + 2 * (i & 15); d[0] = v2[it].x; d[1] = v2[it].y; }
+        }
+#pragma unroll
+        for (int it = 0; it < kIt8; ++it) {
+            const int i = it * 64 + lane;
+            if (i < n8) { double* d = ltile + (i >> 2) * kLatStride + 2 * (i & 3); d[0] = v8[it].x; d[1] = v8[it].y; }
+        }
+        __syncthreads();
+        if (jb >= nyb) continue;
         const int jm = jb > 0 ? jb - 1 : jb, jp = jb < nyb - 1 ? jb + 1 : jb;
-        const double* r = rec + (size_t)jb * LEC_NSTAT;
-        const double* rjm = rec + (size_t)jm * LEC_NSTAT;
-        const double* rjp = rec + (size_t)jp * LEC_NSTAT;
-        const double* rkm = recm + (size_t)jb * LEC_NSTAT;
-        const double* rkp = recp + (size_t)jb * LEC_NSTAT;
-        const double cw = lt[8 * jb + 0], wphi = lt[8 * jb + 1], c = lt[8 * jb + 2], tn = lt[8 * jb + 3];
-        const double gra = lt[8 * jb + 4], grb = lt[8 * jb + 5], grc = lt[8 * jb + 6];
-        const double cm = lt[8 * jm + 2], cp = lt[8 * jp + 2];
+        const double* r = tile + (jb - jlo) * kRecStride;
+        const double* rjm = tile + (jm - jlo) * kRecStride;
+        const double* rjp = tile + (jp - jlo) * kRecStride;
+        const double* l0 = ltile + (jb - jlo) * kLatStride;
+        const double cw = l0[0], wphi = l0[1], c = l0[2], tn = l0[3];
+        const double gra = l0[4], grb = l0[5], grc = l0[6];
+        const double cm = ltile[(jm - jlo) * kLatStride + 2], cp = ltile[(jp - jlo) * kLatStride + 2];
 
         const double mT = r[LEC_S_MT], mU = r[LEC_S_MU], mV = r[LEC_S_MV], mW = r[LEC_S_MW];
         const double mP = r[LEC_S_MP] * ps, mQ = r[LEC_S_MQ];
@@ -146,8 +185,8 @@ __global__ void __launch_bounds__(64) lec_level_terms_kernel(const RedParams p) 
         const double dphiTc = gra * (rjm[LEC_S_MT] - aT) * cm + grb * Ts * c + grc * (rjp[LEC_S_MT] - aT) * cp;
         const double dphiUc = gra * (rjm[LEC_S_MU] / cm) + grb * (mU / c) + grc * (rjp[LEC_S_MU] / cp);
         const double dphiV = gra * rjm[LEC_S_MV] + grb * mV + grc * rjp[LEC_S_MV];
-        const double dpT = pa * (rkm[LEC_S_MT] - aTm) + pb * Ts + pc * (rkp[LEC_S_MT] - aTp);
-        const double dpU = pa * rkm[LEC_S_MU] + pb * mU + pc * rkp[LEC_S_MU];
+        const double dpT = pa * (km2.x - aTm) + pb * Ts + pc * (kp2.x - aTp);
+        const double dpU = pa * km2.y + pb * mU + pc * kp2.y;
 
         acc[V_AZ] += cw * (Ts * Ts);
         acc[V_AE] += cw * sTT;
@@ -199,34 +238,38 @@ __global__ void __launch_bounds__(64) lec_level_terms_kernel(const RedParams p) 
         acc[V_B3 + 4] += cw * (Ws * Ps);
         acc[V_B3 + 5] += cw * sWP;
     }
-#pragma unroll
-    for (int i = 0; i < V_SIG; ++i) acc[i] = wave_sum(acc[i]);
+    // static stability (thermodynamics.py:55-70); the zonal/area mean commutes with the linear d/dp
+    const double pk = p.levtab2[4 * k + 0];
+    double sig = kG * aT / kCp - (pk * kG / kRd) * (pa * aTm + pb * aT + pc * aTp);
+    sig = (sig > 0.03) ? sig : 0.03;
 
-    if (lane == 0) {
-        double* o = p.levraw + (size_t)(tl * nl + k) * LEC_NLEVRAW;
-        const double s2 = 2 * sig, g2 = 2 * kG;
-        o[V_AZ] = acc[V_AZ] / s2;
-        o[V_AE] = acc[V_AE] / s2;
-        o[V_KZ] = acc[V_KZ];
-        o[V_KE] = acc[V_KE];
-        o[V_CZ2] = acc[V_CZ2];
-        o[V_CE2] = acc[V_CE2];
-        o[V_CA1] = acc[V_CA1] / (2 * kRe * sig);
-        o[V_CA2] = acc[V_CA2] / sig;
-        o[V_CK1] = acc[V_CK1]; o[V_CK2] = acc[V_CK2]; o[V_CK3] = acc[V_CK3]; o[V_CK4] = acc[V_CK4]; o[V_CK5] = acc[V_CK5];
-        o[V_GZ] = acc[V_GZ] / (kCp * sig);
-        o[V_GE] = acc[V_GE] / (kCp * sig);
-        o[V_B1 + 0] = acc[V_B1 + 0] / s2; o[V_B1 + 1] = acc[V_B1 + 1] / s2;
-        o[V_B1 + 2] = acc[V_B1 + 2] / g2; o[V_B1 + 3] = acc[V_B1 + 3] / g2;
-        o[V_B1 + 4] = acc[V_B1 + 4] / kG; o[V_B1 + 5] = acc[V_B1 + 5] / kG;
-        o[V_B2 + 0] = acc[V_B2 + 0] / s2; o[V_B2 + 1] = acc[V_B2 + 1] / s2;
-        o[V_B2 + 2] = acc[V_B2 + 2] / g2; o[V_B2 + 3] = acc[V_B2 + 3] / g2;
-        o[V_B2 + 4] = acc[V_B2 + 4] / kG; o[V_B2 + 5] = acc[V_B2 + 5] / kG;
-        o[V_B3 + 0] = acc[V_B3 + 0] / s2; o[V_B3 + 1] = acc[V_B3 + 1] / s2;
-        o[V_B3 + 2] = acc[V_B3 + 2] / g2; o[V_B3 + 3] = acc[V_B3 + 3] / g2;
-        o[V_B3 + 4] = acc[V_B3 + 4] / kG; o[V_B3 + 5] = acc[V_B3 + 5] / kG;
-        o[V_SIG] = sig;
-        for (int i = V_COUNT; i < LEC_NLEVRAW; ++i) o[i] = 0.0;
+    // 64 partial sums per statistic -> one total, through LDS (the staging tile is free): lane s adds the partials of statistic s
+    // in a fixed order (four chains), applies the statistic's divisor and stores it -- no lane-0 epilogue, no butterfly.
+    static_assert(V_SIG * kPartStride <= kStageRows * kRecStride, "partial sums must fit the staging tile");
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < V_SIG; ++i) tile[i * kPartStride + lane] = acc[i];
+    __syncthreads();
+    if (lane < LEC_NLEVRAW) {
+        const int s = lane;
+        double tot = 0.0, div = 1.0;
+        if (s < V_SIG) {
+            const double* q = tile + s * kPartStride;
+            double c0 = q[0], c1 = q[1], c2 = q[2], c3 = q[3];
+#pragma unroll
+            for (int l = 4; l < 64; l += 4) { c0 += q[l]; c1 += q[l + 1]; c2 += q[l + 2]; c3 += q[l + 3]; }
+            tot = (c0 + c1) + (c2 + c3);
+            const int b = (s >= V_B1) ? (s - V_B1) % 6 : -1;         // boundary pieces: Az Ae | Kz Ke | PhiZ PhiE
+            if (s == V_AZ || s == V_AE || b == 0 || b == 1) div = 2 * sig;
+            else if (b == 2 || b == 3) div = 2 * kG;
+            else if (b == 4 || b == 5) div = kG;
+            else if (s == V_CA1) div = 2 * kRe * sig;
+            else if (s == V_CA2) div = sig;
+            else if (s == V_GZ || s == V_GE) div = kCp * sig;
+        } else if (s == V_SIG) {
+            tot = sig;
+        }
+        p.levraw[(size_t)(tl * nl + k) * LEC_NLEVRAW + s] = tot / div;        // x / 1.0 is x
     }
 }
 
@@ -236,48 +279,51 @@ enum {
     F_B1 = 10, F_B2 = 16, F_B3 = 22, F_COUNT = 28
 };
 
-// Builds function `f` of level for time step `tl` into row[0..nl) and applies the interpolation half of
+// Builds the F_COUNT functions of level of time step `tl` into fn[f][0..nl) and applies the interpolation half of
 // _handle_nans (energy_contents.py:190-208): linear in p across interior gaps, no extrapolation.
 // BAz's bottom-top term (F_B3) is the exception: the reference interpolates it per latitude before the area mean
 // (lec_level_terms_kernel has done that) and only DROPS the levels that are still NaN (boundary_terms.py:169-176).
-// Returns the number of NaN levels found before the repair.
-__device__ int build_level_function(const RedParams& p, int tl, int f, double* row) {
+// Phase 1: one LEVEL per lane (its levraw record read once, every function evaluated without divergence);
+// phase 2: one FUNCTION per lane scans its levels in LDS.  Returns, on lane f < F_COUNT, the number of NaN levels
+// of function f found before the repair (0 on the other lanes).
+__device__ int build_level_functions(const RedParams& p, int tl, double (*fn)[kMaxNl], int lane) {
     const int nl = p.nl;
     const double* raw = p.levraw + (size_t)tl * nl * LEC_NLEVRAW;
     const double* lv = p.levtab2;
-    int nnan = 0;
-    for (int k = 0; k < nl; ++k) {
+    for (int k = lane; k < nl; k += 64) {
         const double* o = raw + (size_t)k * LEC_NLEVRAW;
         const double c1k = kRd / (lv[4 * k] * kG);   // Rd / (p g), conversion_terms.py:146,172
-        double x;
-        switch (f) {
-            case F_AZ: x = o[V_AZ]; break;
-            case F_AE: x = o[V_AE]; break;
-            case F_KZ: x = o[V_KZ]; break;
-            case F_KE: x = o[V_KE]; break;
-            case F_CZ: x = -(c1k * o[V_CZ2]); break;
-            case F_CA: x = -(o[V_CA1] + o[V_CA2]); break;
-            case F_CK: x = o[V_CK1] + o[V_CK2] + o[V_CK3] + o[V_CK4] + o[V_CK5]; break;
-            case F_CE: x = -(c1k * o[V_CE2]); break;
-            case F_GZ: x = o[V_GZ]; break;
-            case F_GE: x = o[V_GE]; break;
-            default: x = o[V_B1 + (f - F_B1)]; break;   // V_B1.. V_B3 are contiguous like F_B1..F_B3
-        }
-        row[k] = x;
-        nnan += isnan(x) ? 1 : 0;
+        fn[F_AZ][k] = o[V_AZ];
+        fn[F_AE][k] = o[V_AE];
+        fn[F_KZ][k] = o[V_KZ];
+        fn[F_KE][k] = o[V_KE];
+        fn[F_CZ][k] = -(c1k * o[V_CZ2]);
+        fn[F_CA][k] = -(o[V_CA1] + o[V_CA2]);
+        fn[F_CK][k] = o[V_CK1] + o[V_CK2] + o[V_CK3] + o[V_CK4] + o[V_CK5];
+        fn[F_CE][k] = -(c1k * o[V_CE2]);
+        fn[F_GZ][k] = o[V_GZ];
+        fn[F_GE][k] = o[V_GE];
+#pragma unroll
+        for (int i = 0; i < 18; ++i) fn[F_B1 + i][k] = o[V_B1 + i];       // V_B1.. V_B3 are contiguous like F_B1..F_B3
     }
-    if (nnan && f != F_B3) {
-        int last_ok = -1;
-        for (int k = 0; k < nl; ++k) {
-            if (!isnan(row[k])) { last_ok = k; continue; }
-            int nxt = k + 1;
-            while (nxt < nl && isnan(row[nxt])) ++nxt;
-            if (last_ok >= 0 && nxt < nl) {
-                const double xl = lv[4 * last_ok], xr = lv[4 * nxt], yl = row[last_ok], yr = row[nxt];
-                const double slope = (yr - yl) / (xr - xl);
-                for (int q = k; q < nxt; ++q) row[q] = slope * (lv[4 * q] - xl) + yl;
+    __syncthreads();
+    int nnan = 0;
+    if (lane < F_COUNT) {
+        double* row = fn[lane];
+        for (int k = 0; k < nl; ++k) nnan += isnan(row[k]) ? 1 : 0;
+        if (nnan && lane != F_B3) {
+            int last_ok = -1;
+            for (int k = 0; k < nl; ++k) {
+                if (!isnan(row[k])) { last_ok = k; continue; }
+                int nxt = k + 1;
+                while (nxt < nl && isnan(row[nxt])) ++nxt;
+                if (last_ok >= 0 && nxt < nl) {
+                    const double xl = lv[4 * last_ok], xr = lv[4 * nxt], yl = row[last_ok], yr = row[nxt];
+                    const double slope = (yr - yl) / (xr - xl);
+                    for (int q = k; q < nxt; ++q) row[q] = slope * (lv[4 * q] - xl) + yl;
+                }
+                k = nxt - 1;
             }
-            k = nxt - 1;
         }
     }
     return nnan;
@@ -288,11 +334,9 @@ __device__ int build_level_function(const RedParams& p, int tl, int f, double* r
 __global__ void __launch_bounds__(64) lec_dropmask_kernel(const RedParams p) {
     __shared__ double fn[F_COUNT][kMaxNl];
     const int tl = blockIdx.x, lane = threadIdx.x;
-    if (lane < F_COUNT) {
-        if (build_level_function(p, tl, lane, fn[lane])) {
-            for (int k = 0; k < p.nl; ++k)
-                if (isnan(fn[lane][k])) atomicOr(&p.dropmask[lane * p.nl + k], 1);
-        }
+    if (build_level_functions(p, tl, fn, lane)) {
+        for (int k = 0; k < p.nl; ++k)
+            if (isnan(fn[lane][k])) atomicOr(&p.dropmask[lane * p.nl + k], 1);
     }
 }
 
@@ -306,10 +350,9 @@ __global__ void __launch_bounds__(64) lec_vertical_kernel(const RedParams p) {
     const double* raw = p.levraw + (size_t)tl * nl * LEC_NLEVRAW;
     const double* lv = p.levtab2;
 
-    int nnan = 0;
+    int nnan = build_level_functions(p, tl, fn, lane);
     if (lane < F_COUNT) {
         const int f = lane;
-        nnan = build_level_function(p, tl, f, fn[f]);
         // the dropping half of _handle_nans: levels that are still NaN (here, or at any time step in the fixed framework)
         int k0 = 0, k1 = nl - 1;
         if (p.drop_any_time) {
@@ -396,6 +439,8 @@ static int reduce_impl(const lec_reduce_args* a, bool mask_only, const char* who
     if (a->t_count > 65535) return lec_set_error(LEC_ERR_UNSUPPORTED, "lec_reduce: more than 65535 time steps in one call");
     if (a->n_box != 1 && a->n_box != a->t_count) return lec_set_error(LEC_ERR_ARG, "lec_reduce: n_box must be 1 or t_count");
     if (a->drop_any_time < 0 || a->drop_any_time > 2) return lec_set_error(LEC_ERR_ARG, "lec_reduce: drop_any_time must be 0, 1 or 2");
+    if ((reinterpret_cast<uintptr_t>(a->rows_d) | reinterpret_cast<uintptr_t>(a->lattab2_d)) & 15)
+        return lec_set_error(LEC_ERR_ARG, "lec_reduce / lec_dropmask: rows_d and lattab2_d must be 16-byte aligned");
     if ((a->drop_any_time || mask_only) && !a->dropmask_d) return lec_set_error(LEC_ERR_ARG, "lec_reduce / lec_dropmask: drop_any_time needs dropmask_d");
     (void)who;
     RedParams p;

@@ -18,7 +18,7 @@ rows = collections.defaultdict(lambda: collections.defaultdict(list)); meta = {}
 for f in glob.glob("$OUT/p*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        if "lec_row" in n or "lec_box" in n or "lec_qtime" in n:
+        if "lec_" in n and (not "$LEC_PMC_ONLY" or "$LEC_PMC_ONLY" in n):
             k = n.replace("(anonymous namespace)::", "").replace("void ", "").split("(lec::")[0][:80]
             rows[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
             meta[k] = (r["VGPR_Count"], r["SGPR_Count"], r["LDS_Block_Size"], r["Workgroup_Size"], r["Grid_Size"])
