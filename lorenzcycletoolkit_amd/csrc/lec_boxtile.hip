@@ -56,9 +56,10 @@ constexpr int kS4 = 80;              // tile row stride in doubles: 64 columns +
 constexpr int kTile = kWR * kS4;
 constexpr int kSide = 16;            // per-row side values: 5 shifts, f of the first point, a..f of the last point, T u v at the east column
 #ifndef LEC_BT_LEVELS
-#define LEC_BT_LEVELS 10
+#define LEC_BT_LEVELS 0
 #endif
-constexpr int kLevelChunk = LEC_BT_LEVELS;      // levels per wave (the T window's prologue is paid once per chunk)
+constexpr int kLevelsFixed = LEC_BT_LEVELS;     // > 0: levels per wave fixed at build time (experiments); 0: p.jgroup, chosen per launch
+constexpr int kMinLevels = 5;                   // the T window's prologue (two extra level loads) is paid once per chunk of levels
 constexpr int kLB = 4;               // levels whose rows are finished together (16 lanes: 4 levels x 4 rows)
 constexpr int kPS = 65;              // stride between the statistics of the partial-sum array (odd: conflict-free both ways)
 
@@ -122,7 +123,8 @@ __global__ void __launch_bounds__(64, 2) lec_boxtile_kernel(const RowParams p) {
     // level chunk, so the waves resident on an XCD are neighbours in latitude and time: the T rows at j+-1 (halo) and t+-1 are rows
     // a sibling loads as its own (L2)
     const int n_rb = (p.nyb_max + kWR - 1) / kWR;
-    const int n_kc = (p.nl + kLevelChunk - 1) / kLevelChunk;
+    const int kchunk = p.jgroup;                     // levels per wave
+    const int n_kc = (p.nl + kchunk - 1) / kchunk;
     const int xcd = blockIdx.x & 7;
     int q0 = blockIdx.x >> 3;
     const int rbi = q0 % n_rb; q0 /= n_rb;
@@ -136,7 +138,7 @@ __global__ void __launch_bounds__(64, 2) lec_boxtile_kernel(const RowParams p) {
     const int iw = p.box[4 * bi + 0], ie = p.box[4 * bi + 1], js = p.box[4 * bi + 2], jn = p.box[4 * bi + 3];
     const int nxb = ie - iw + 1, nyb = jn - js + 1;
     const int jb0 = rbi * kWR;
-    const int k0 = kc * kLevelChunk, k1 = min(k0 + kLevelChunk, p.nl);
+    const int k0 = kc * kchunk, k1 = min(k0 + kchunk, p.nl);
     if (jb0 >= nyb) {       // a row block that holds only padding rows of a box lower than nyb_max
         const int nrow = min(kWR, p.nyb_max - jb0);
         for (int k = k0; k < k1; ++k) {
@@ -447,8 +449,20 @@ __global__ void __launch_bounds__(64, 2) lec_boxtile_kernel(const RowParams p) {
 
 template <typename TIN>
 int launch_tiles(RowParams p, bool uniform, int mode, hipStream_t st) {
-    const long long n_rb = (p.nyb_max + kWR - 1) / kWR, n_kc = (p.nl + kLevelChunk - 1) / kLevelChunk;
+    const long long n_rb = (p.nyb_max + kWR - 1) / kWR;
     p.jchunk = (p.t_count + 7) / 8;                       // time steps per XCD
+    // levels per wave: as many as still leave kTargetWaves one-wave workgroups (four rounds of the 2048 the chip holds at two per SIMD)
+    // -- long level walks read best (profiles/r02_notes.md: 4 rows x 37 levels 6 % ahead of 4 x 10), short launches need the waves
+    if (kLevelsFixed > 0) p.jgroup = kLevelsFixed;
+    if (p.jgroup < 1) {
+        constexpr long long kTargetWaves = 8192;
+        const long long per_chunk = 8LL * p.jchunk * n_rb;
+        const long long want = (kTargetWaves + per_chunk - 1) / per_chunk;
+        const long long n_kc0 = want < 1 ? 1 : (want > (p.nl + kMinLevels - 1) / kMinLevels ? (p.nl + kMinLevels - 1) / kMinLevels : want);
+        p.jgroup = (int)((p.nl + n_kc0 - 1) / n_kc0);
+    }
+    if (p.jgroup > p.nl) p.jgroup = p.nl;
+    const long long n_kc = (p.nl + p.jgroup - 1) / p.jgroup;
     if (p.tgroup < 1) p.tgroup = 8;
     if (p.tgroup > p.jchunk) p.tgroup = p.jchunk;
     const long long tgroups = (p.jchunk + p.tgroup - 1) / p.tgroup;
@@ -468,7 +482,8 @@ int launch_tiles(RowParams p, bool uniform, int mode, hipStream_t st) {
 
 }  // namespace
 
-// mode: 0 no Q, 1 dT/dt from the cube's time neighbours per point, 2 dT/dt cube; p.tgroup: time steps per tile group (< 1: default)
+// mode: 0 no Q, 1 dT/dt from the cube's time neighbours per point, 2 dT/dt cube; p.tgroup: time steps per tile group, p.jgroup: levels
+// per wave (< 1: chosen here)
 int lec_launch_boxtile(const lec::RowParams& p, int dtype, bool uniform, int mode, hipStream_t st) {
     return dtype == LEC_F64 ? launch_tiles<double>(p, uniform, mode, st) : launch_tiles<float>(p, uniform, mode, st);
 }

@@ -414,6 +414,7 @@ extern "C" int lec_rowstats(const lec_rowstats_args* a) {
         // form of mode 3 does not apply
         RowParams pt = p;
         pt.tgroup = tu.tile_t;                              // time steps per tile group; 0 = the kernel's default (8)
+        pt.jgroup = tu.tile_j;                              // levels per wave; 0 = chosen from the launch size
         rc = lec_launch_boxtile(pt, a->dtype, uni, wq, st);
     } else {
         // Single-sweep row kernels.  All terms with dT/dt from the cube on one fixed box (the headline configuration, mode 3): a
