@@ -40,6 +40,10 @@ __global__ void __launch_bounds__(64 * BT * BK * BJ, LEC_MINW_SINGLE) lec_rowblo
     __shared__ double red[NW][kRound * red_stride(64)];
     __shared__ double tot[NW][24];
     __shared__ __attribute__((aligned(16))) TIN xch[2][NW][64 * VEC];
+#if defined(LEC_RB_PAD) && LEC_RB_PAD > 0
+    __shared__ double occupancy_pad[LEC_RB_PAD];              // measurement builds: fewer resident workgroups per CU
+    if (p.nt < 0) { occupancy_pad[threadIdx.x] = p.rows[threadIdx.x]; __syncthreads(); p.rows[threadIdx.x] = occupancy_pad[(threadIdx.x * 7) % LEC_RB_PAD]; }
+#endif
 
     // wave-uniform: everything derived from the wave index stays in SGPRs
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
