@@ -192,12 +192,12 @@ def run_rank(args):
         raise SystemExit("bench.py: no GPU visible: the HIP path is the only path")
     if backend == "nccl" and world > ndev:
         raise SystemExit(f"bench.py: {world} ranks but {ndev} GPU(s): RCCL needs one GPU per rank")
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
     local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)      # the rank's GPU is already current
 
     from lorenzcycletoolkit_amd.engine import LECEngine
     from lorenzcycletoolkit_amd.parallel import gather_result, halo_range, merge_dropmask, shard_range
@@ -268,9 +268,15 @@ def run_rank(args):
         tuning = {k: (v if k in ("kernel", "order") else int(v)) for k, v in (kv.split("=") for kv in args.tuning.split(","))}
     stage1 = dict(with_q=with_q, tuning=tuning, per_step_boxes=bool(args.moving))
 
-    def sync(barrier=True):
-        if world > 1 and barrier:
+    def barrier():
+        if backend == "nccl":
+            dist.barrier(device_ids=[local_rank])
+        else:
             dist.barrier()
+
+    def sync(with_barrier=True):
+        if world > 1 and with_barrier:
+            barrier()
         torch.cuda.synchronize()
 
     def one_pass(record):
@@ -426,7 +432,7 @@ def run_rank(args):
             out["cpu_baseline"] = cpu_baseline(kind)
         print(json.dumps(out, ensure_ascii=False), flush=True)
     if world > 1:
-        dist.barrier()
+        barrier()
         dist.destroy_process_group()
 
 
