@@ -6,7 +6,8 @@ tallied at 64 B -- calibrated on configurations with a known byte count: the fix
 algorithmic bytes after the correction, the moving no-Q run 1.255 x = its 128-byte-line over-fetch of 488-byte rows), and an entry in
 profiles/pmc_summary.json that bench.py reads for roofline.traffic.
 
-Usage: tools/summarize_prof.py <round> <tag> <pmc_summary key or ->"""
+Usage: tools/summarize_prof.py <round> <tag> <pmc_summary key or ->      (keys: rowstats_f64_all_hbm_bytes_per_timestep, rowstats_f64_noq_...,
+rowstats_f32_all_..., rowstats_moving_hbm_bytes_per_timestep)"""
 import csv
 import glob
 import json
@@ -30,7 +31,7 @@ def stage1(n):
     m = re.search(r"lec_rowsweep_kernel<\w+, \d+, \w+, (\d+),", n)
     return not (m and m.group(1) == "0" and not noq_run)
 
-stats = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))[0]
+stats = max(glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv")), key=os.path.getmtime)      # gpurun merges runs: newest
 rows = list(csv.DictReader(open(stats)))
 with open(os.path.join(dst, f"{rnd}_{tag}_kernel_stats.csv"), "w", newline="") as f:
     w = csv.DictWriter(f, fieldnames=rows[0].keys())
@@ -48,7 +49,7 @@ out = {"tag": tag, "bench_line": bench, "stage1_kernels_ms_per_call": stage1_ms,
 pm = glob.glob(os.path.join(src, "pmc_1", "*", "*_counter_collection.csv"))
 if pm:
     per = {}
-    for r in csv.DictReader(open(pm[0])):
+    for r in csv.DictReader(open(max(pm, key=os.path.getmtime))):
         if stage1(r["Kernel_Name"]) and r["Counter_Name"] == "FETCH_SIZE":
             per.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
     fetch_kib = sum(sum(v) / len(v) for v in per.values())
