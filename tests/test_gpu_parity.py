@@ -203,22 +203,33 @@ def test_config5_shape_moving_boxes(dtype):
 
 
 def test_box_tile_kernel_random_geometries():
-    """Forty random geometries (box 2..150 columns x 2..90 rows anywhere in the grid, 2..23 levels, 1..5 time steps, uniform or not,
+    """Six corner geometries and forty random ones (box 2..150 columns x 2..90 rows anywhere in the grid, 2..23 levels, 1..5 time steps, uniform or not,
     fp32 / fp64 storage, dT/dt from the time axis or from a cube, per-step boxes of different sizes): the box-tile kernel against
     the one-wave-per-row kernel, record by record, and the padding rows of the lower boxes must be zero."""
     rng = np.random.default_rng(2024)
-    for case in range(40):
-        nt, nl = int(rng.integers(1, 6)), int(rng.integers(2, 24))
-        ny, nx = int(rng.integers(8, 100)), int(rng.integers(8, 170))
-        dtype = np.float32 if rng.random() < 0.3 else np.float64
-        nonuni = bool(rng.random() < 0.3)
-        use_cube = bool(rng.random() < 0.4) or nt == 1
-        dom = synthetic_domain(nt, nl, ny, nx, seed=1000 + case, dtype=dtype, nonuniform_lon=nonuni)
-        boxes = []
-        for _ in range(nt):
-            wx, wy = int(rng.integers(2, min(nx, 150) + 1)), int(rng.integers(2, min(ny, 90) + 1))
-            iw, js = int(rng.integers(0, nx - wx + 1)), int(rng.integers(0, ny - wy + 1))
-            boxes.append((iw, iw + wx - 1, js, js + wy - 1))
+    # the corners of the cube first (the kernel's halo and prefetch addresses are clamped, never masked): whole grid, the first and the
+    # last 2 x 2 / 3 x 3 points, a two-column strip over all latitudes at the east edge, a two-row strip at the north edge
+    corner_cases = [
+        (2, 5, 12, 70, [(0, 69, 0, 11)] * 2), (2, 4, 9, 10, [(0, 1, 0, 1), (7, 9, 6, 8)]), (3, 3, 40, 30, [(28, 29, 0, 39)] * 3),
+        (1, 2, 30, 140, [(0, 139, 28, 29)]), (2, 6, 66, 64, [(0, 63, 0, 64), (0, 63, 1, 65)]), (2, 3, 8, 65, [(0, 64, 0, 7), (1, 64, 2, 7)]),
+    ]
+    for case in range(40 + len(corner_cases)):
+        if case < len(corner_cases):
+            nt, nl, ny, nx, boxes = corner_cases[case]
+            dtype, nonuni, use_cube = (np.float64, np.float32)[case % 2], case % 3 == 2, case % 2 == 1 or nt == 1
+            dom = synthetic_domain(nt, nl, ny, nx, seed=900 + case, dtype=dtype, nonuniform_lon=nonuni)
+        else:
+            nt, nl = int(rng.integers(1, 6)), int(rng.integers(2, 24))
+            ny, nx = int(rng.integers(8, 100)), int(rng.integers(8, 170))
+            dtype = np.float32 if rng.random() < 0.3 else np.float64
+            nonuni = bool(rng.random() < 0.3)
+            use_cube = bool(rng.random() < 0.4) or nt == 1
+            dom = synthetic_domain(nt, nl, ny, nx, seed=1000 + case, dtype=dtype, nonuniform_lon=nonuni)
+            boxes = []
+            for _ in range(nt):
+                wx, wy = int(rng.integers(2, min(nx, 150) + 1)), int(rng.integers(2, min(ny, 90) + 1))
+                iw, js = int(rng.integers(0, nx - wx + 1)), int(rng.integers(0, ny - wy + 1))
+                boxes.append((iw, iw + wx - 1, js, js + wy - 1))
         eng = _engine(dom)
         f = [_dev(a) for a in (dom.tair, dom.u, dom.v, dom.omega, dom.geopt)]
         kw = dict(keep_rows=True, per_step_boxes=True)
