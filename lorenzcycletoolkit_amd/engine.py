@@ -101,6 +101,7 @@ class LECEngine:
         self._levtab2 = self._up(levtab2)
         self._box_cache = {}
         self._work = {}        # stage-2 workspaces by shape: am, levraw, dropmask (true scratch: never handed out)
+        self._tcoef = None     # (time axis, its d/dt coefficients on the device) of the last call
 
     # -- helpers ---------------------------------------------------------------------------
     def _up(self, a: np.ndarray, dtype=torch.float64) -> torch.Tensor:
@@ -212,7 +213,10 @@ class LECEngine:
                 raise ValueError("time_s must have one entry per time step of the cube")
             if nt < 2:
                 raise ValueError("dT/dt by finite differences needs at least 2 time steps")
-            tcoef = self._up(tables.time_coefs(time_s))
+            # cached: an upload from pageable memory makes the host wait for the stream at every call
+            if self._tcoef is None or self._tcoef[0].shape != time_s.shape or not np.array_equal(self._tcoef[0], time_s):
+                self._tcoef = (time_s.copy(), self._up(tables.time_coefs(time_s)))
+            tcoef = self._tcoef[1]
 
         f64 = dict(dtype=torch.float64, device=tair.device)
         if rows_out is None:
@@ -238,8 +242,6 @@ class LECEngine:
             if timing is not None:
                 ev1.record()
                 timing.append((ev0, ev1))
-        # tcoef is released to torch's caching allocator only after the stream work is enqueued; the allocator
-        # is stream-ordered, so reuse on this stream is safe.
         return rows
 
     def reduce(self, rows: torch.Tensor, boxes: Sequence[Sequence[int]], *, phi_scale: float = 1.0,
