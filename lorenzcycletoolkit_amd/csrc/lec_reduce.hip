@@ -59,19 +59,24 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-// grid (nl, t_count), block 64
+// grid (nl, t_count), block 64.  Like lec_level_terms_kernel: the record loads are addressed from the kernel arguments alone (nyb_max
+// rows) and issued before the box height arrives; rows below a lower box are masked out afterwards.
 __global__ void __launch_bounds__(64) lec_area_means_kernel(const RedParams p) {
     const int k = blockIdx.x, tl = blockIdx.y, lane = threadIdx.x;
     const int bi = (p.n_box == 1) ? 0 : tl;
-    const int nyb = p.box[4 * bi + 3] - p.box[4 * bi + 2] + 1;
     const double* rec = p.rows + (size_t)(tl * p.nl + k) * p.nyb_max * LEC_NSTAT;
     const double* lt = p.lattab2 + (size_t)bi * p.nyb_max * 8;
     double a[6] = {0, 0, 0, 0, 0, 0};
-    for (int jb = lane; jb < nyb; jb += 64) {
-        const double cw = lt[8 * jb + 0];
-        const double* r = rec + (size_t)jb * LEC_NSTAT;
-#pragma unroll
-        for (int s = 0; s < 6; ++s) a[s] += cw * r[s];
+    int nyb = 0;
+    for (int j0 = 0; j0 < p.nyb_max; j0 += 64) {
+        const int jb = j0 + lane, jc = min(jb, p.nyb_max - 1);
+        const dbl2_t* r = reinterpret_cast<const dbl2_t*>(rec + (size_t)jc * LEC_NSTAT);
+        const dbl2_t v0 = r[0], v1 = r[1], v2 = r[2];          // the six zonal means [T] [u] [v] [w] [Phi] [Q]
+        const double cw = lt[8 * jc + 0];
+        if (j0 == 0) nyb = p.box[4 * bi + 3] - p.box[4 * bi + 2] + 1;
+        if (jb < nyb) {
+            a[0] += cw * v0.x; a[1] += cw * v0.y; a[2] += cw * v1.x; a[3] += cw * v1.y; a[4] += cw * v2.x; a[5] += cw * v2.y;
+        }
     }
 #pragma unroll
     for (int s = 0; s < 6; ++s) a[s] = wave_sum(a[s]);
