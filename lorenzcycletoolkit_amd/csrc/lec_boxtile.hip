@@ -215,7 +215,11 @@ __global__ void __launch_bounds__(64, 2) lec_boxtile_kernel(const RowParams p) {
         return *reinterpret_cast<const TIN*>(reinterpret_cast<const char*>(row) + off * (unsigned)sizeof(TIN));
     };
     auto ldnt = [](const TIN* __restrict__ row, unsigned off) -> TIN {
+#if defined(LEC_BT_PLAIN) && LEC_BT_PLAIN
+        return *reinterpret_cast<const TIN*>(reinterpret_cast<const char*>(row) + off * (unsigned)sizeof(TIN));
+#else
         return __builtin_nontemporal_load(reinterpret_cast<const TIN*>(reinterpret_cast<const char*>(row) + off * (unsigned)sizeof(TIN)));
+#endif
     };
     // loads of the pass (level k, column chunk at c0).  `fresh`: the whole T window (no predecessor pass to inherit it from)
     auto issue_loads = [&](const int k, const int c0, const bool fresh) {

@@ -27,52 +27,56 @@ __device__ __forceinline__ double ld(const P& p, int n, int nmax, int tl, int k0
     return NT ? __builtin_nontemporal_load(q) : *q;
 }
 
-template <int BATCH, int WR, int KC, bool NT>
-__global__ void __launch_bounds__(64) probe(const P p) {
+template <int BATCH, int WR, int KC, bool NT, int WT = 1, bool SYNC = false>
+__global__ void __launch_bounds__(64 * WT) probe(const P p) {
     extern __shared__ double pad[];
-    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3, lane = threadIdx.x;
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int tchunk = (p.T + 7) / 8, nrb = (NB + WR - 1) / WR, nkc = (NL + KC - 1) / KC;
     const int rbi = q % nrb, kc = (q / nrb) % nkc, tt = q / (nrb * nkc);
-    const int tl = xcd * tchunk + tt;
-    if (tt >= tchunk || tl >= p.T) return;
-    const int iw = p.box[2 * tl], js = p.box[2 * tl + 1];
+    const int tl = xcd * tchunk + tt * WT + wv;
+    if (tt * WT >= tchunk) return;                         // whole workgroup
+    const bool live = tt * WT + wv < tchunk && tl < p.T;
+    if (!live && !SYNC) return;
+    const int tls = live ? tl : xcd * tchunk;
+    const int iw = p.box[2 * tls], js = p.box[2 * tls + 1];
     const int k0 = kc * KC, nk = min(KC, NL - k0), nmax = nk * WR * NF;
     double a[BATCH], b[BATCH], acc = 0.0;
 #pragma unroll
-    for (int i = 0; i < BATCH; ++i) a[i] = ld<WR, KC, NT>(p, i, nmax, tl, k0, rbi * WR, iw, js, lane);
+    for (int i = 0; i < BATCH; ++i) a[i] = ld<WR, KC, NT>(p, i, nmax, tls, k0, rbi * WR, iw, js, lane);
     for (int n = BATCH; n < nmax + BATCH; n += 2 * BATCH) {
+        if (SYNC) __builtin_amdgcn_s_barrier();
 #pragma unroll
-        for (int i = 0; i < BATCH; ++i) b[i] = ld<WR, KC, NT>(p, n + i, nmax, tl, k0, rbi * WR, iw, js, lane);
+        for (int i = 0; i < BATCH; ++i) b[i] = ld<WR, KC, NT>(p, n + i, nmax, tls, k0, rbi * WR, iw, js, lane);
 #pragma unroll
         for (int i = 0; i < BATCH; ++i) acc += a[i];
 #pragma unroll
-        for (int i = 0; i < BATCH; ++i) a[i] = ld<WR, KC, NT>(p, n + BATCH + i, nmax, tl, k0, rbi * WR, iw, js, lane);
+        for (int i = 0; i < BATCH; ++i) a[i] = ld<WR, KC, NT>(p, n + BATCH + i, nmax, tls, k0, rbi * WR, iw, js, lane);
 #pragma unroll
         for (int i = 0; i < BATCH; ++i) acc += b[i];
     }
-    if (lane == 0) pad[0] = acc;
-    p.out[(size_t)blockIdx.x * 64 + lane] = acc + pad[0];
+    if (lane == 0) pad[wv] = acc;
+    p.out[((size_t)blockIdx.x * WT + wv) * 64 + lane] = acc + pad[wv];
 }
 
-template <int BATCH, int WR = 4, int KC = 10, bool NT = true>
+template <int BATCH, int WR = 4, int KC = 10, bool NT = true, int WT = 1, bool SYNC = false>
 void run(const P& p, int waves_per_cu) {
     const int tchunk = (p.T + 7) / 8, nrb = (NB + WR - 1) / WR, nkc = (NL + KC - 1) / KC;
-    dim3 grid(8 * tchunk * nrb * nkc), block(64);
-    const size_t lds = (size_t)(160 * 1024 / waves_per_cu) - 512;
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&probe<BATCH, WR, KC, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dim3 grid(8 * ((tchunk + WT - 1) / WT) * nrb * nkc), block(64 * WT);
+    const size_t lds = (size_t)(160 * 1024 / waves_per_cu) * WT - 512;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&probe<BATCH, WR, KC, NT, WT, SYNC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    hipLaunchKernelGGL((probe<BATCH, WR, KC, NT>), grid, block, lds, 0, p);
+    hipLaunchKernelGGL((probe<BATCH, WR, KC, NT, WT, SYNC>), grid, block, lds, 0, p);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(a));
     const int reps = 5;
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((probe<BATCH, WR, KC, NT>), grid, block, lds, 0, p);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((probe<BATCH, WR, KC, NT, WT, SYNC>), grid, block, lds, 0, p);
     CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
     float ms; CK(hipEventElapsedTime(&ms, a, b));
     ms /= reps;
     // requested bytes: the loads beyond a wave's sequence are clamped repeats (L1 hits): count the sequence only, rows clamped to the box
     const double gb = (double)p.T * NL * (nrb * WR) * NB * 8 * NF / 1e9;
-    hipFuncAttributes fa; CK(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&probe<BATCH, WR, KC, NT>)));
-    printf("  [%3d VGPRs] %s rows %2d x levels %2d", fa.numRegs, NT ? "nt   " : "plain", WR, KC);
+    hipFuncAttributes fa; CK(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&probe<BATCH, WR, KC, NT, WT, SYNC>)));
+    printf("  [%3d VGPRs] %s rows %2d x levels %2d, %d steps per workgroup%s", fa.numRegs, NT ? "nt   " : "plain", WR, KC, WT, SYNC ? " (barrier per batch)" : "");
     printf("  waves/CU %2d  batch %2d (%3d..%3d loads in flight per wave, %3.0f..%3.0f KB per CU): %.3f ms  %.0f GB/s requested\n", waves_per_cu, BATCH, BATCH,
            2 * BATCH, waves_per_cu * BATCH * 0.488, waves_per_cu * 2 * BATCH * 0.488, ms, gb / ms * 1e3);
 }
@@ -98,6 +102,14 @@ int main(int argc, char** argv) {
             if (w <= 8) run<56>(p, w);
         }
     }
+    printf("several consecutive time steps per workgroup (time-neighbour rows may hit in the CU's L1):\n");
+    for (int rep = 0; rep < 2; ++rep) {
+        run<28, 4, 10, false, 1>(p, 8); run<28, 4, 10, false, 4, true>(p, 8); run<28, 4, 10, false, 2, true>(p, 8);
+        run<14, 4, 10, false, 1>(p, 8); run<14, 4, 10, false, 4, true>(p, 8);
+        run<14, 4, 10, false, 1>(p, 16); run<14, 4, 10, false, 4, true>(p, 16); run<14, 4, 10, false, 2, true>(p, 16); run<14, 4, 10, false, 4, false>(p, 16);
+        run<14, 4, 10, true, 1>(p, 16); run<14, 4, 10, true, 4, true>(p, 16);
+    }
+    if (argc > 3) return 0;
     printf("plain loads instead of nontemporal ones:\n");
     run<28, 4, 10, false>(p, 8); run<28, 4, 10, false>(p, 16); run<14, 4, 10, false>(p, 32); run<28, 61, 1, false>(p, 8);
     printf("T(t-1), T(t+1) replaced by two more reads of T(t) (certain cache hits):\n");
