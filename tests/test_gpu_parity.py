@@ -273,6 +273,34 @@ def test_moving_boxes_of_mixed_widths_shard_bit_identically(nonuni):
         assert torch.equal(part.scalars, whole.scalars[a:b]), (a, b)
 
 
+def test_random_domains_against_the_oracle():
+    """Twelve random small domains (3..6 time steps on an uneven time axis, 3..9 levels, boxes of 3..70 columns x 3..18 rows, uniform
+    or table longitudes, fp32 / fp64 storage): all 16 terms, budgets, residuals and 21 level tables of the fixed and of the moving
+    framework against the un-factored oracle."""
+    rng = np.random.default_rng(4242)
+    for case in range(12):
+        nt, nl = int(rng.integers(3, 7)), int(rng.integers(3, 10))
+        ny, nx = int(rng.integers(6, 24)), int(rng.integers(8, 90))
+        dtype = np.float32 if case % 3 == 2 else np.float64
+        dom = synthetic_domain(nt, nl, ny, nx, seed=5000 + case, dtype=dtype, nonuniform_lon=bool(case % 4 == 1))
+        dom.time_s = np.cumsum(rng.integers(1, 4, nt) * 3600.0)            # 1..3-hourly steps: np.gradient's non-uniform stencil
+
+        def limits():
+            wx, wy = int(rng.integers(3, min(nx, 70) + 1)), int(rng.integers(3, min(ny, 18) + 1))
+            iw, js = int(rng.integers(0, nx - wx + 1)), int(rng.integers(0, ny - wy + 1))
+            return (dom.lon[iw], dom.lon[iw + wx - 1], dom.lat[js], dom.lat[js + wy - 1])
+
+        lim = limits()
+        what = f"case {case}: nt={nt} nl={nl} grid {ny}x{nx} {np.dtype(dtype).name}"
+        check_fixed(dom, lim, what=what + f" fixed {lim}")
+        per_step = [limits() for _ in range(nt)]
+        eng = _engine(dom)
+        res = eng.compute(*[_dev(a) for a in (dom.tair, dom.u, dom.v, dom.omega, dom.geopt)], [eng.box_from_limits(*lm) for lm in per_step],
+                          time_s=dom.time_s)          # dT/dt over the series' time axis on the device, as the moving framework does
+        ref_s, ref_l = o.lec_moving(as_f64(dom), per_step)
+        compare(res.scalars_dict(), res.levels_dict(), ref_s, ref_l, TOL, what + " moving")
+
+
 def test_fixed_box_kernels_random_geometries():
     """Thirty random fixed boxes (2..2600 columns starting at even and odd columns -- aligned and unaligned vector trips, one-trip and
     many-trip rows -- 2..40 rows, 2..9 levels, 2..5 time steps, uniform or table longitudes, fp32 / fp64 storage, dT/dt from the time
