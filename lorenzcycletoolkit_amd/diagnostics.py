@@ -9,6 +9,13 @@ tests/test_diagnostics_cpu.py), and the box / extremum logic against the referen
 difference: extremum POSITIONS skip NaN like the values do (the reference's argmin / argmax land on a NaN cell).  Vorticity here is the spherical form zeta = dv/dx - du/dy + (u/Re) tan(phi) with
 dx = Re cos(phi) d(lambda), dy = Re d(phi) and MetPy-style three-point derivatives (second order, also at
 the edges); MetPy's default geodesic uses the WGS84 ellipsoid, so values can differ by a few 1e-3 relative.
+
+What a maintainer with MetPy 1.6.2 at hand should check first: the reference opens its files with plain ``xr.open_dataset`` (no
+``parse_cf`` / ``assign_crs`` anywhere in it), and MetPy's ``parse_grid_arguments`` falls back to the plain Cartesian
+``dv/dx - du/dy`` on geodesic grid distances when a DataArray carries no CRS -- i.e. WITHOUT the curvature term u tan(phi) / Re that the
+spherical form here (and MetPy's own map-factor path for data WITH a CRS) includes.  If that is what the reference's runs do, their zeta
+differs from this module's by that term (about 1 % of a cyclone's extremum at 30 degrees latitude, more poleward); the positions of the
+extrema and the two other columns (height minimum, wind maximum) are unaffected.
 """
 from __future__ import annotations
 
