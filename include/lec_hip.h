@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define LEC_ABI_VERSION 4
+#define LEC_ABI_VERSION 5
 
 /* number of fp64 values per (time, level, lat) row record written by lec_rowstats */
 #define LEC_NSTAT 32
@@ -210,6 +210,30 @@ typedef struct lec_ingest_args {
     void* stream;
 } lec_ingest_args;
 
+/*
+ * 850-hPa track diagnostics of the moving framework, one box per time step:
+ *   lec_moving_framework.py:650-663  wind_speed(u, v), vorticity(u, v) on the whole 850-hPa slice
+ *   lec_moving_framework.py:269-417  get_position: the extrema inside the box (inclusive label slices)
+ *   tools.py:95-128                  find_extremum_coordinates
+ * zeta = 1 / (Re cos(phi)) dv/dlambda - 1 / Re du/dphi + u tan(phi) / Re with three-point derivatives on the (possibly uneven)
+ * coordinates, second order also at the ends of the domain (the stencil of metpy.calc.first_derivative); the host supplies the
+ * stencils as tables.  NaN (below-ground points) is skipped, values and positions alike; among equal values the first in
+ * row-major order of the box wins (numpy's argmin / argmax).  Parity of the vorticity against MetPy itself is unpinned.
+ */
+typedef struct lec_diag_args {
+    const double* u_d;          /* [nt][ny][nx] eastward wind at 850 hPa (m/s) */
+    const double* v_d;          /* [nt][ny][nx] northward wind */
+    const double* hgt_d;        /* [nt][ny][nx] geopotential height (gpm) */
+    int32_t nt, ny, nx, reserved0;
+    const int32_t* box_d;       /* [nt][6]  iw, ie, js, jn: inclusive index ranges of the box; jc, ic: the grid point nearest its centre */
+    const double* lontab_d;     /* [nx][4]  first index of the point's three-point stencil (as a double), d/dlambda coefficients (1/rad) */
+    const double* lattab_d;     /* [ny][6]  first index of the stencil, d/dphi coefficients (1/rad), cos(phi), tan(phi) */
+    double* val_d;              /* [nt][5]  zeta minimum, zeta maximum, height minimum, wind-speed maximum, zeta at (jc, ic);
+                                            NaN when the box holds no finite value */
+    int32_t* pos_d;             /* [nt][8]  (j, i) grid indices of the four extrema, in that order; -1 when there is none */
+    void* stream;
+} lec_diag_args;
+
 int lec_version(void);
 const char* lec_last_error(void);
 
@@ -225,6 +249,8 @@ int lec_reduce(const lec_reduce_args* args);
  * Uses am_d / levraw_d as workspace; scalars_d, levels_d, nanflag_d are not touched and may be NULL.
  * For series processed in shards or chunks: merge the masks, then call lec_reduce with drop_any_time = 2. */
 int lec_dropmask(const lec_reduce_args* args);
+
+int lec_track_diag(const lec_diag_args* args);
 
 #ifdef __cplusplus
 }

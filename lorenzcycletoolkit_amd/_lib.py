@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # LEC_LIB: alternative build of the same ABI (kernel experiments only)
 LIB_PATH = os.environ.get("LEC_LIB") or os.path.join(_HERE, "liblec_hip.so")
 
-LEC_ABI_VERSION = 4
+LEC_ABI_VERSION = 5
 LEC_NSTAT = 32
 LEC_NLEVRAW = 40
 LEC_NSCALAR = 16
@@ -22,7 +22,7 @@ LEC_F64, LEC_F32, LEC_I16 = 0, 1, 2
 KERNEL_AUTO, KERNEL_TWO_SWEEP, KERNEL_ROW_SWEEP, KERNEL_ROW_BLOCK, KERNEL_BOX_TILE = 0, 1, 2, 3, 4
 ORDER_AUTO, ORDER_MEMORY, ORDER_XCD_LAT, ORDER_XCD_TILED = 0, 1, 2, 7
 
-EXPORTS = ["lec_version", "lec_last_error", "lec_max_row", "lec_rowstats", "lec_reduce", "lec_dropmask", "lec_ingest"]
+EXPORTS = ["lec_version", "lec_last_error", "lec_max_row", "lec_rowstats", "lec_reduce", "lec_dropmask", "lec_ingest", "lec_track_diag"]
 
 
 class Tuning(C.Structure):
@@ -81,6 +81,14 @@ class LecLibraryError(RuntimeError):
     pass
 
 
+class DiagArgs(C.Structure):
+    """struct lec_diag_args (include/lec_hip.h)."""
+    _fields_ = [("u_d", C.c_void_p), ("v_d", C.c_void_p), ("hgt_d", C.c_void_p),
+                ("nt", C.c_int32), ("ny", C.c_int32), ("nx", C.c_int32), ("reserved0", C.c_int32),
+                ("box_d", C.c_void_p), ("lontab_d", C.c_void_p), ("lattab_d", C.c_void_p),
+                ("val_d", C.c_void_p), ("pos_d", C.c_void_p), ("stream", C.c_void_p)]
+
+
 _lib = None
 
 
@@ -111,6 +119,8 @@ def load():
     lib.lec_dropmask.argtypes = [C.POINTER(ReduceArgs)]
     lib.lec_ingest.restype = C.c_int
     lib.lec_ingest.argtypes = [C.POINTER(IngestArgs)]
+    lib.lec_track_diag.restype = C.c_int
+    lib.lec_track_diag.argtypes = [C.POINTER(DiagArgs)]
     if lib.lec_version() != LEC_ABI_VERSION:
         raise LecLibraryError(f"liblec_hip.so ABI {lib.lec_version()} != expected {LEC_ABI_VERSION}")
     _lib = lib

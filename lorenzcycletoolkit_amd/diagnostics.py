@@ -2,13 +2,18 @@
 tools.py:95-128 of the reference): relative vorticity, wind speed, and the position of the vorticity
 extremum / height minimum / wind maximum inside each time step's box, written to ``*_trackfile``.
 
-Not part of the LEC hot path: a few (time, lat, lon) slices on the host.  Parity UNPINNED against MetPy (SURVEY.md
-section 8c): the reference calls MetPy's ``vorticity`` / ``wind_speed`` and its only sample trackfile
-has these columns empty; the formulas here are checked against an independent restatement (oracle/track_diagnostics.py,
-tests/test_diagnostics_cpu.py), and the box / extremum logic against the reference's own get_position.  One deliberate
-difference: extremum POSITIONS skip NaN like the values do (the reference's argmin / argmax land on a NaN cell).  Vorticity here is the spherical form zeta = dv/dx - du/dy + (u/Re) tan(phi) with
-dx = Re cos(phi) d(lambda), dy = Re d(phi) and MetPy-style three-point derivatives (second order, also at
-the edges); MetPy's default geodesic uses the WGS84 ellipsoid, so values can differ by a few 1e-3 relative.
+The numbers come from the device (``lec_track_diag``, csrc/lec_diag.hip): three 850-hPa slices are uploaded, one workgroup per
+time step evaluates vorticity and wind speed in that step's box and reduces the extrema with their grid positions.  The host builds
+the derivative stencils (``stencil_tables``), turns box limits into index ranges (``box_ranges``) and applies the reference's
+precedence rules (``positions``).  There is no host evaluation of the fields.
+
+Parity UNPINNED against MetPy: the reference calls MetPy's ``vorticity`` / ``wind_speed`` and its only
+sample trackfile has these columns empty; the kernel is checked against an independent restatement (oracle/track_diagnostics.py,
+tests/test_gpu_diagnostics.py), the box / extremum logic against the reference's own get_position.  One deliberate difference:
+extremum POSITIONS skip NaN like the values do (the reference's argmin / argmax land on a NaN cell).  Vorticity is the spherical
+form zeta = dv/dx - du/dy + (u/Re) tan(phi) with dx = Re cos(phi) d(lambda), dy = Re d(phi) and MetPy-style three-point
+derivatives (second order, also at the edges); MetPy's default geodesic uses the WGS84 ellipsoid, so values can differ by a few
+1e-3 relative.
 
 What a maintainer with MetPy 1.6.2 at hand should check first: the reference opens its files with plain ``xr.open_dataset`` (no
 ``parse_cf`` / ``assign_crs`` anywhere in it), and MetPy's ``parse_grid_arguments`` falls back to the plain Cartesian
@@ -19,77 +24,111 @@ extrema and the two other columns (height minimum, wind maximum) are unaffected.
 """
 from __future__ import annotations
 
+import ctypes as C
+
 import numpy as np
 
-from .constants import G, RE
+from . import _lib
+from .constants import G
 
 
-def first_derivative(f: np.ndarray, x: np.ndarray, axis: int) -> np.ndarray:
-    """Three-point derivative on a possibly non-uniform axis, second-order one-sided at both ends
-    (the stencil of metpy.calc.first_derivative)."""
-    f = np.moveaxis(np.asarray(f, dtype=np.float64), axis, -1)
+def _three_point(x: np.ndarray) -> np.ndarray:
+    """[n][4]: per point the first index of its three-point stencil and the three derivative coefficients on the (possibly
+    uneven) coordinate ``x`` -- the parabola through three neighbours, differentiated at the point itself: centred in the
+    interior, one-sided (still second order) at both ends (the stencil of metpy.calc.first_derivative)."""
     x = np.asarray(x, dtype=np.float64)
     n = x.size
     if n < 3:
-        raise ValueError("first_derivative needs at least 3 points")
-    out = np.empty_like(f)
+        raise ValueError("three-point derivatives need at least 3 points")
     d = np.diff(x)
-    d0, d1 = d[:-1], d[1:]                         # spacing left / right of the interior points
-    out[..., 1:-1] = (-d1 / (d0 * (d0 + d1)) * f[..., :-2] + (d1 - d0) / (d0 * d1) * f[..., 1:-1]
-                      + d0 / (d1 * (d0 + d1)) * f[..., 2:])
+    tab = np.empty((n, 4))
+    d0, d1 = d[:-1], d[1:]                                   # spacing left / right of the interior points
+    tab[1:-1, 0] = np.arange(n - 2)
+    tab[1:-1, 1] = -d1 / (d0 * (d0 + d1))
+    tab[1:-1, 2] = (d1 - d0) / (d0 * d1)
+    tab[1:-1, 3] = d0 / (d1 * (d0 + d1))
     a, b = d[0], d[1]
-    out[..., 0] = -(2 * a + b) / (a * (a + b)) * f[..., 0] + (a + b) / (a * b) * f[..., 1] - a / (b * (a + b)) * f[..., 2]
+    tab[0] = (0, -(2 * a + b) / (a * (a + b)), (a + b) / (a * b), -a / (b * (a + b)))
     a, b = d[-2], d[-1]
-    out[..., -1] = b / (a * (a + b)) * f[..., -3] - (a + b) / (a * b) * f[..., -2] + (a + 2 * b) / (b * (a + b)) * f[..., -1]
-    return np.moveaxis(out, -1, axis)
+    tab[-1] = (n - 3, b / (a * (a + b)), -(a + b) / (a * b), (a + 2 * b) / (b * (a + b)))
+    return tab
 
 
-def vorticity(u: np.ndarray, v: np.ndarray, lat_deg: np.ndarray, lon_deg: np.ndarray) -> np.ndarray:
-    """Relative vorticity on a regular lat/lon grid, arrays [..., lat, lon]."""
+def stencil_tables(lat_deg, lon_deg):
+    """(lontab [nx][4], lattab [ny][6]) of struct lec_diag_args: d/dlambda and d/dphi stencils in 1/rad, cos(phi), tan(phi)."""
     phi = np.deg2rad(np.asarray(lat_deg, dtype=np.float64))
     lam = np.deg2rad(np.asarray(lon_deg, dtype=np.float64))
-    cosphi = np.cos(phi)[:, None]
-    dvdx = first_derivative(v, lam, -1) / (RE * cosphi)
-    dudy = first_derivative(u, phi, -2) / RE
-    return dvdx - dudy + (np.asarray(u, dtype=np.float64) / RE) * np.tan(phi)[:, None]
+    lattab = np.empty((phi.size, 6))
+    lattab[:, :4] = _three_point(phi)
+    lattab[:, 4], lattab[:, 5] = np.cos(phi), np.tan(phi)
+    return np.ascontiguousarray(_three_point(lam)), lattab
 
 
-def wind_speed(u, v):
-    return np.sqrt(np.asarray(u, dtype=np.float64) ** 2 + np.asarray(v, dtype=np.float64) ** 2)
-
-
-def box_positions(zeta, hgt, wspd, lat_deg, lon_deg, limits, track_row=None, use_track_zeta=False):
-    """get_position for one time step.  ``limits``: dict with min/max lat/lon and central_lat/lon.
-    Values present (and not NaN) in the track row take precedence, as in the reference."""
+def box_ranges(lat_deg, lon_deg, limits) -> tuple:
+    """(iw, ie, js, jn, jc, ic): the inclusive index ranges of the label slices .sel(lat=slice(min_lat, max_lat), lon=slice(min_lon,
+    max_lon)) of get_position (lec_moving_framework.py:300-310) and the grid point nearest the box centre (used with -z)."""
     lat, lon = np.asarray(lat_deg), np.asarray(lon_deg)
-    jj = np.flatnonzero((lat >= limits["min_lat"]) & (lat <= limits["max_lat"]))     # label slices: inclusive
+    jj = np.flatnonzero((lat >= limits["min_lat"]) & (lat <= limits["max_lat"]))
     ii = np.flatnonzero((lon >= limits["min_lon"]) & (lon <= limits["max_lon"]))
-    sl = np.ix_(jj, ii)
-    z, h, w = zeta[sl], hgt[sl], wspd[sl]
-    south = limits["min_lat"] < 0
-    have = lambda name: track_row is not None and name in track_row.index and not np.isnan(float(track_row[name]))
+    if jj.size == 0 or ii.size == 0:
+        raise ValueError(f"box {limits} holds no grid point of the data")
+    jc = int(np.argmin(np.abs(lat - limits["central_lat"])))
+    ic = int(np.argmin(np.abs(lon - limits["central_lon"])))
+    return int(ii[0]), int(ii[-1]), int(jj[0]), int(jj[-1]), jc, ic
 
+
+def device_extrema(u850, v850, hgt850, lat_deg, lon_deg, limits_per_step, device="cuda:0"):
+    """``lec_track_diag`` on [time, lat, lon] slices (host arrays or device tensors): returns (val [nt][5], pos [nt][8]) as NumPy
+    arrays -- zeta minimum, zeta maximum, height minimum, wind maximum, zeta at the box centre; (j, i) of the four extrema."""
+    import torch
+    lib = _lib.load()
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise _lib.LecLibraryError("the track diagnostics run on the GPU: there is no CPU path")
+    up = lambda a: (a if isinstance(a, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(a))).to(device=dev, dtype=torch.float64).contiguous()
+    u, v, h = up(u850), up(v850), up(hgt850)
+    if u.dim() != 3 or v.shape != u.shape or h.shape != u.shape:
+        raise ValueError("u, v and height must be [time, lat, lon] slices of one shape")
+    nt, ny, nx = (int(x) for x in u.shape)
+    if (ny, nx) != (np.asarray(lat_deg).size, np.asarray(lon_deg).size) or len(limits_per_step) != nt:
+        raise ValueError("slices, coordinates and boxes do not match")
+    lontab, lattab = stencil_tables(lat_deg, lon_deg)
+    box = np.array([box_ranges(lat_deg, lon_deg, lim) for lim in limits_per_step], dtype=np.int32).reshape(nt, 6)
+    box_d, lon_d, lat_d = torch.as_tensor(box).to(dev), torch.as_tensor(lontab).to(dev), torch.as_tensor(lattab).to(dev)
+    val = torch.empty((nt, 5), dtype=torch.float64, device=dev)
+    pos = torch.empty((nt, 8), dtype=torch.int32, device=dev)
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    args = _lib.DiagArgs(u_d=ptr(u), v_d=ptr(v), hgt_d=ptr(h), nt=nt, ny=ny, nx=nx, reserved0=0, box_d=ptr(box_d), lontab_d=ptr(lon_d),
+                         lattab_d=ptr(lat_d), val_d=ptr(val), pos_d=ptr(pos), stream=C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    with torch.cuda.device(dev):
+        _lib.check(lib.lec_track_diag(C.byref(args)), "lec_track_diag")
+    return val.cpu().numpy(), pos.cpu().numpy()
+
+
+def positions(val, pos, lat_deg, lon_deg, limits, track_row=None, use_track_zeta=False) -> dict:
+    """get_position for one time step from the device's extrema (``val`` [5], ``pos`` [8] of ``device_extrema``).  Values present
+    (and not NaN) in the track row take precedence, as in the reference; with -z the vorticity is read at the box centre."""
+    lat, lon = np.asarray(lat_deg), np.asarray(lon_deg)
+    south = limits["min_lat"] < 0                              # hemisphere rule of the VALUE (lec_moving_framework.py:330-341)
+    have = lambda name: track_row is not None and name in track_row.index and not np.isnan(float(track_row[name]))
     if have("min_max_zeta_850"):
         zval = float(track_row["min_max_zeta_850"])
     elif use_track_zeta and track_row is not None:
-        j0 = int(np.argmin(np.abs(lat - limits["central_lat"])))
-        i0 = int(np.argmin(np.abs(lon - limits["central_lon"])))
-        zval = float(zeta[j0, i0])
+        zval = float(val[4])
     else:
-        zval = float(np.nanmin(z) if south else np.nanmax(z))
-    # xarray's .min() / .max() skip NaN (below-ground points at 850 hPa): so do these, values and positions alike
-    hval = float(track_row["min_hgt_850"]) if have("min_hgt_850") else float(np.nanmin(h))
-    wval = float(track_row["max_wind_850"]) if have("max_wind_850") else float(np.nanmax(w))
+        zval = float(val[0] if south else val[1])
+    # xarray's .min() / .max() skip NaN (below-ground points at 850 hPa): so do the kernel's extrema, values and positions alike
+    hval = float(track_row["min_hgt_850"]) if have("min_hgt_850") else float(val[2])
+    wval = float(track_row["max_wind_850"]) if have("max_wind_850") else float(val[3])
 
-    def where(a, use_min):
-        if np.isnan(a).all():
-            return float("nan"), float("nan")
-        idx = np.unravel_index(np.nanargmin(a) if use_min else np.nanargmax(a), a.shape)
-        return float(lat[jj][idx[0]]), float(lon[ii][idx[1]])
+    def where(q):
+        j, i = int(pos[2 * q]), int(pos[2 * q + 1])
+        return (float("nan"), float("nan")) if j < 0 else (float(lat[j]), float(lon[i]))
 
-    zlat, zlon = where(z, lat[jj].min() < 0)
-    hlat, hlon = where(h, True)
-    wlat, wlon = where(w, False)
+    js = box_ranges(lat, lon, limits)[2]
+    zlat, zlon = where(0 if lat[js] < 0 else 1)                # hemisphere rule of the POSITION: the box's southernmost latitude (tools.py:95-128)
+    hlat, hlon = where(2)
+    wlat, wlon = where(3)
     return {
         "min_max_zeta_850_lat": zlat, "min_max_zeta_850_lon": zlon, "min_max_zeta_850": zval,
         "min_hgt_850_lat": hlat, "min_hgt_850_lon": hlon, "min_hgt_850": hval,
@@ -97,7 +136,7 @@ def box_positions(zeta, hgt, wspd, lat_deg, lon_deg, limits, track_row=None, use
     }
 
 
-def track_diagnostics(data, variable_list_df, limits_per_step, track=None, use_track_zeta=False):
+def track_diagnostics(data, variable_list_df, limits_per_step, track=None, use_track_zeta=False, device="cuda:0"):
     """All time steps: u, v, geopotential height at 85000 Pa -> list of position dicts."""
     k850 = int(np.flatnonzero(data.level == 85000.0)[0])
     name = lambda role: str(variable_list_df.loc[role]["Variable"])
@@ -110,12 +149,11 @@ def track_diagnostics(data, variable_list_df, limits_per_step, track=None, use_t
         hgt = get("Geopotential Height").astype(np.float64)
     else:
         hgt = get("Geopotential").astype(np.float64) / G       # -> gpm
-    zeta = vorticity(u, v, data.lat, data.lon)
-    wspd = wind_speed(u, v)
+    val, pos = device_extrema(u, v, hgt, data.lat, data.lon, limits_per_step, device=device)
     out = []
     for t, lim in enumerate(limits_per_step):
         row = None
         if track is not None:
             row = track.iloc[int(np.argmin(np.abs(track.index - data.time[t])))]
-        out.append(box_positions(zeta[t], hgt[t], wspd[t], data.lat, data.lon, lim, row, use_track_zeta))
+        out.append(positions(val[t], pos[t], data.lat, data.lon, lim, row, use_track_zeta))
     return out

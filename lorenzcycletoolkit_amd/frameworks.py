@@ -291,9 +291,10 @@ def lec_moving(data: ds.LECDataset, variable_list_df: pd.DataFrame, dTdt, result
     app_logger.info(f"Results saved to {results_file}")
     # 850-hPa diagnostics of every box (lec_moving_framework.py:650-709); parity unpinned, see diagnostics.py
     app_logger.info("850 hPa track diagnostics (min_max_zeta_850, min_hgt_850, max_wind_850): spherical three-point vorticity on the "
-                    "host; NOT pinned against MetPy 1.6.2's vorticity (geodesic grid distances), expect agreement to a few 1e-3 relative")
+                    "GPU (lec_track_diag); NOT pinned against MetPy 1.6.2's vorticity (geodesic grid distances), expect agreement to a few 1e-3 relative")
     from .diagnostics import track_diagnostics
-    positions = track_diagnostics(data, variable_list_df, limits, track, use_track_zeta=bool(getattr(args, "zeta", False)))
+    positions = track_diagnostics(data, variable_list_df, limits, track, use_track_zeta=bool(getattr(args, "zeta", False)),
+                                  device=_device(args))
     out_track = pd.DataFrame([{**l, **p} for l, p in zip(limits, positions)])
     out_track = out_track.rename(columns={"datestr": "time", "central_lat": "Lat", "central_lon": "Lon"})
     out_track.to_csv(os.path.join(results_subdirectory, f"{infile_name}_{method}_trackfile"), index=False, sep=";")
