@@ -12,7 +12,7 @@ from typing import Sequence
 
 import numpy as np
 
-from .constants import G, KAPPA, P0_PA, RE
+from .constants import KAPPA, P0_PA, RE
 
 
 def gradient_coefs(x: np.ndarray) -> np.ndarray:

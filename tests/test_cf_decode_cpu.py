@@ -3,7 +3,6 @@
 The GPU twin of this file is tests/test_gpu_ingest.py::test_lec_ingest_cube_equals_the_oracle_decode."""
 import argparse
 import os
-import shutil
 
 import numpy as np
 import pytest

@@ -148,7 +148,6 @@ def test_era5_style_fixed_and_track_cli(workdir, golden_dir):
     """The reference's tests/test_ERA5_fixed.py and tests/test_ERA5_track.py re-stated (same namelist, box and track inputs, flags
     -r -f -p -v and -r -t -p -v); numbers against the oracle on the host-decoded data."""
     import lorenzcycletoolkit
-    from lorenzcycletoolkit_amd import dataset as ds
     shutil.copy(os.path.join(golden_dir, "inputs", "namelist_ERA5"), workdir / "inputs" / "namelist")
     shutil.copy(os.path.join(golden_dir, "inputs", "box_limits_Reg1"), workdir / "inputs" / "box_limits")
     shutil.copy(os.path.join(golden_dir, "inputs", "track_testdata_ERA5"), workdir / "inputs" / "track")

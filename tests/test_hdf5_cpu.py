@@ -5,7 +5,6 @@ function of a seed, so the expected arrays are regenerated here.  Variants: old-
 array chunk index, contiguous and chunked, shuffle + deflate, int16-packed and float32, fixed- and variable-length
 string attributes, dimension scales."""
 import argparse
-import importlib.util
 import os
 
 import numpy as np
