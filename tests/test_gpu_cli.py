@@ -91,6 +91,48 @@ def test_testdata_track_cli(workdir, golden_dir):
     assert trk["min_hgt_850_lat"].between(-30, -15).all() and trk["max_wind_850_lon"].between(-52.5, -37.5).all()
 
 
+def test_track_with_width_and_length_columns(workdir, golden_dir):
+    """A track file that carries its own box sizes (lec_moving_framework.py:224-225: width / length per time step; select_area.py:
+    305-313: the pre-crop uses their maxima).  Numbers against the oracle with those boxes; -o is ignored by the moving framework
+    (lec_moving_framework.py:525-528: the results file keeps its name)."""
+    (workdir / "inputs" / "track").write_text(
+        "time;Lat;Lon;length;width\n2005-08-08-0000;-22.5;-45;15;15\n2005-08-08-0600;-22.5;-45;10;12.5\n2005-08-08-1200;-25;-42.5;12.5;10\n"
+        "2005-08-08-1800;-22.5;-45;10;10\n2005-08-09-0000;-20;-47.5;15;12.5\n")
+    infile = os.path.join(golden_dir, "testdata_NCEP-R2.nc")
+    _main([infile, "-r", "-t", "-o", "ignored_name"])
+    out = workdir / "LEC_Results" / "testdata_NCEP-R2_track"
+    assert not (out / "ignored_name.csv").exists()
+    got = pd.read_csv(out / "testdata_NCEP-R2_track_results.csv", index_col=0)
+    tr = pd.read_csv(workdir / "inputs" / "track", sep=";")
+    dom = o.load_ncep_sample(infile, dtype=np.float64)
+    domt = o.crop_domain_track(dom, tr.Lat.values, tr.Lon.values, max_width=tr.width.max(), max_length=tr.length.max())
+    limits = [(lo - w / 2, lo + w / 2, la - l / 2, la + l / 2) for la, lo, l, w in zip(tr.Lat, tr.Lon, tr.length, tr.width)]
+    ref, _ = o.lec_moving(domt, limits)
+    for c in ("Az", "Ae", "Kz", "Ke", "Cz", "Ca", "Ck", "Ce", "BAz", "BAe", "BKz", "BKe", "BΦZ", "BΦE", "Gz", "Ge"):
+        r = np.asarray(ref[c], dtype=np.float64)
+        assert np.max(np.abs(got[c].values - r)) <= 1e-9 * np.max(np.abs(r)), c
+    trk = pd.read_csv(out / "testdata_NCEP-R2_track_trackfile", sep=";")
+    assert trk["length"].tolist() == [15, 10, 12.5, 10, 15] and trk["width"].tolist() == [15, 12.5, 10, 10, 12.5]
+    assert np.allclose(trk["max_lon"] - trk["min_lon"], trk["width"]) and np.allclose(trk["max_lat"] - trk["min_lat"], trk["length"])
+
+
+def test_custom_box_limits_file_meets_the_crop_by_inputs_box_limits(workdir, golden_dir):
+    """SURVEY B-6: slice_domain always crops by the hard-coded inputs/box_limits (select_area.py:273-275) while lec_fixed takes its
+    box from --box_limits (lec_fixed_framework.py:59-63): with a custom file the data are cropped first and the box is then the
+    nearest grid points INSIDE that crop.  A custom box reaching beyond the crop therefore collapses onto it."""
+    (workdir / "inputs" / "box_limits").write_text("min_lon;-55\nmax_lon;-36\nmin_lat;-35\nmax_lat;-20\n")
+    (workdir / "inputs" / "wide").write_text("min_lon;-70\nmax_lon;-40\nmin_lat;-50\nmax_lat;-25\n")
+    infile = os.path.join(golden_dir, "Catarina_NCEP-R2.nc")
+    _main([infile, "-r", "-f", "--box_limits", "inputs/wide", "-o", "custom"])
+    got = pd.read_csv(workdir / "LEC_Results" / "Catarina_NCEP-R2_fixed" / "custom.csv", index_col=0)
+    dom = o.crop_domain(o.load_ncep_sample(infile, dtype=np.float64), -55, -36, -35, -20)
+    ref, _ = o.lec_fixed(dom, -70, -40, -50, -25)           # nearest points of the CROPPED axes: west and south edges of the crop
+    assert dom.lon[o.select_nearest(dom.lon, -70)] == dom.lon[0] and dom.lat[o.select_nearest(dom.lat, -50)] == dom.lat[0]
+    for c in ("Az", "Ae", "Kz", "Ke", "Cz", "Ca", "Ck", "Ce", "BAz", "BAe", "BKz", "BKe", "Gz", "Ge"):
+        r = np.asarray(ref[c], dtype=np.float64)
+        assert np.max(np.abs(got[c].values - r)) <= 1e-9 * np.max(np.abs(r)), c
+
+
 def test_non_residual_mode_fails_like_the_reference(workdir, golden_dir):
     (workdir / "inputs" / "box_limits").write_text("min_lon;-55\nmax_lon;-36\nmin_lat;-35\nmax_lat;-20\n")
     with pytest.raises(KeyError, match="Friction Velocity"):       # SURVEY B-8: only -r works in the reference
