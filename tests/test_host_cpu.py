@@ -100,6 +100,7 @@ def test_struct_sizes_match_header_layout():
     assert ctypes.sizeof(_lib.ReduceArgs) == 8 + 4 * 4 + 4 * 8 + 8 + 2 * 4 + 8 + 6 * 8
     # lec_ingest_args: pointer + 2 int32 + 4 int32 + 3 int32 (+4 padding) + 3 pointers + 2 int32 + 4 doubles + 2 int32 + 2 pointers
     assert ctypes.sizeof(_lib.IngestArgs) == 8 + 9 * 4 + 4 + 3 * 8 + 2 * 4 + 4 * 8 + 2 * 4 + 2 * 8
+    assert ctypes.sizeof(_lib.DiagArgs) == 3 * 8 + 4 * 4 + 6 * 8        # lec_diag_args: 3 pointers + 4 int32 + 6 pointers
 
 
 def test_argument_errors_without_gpu():
@@ -117,3 +118,6 @@ def test_argument_errors_without_gpu():
     g = _lib.IngestArgs()
     assert lib.lec_ingest(ctypes.byref(g)) == 1 and b"null" in lib.lec_last_error()
     assert lib.lec_ingest(None) == 1
+    d = _lib.DiagArgs()
+    assert lib.lec_track_diag(ctypes.byref(d)) == 1 and b"null" in lib.lec_last_error()
+    assert lib.lec_track_diag(None) == 1
