@@ -17,6 +17,11 @@
 #include "lec_internal.h"
 #include "lec_rowcommon.h"
 
+// Two kernels form the per-level sums (lec_level_terms_kernel for any box height, lec_level_small_kernel for up to 64 rows) from the
+// same source lines (lec_level_row.inc).  Contraction is off in this file so that they also give the same BITS: which products the
+// compiler would fuse into multiply-adds depends on the surrounding code.
+#pragma clang fp contract(off)
+
 namespace {
 using lec::dbl2_t;
 
@@ -181,67 +186,15 @@ __global__ void __launch_bounds__(64) lec_level_terms_kernel(const RedParams p) 
         const double gra = l0[4], grb = l0[5], grc = l0[6];
         const double cm = ltile[(jm - jlo) * kLatStride + 2], cp = ltile[(jp - jlo) * kLatStride + 2];
 
-        const double mT = r[LEC_S_MT], mU = r[LEC_S_MU], mV = r[LEC_S_MV], mW = r[LEC_S_MW];
-        const double mP = r[LEC_S_MP] * ps, mQ = r[LEC_S_MQ];
-        const double Ts = mT - aT, Ws = mW - aW, Ps = mP - aP, Qs = mQ - aQ;      // X* = [X] - {[X]}
-        const double sTT = r[LEC_S_TT], sUU = r[LEC_S_UU], sVV = r[LEC_S_VV], sVT = r[LEC_S_VT], sWT = r[LEC_S_WT];
-        const double sUV = r[LEC_S_UV], sWU = r[LEC_S_WU], sWV = r[LEC_S_WV], sWP = r[LEC_S_WP] * ps, sQT = r[LEC_S_QT];
-
-        const double dphiTc = gra * (rjm[LEC_S_MT] - aT) * cm + grb * Ts * c + grc * (rjp[LEC_S_MT] - aT) * cp;
-        const double dphiUc = gra * (rjm[LEC_S_MU] / cm) + grb * (mU / c) + grc * (rjp[LEC_S_MU] / cp);
-        const double dphiV = gra * rjm[LEC_S_MV] + grb * mV + grc * rjp[LEC_S_MV];
-        const double dpT = pa * (km2.x - aTm) + pb * Ts + pc * (kp2.x - aTp);
-        const double dpU = pa * km2.y + pb * mU + pc * kp2.y;
-
-        acc[V_AZ] += cw * (Ts * Ts);
-        acc[V_AE] += cw * sTT;
-        acc[V_KZ] += cw * (mU * mU + mV * mV);
-        acc[V_KE] += cw * (sUU + sVV);
-        acc[V_CZ2] += cw * (Ws * Ts);
-        acc[V_CE2] += cw * sWT;
-        acc[V_CA1] += cw * (sVT * dphiTc);
-        acc[V_CA2] += cw * (sWT * dpT);
-        acc[V_CK1] += cw * (c * sUV / kRe * dphiUc);
-        acc[V_CK2] += cw * (sVV / kRe * dphiV);
-        acc[V_CK3] += cw * (tn * sUU * mV / kRe);
-        acc[V_CK4] += cw * (sWU * dpU);
-        acc[V_CK5] += cw * (sWV * dpU);   // sic: d[u]/dp, conversion_terms.py:225-229
-        acc[V_GZ] += cw * (Qs * Ts);
-        acc[V_GE] += cw * sQT;
-
-        // east-west pieces, plain trapezoid over phi (boundary_terms.py:135-147,188-197,237-246,287-296,337-344,377-388)
-        const double TW = r[LEC_S_TW], TE = r[LEC_S_TE], uW = r[LEC_S_UW], uE = r[LEC_S_UE], vW = r[LEC_S_VW], vE = r[LEC_S_VE];
-        const double TpW = TW - mT, TpE = TE - mT;
-        const double upW = uW - mU, upE = uE - mU, vpW = vW - mV, vpE = vE - mV;
-        const double EW_ = upW * upW + vpW * vpW, EE_ = upE * upE + vpE * vpE;
-        const double KW_ = uW * uW + vW * vW - EW_, KE_ = uE * uE + vE * vE - EE_;
-        acc[V_B1 + 0] += wphi * (((2 * Ts * TpE * uE) + (Ts * Ts * uE)) - ((2 * Ts * TpW * uW) + (Ts * Ts * uW)));
-        acc[V_B1 + 1] += wphi * (uE * (TpE * TpE) - uW * (TpW * TpW));
-        acc[V_B1 + 2] += wphi * (uE * KE_ - uW * KW_);
-        acc[V_B1 + 3] += wphi * (uE * EE_ - uW * EW_);
-        acc[V_B1 + 4] += wphi * (mV * Ps);
-        acc[V_B1 + 5] += wphi * (vpE * Ps - vpW * Ps);
-
-        // north-south pieces (boundary_terms.py:150-163,200-212,249-262,299-310,347-356,390-399)
-        const double sgn = (jb == nyb - 1 ? 1.0 : 0.0) - (jb == 0 ? 1.0 : 0.0);
-        if (sgn != 0.0) {
-            acc[V_B2 + 0] += sgn * (((sVT * 2 * Ts) + (Ts * Ts * mV)) * c);
-            acc[V_B2 + 1] += sgn * (r[LEC_S_VTT] * c);
-            acc[V_B2 + 2] += sgn * (r[LEC_S_KV] * c);
-            acc[V_B2 + 3] += sgn * (r[LEC_S_EV] * c);
-            acc[V_B2 + 4] += sgn * (mV * Ps * c);
-            acc[V_B2 + 5] += sgn * (mV * Ps * c);   // BPhiE term 2 uses zonal means, boundary_terms.py:390
-        }
-
-        // bottom-top pieces, area means (boundary_terms.py:165-176,214-221,264-271,312-318,358-363,401-413)
-        double x3 = (2 * sWT) * Ts + mW * (Ts * Ts);
-        if (isnan(x3)) x3 = baz3_repaired(p, am, tl, k, jb);        // per latitude, before the area mean (the reference's order)
-        acc[V_B3 + 0] += cw * x3;
-        acc[V_B3 + 1] += cw * r[LEC_S_WTT];
-        acc[V_B3 + 2] += cw * r[LEC_S_KW];
-        acc[V_B3 + 3] += cw * r[LEC_S_EW];
-        acc[V_B3 + 4] += cw * (Ws * Ps);
-        acc[V_B3 + 5] += cw * sWP;
+#define LEC_BAZ3_REPAIR(jb_) baz3_repaired(p, am, tl, k, (jb_))
+#define LEC_ROW_COMMON
+#define LEC_ROW_PART_A
+#define LEC_ROW_PART_B
+#include "lec_level_row.inc"
+#undef LEC_ROW_COMMON
+#undef LEC_ROW_PART_A
+#undef LEC_ROW_PART_B
+#undef LEC_BAZ3_REPAIR
     }
     // static stability (thermodynamics.py:55-70); the zonal/area mean commutes with the linear d/dp
     const double pk = p.levtab2[4 * k + 0];
@@ -276,6 +229,181 @@ __global__ void __launch_bounds__(64) lec_level_terms_kernel(const RedParams p) 
         }
         p.levraw[(size_t)(tl * nl + k) * LEC_NLEVRAW + s] = tot / div;        // x / 1.0 is x
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Boxes of at most 64 latitude rows (the moving framework's 61 x 61 boxes, every regional box on a 2.5-degree grid): one wave per
+// (level, time step), one row per lane, the record in registers, the area means formed here (no lec_area_means_kernel launch, no
+// `am` round trip), neighbouring rows through lane shuffles, no staging tile.  Same row arithmetic (lec_level_row.inc), same butterfly for the area
+// means, same four-chain reduction: the numbers are those of the general kernels, bit for bit.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int kSmallRows = 64;
+constexpr int kSmallRound = 18;       // sums per reduction round (two rounds: 15 + 18)
+
+// {[T]} of another level exactly as that level's own wave forms it: the products of lec_area_means_kernel summed in the order of
+// wave_sum's xor butterfly -- lane 0 ends with ((((l0 + l32) + (l16 + l48)) + ...): pairs 32 apart first, then 16, 8, 4, 2, 1 -- written
+// as five nested two-trip loops (rolled: this is the rare NaN-repair path and must not cost the kernel its registers)
+__device__ double area_mean_T_small(const RedParams& p, const double* lt, int nyb, int tl, int level) {
+    const double* rec = p.rows + (size_t)(tl * p.nl + level) * p.nyb_max * LEC_NSTAT;
+    auto leaf = [&](int l) -> double { return l < nyb ? lt[8 * l] * rec[(size_t)l * LEC_NSTAT + LEC_S_MT] : 0.0; };
+    double a1 = 0.0, a2 = 0.0, a4 = 0.0, a8 = 0.0, a16 = 0.0;
+#pragma unroll 1
+    for (int b1 = 0; b1 < 2; b1 += 1) {
+#pragma unroll 1
+        for (int b2 = 0; b2 < 4; b2 += 2) {
+#pragma unroll 1
+            for (int b4 = 0; b4 < 8; b4 += 4) {
+#pragma unroll 1
+                for (int b8 = 0; b8 < 16; b8 += 8) {
+#pragma unroll 1
+                    for (int b16 = 0; b16 < 32; b16 += 16) {
+                        const int i = b1 | b2 | b4 | b8 | b16;
+                        const double s32 = leaf(i) + leaf(i ^ 32);
+                        a16 = b16 ? a16 + s32 : s32;
+                    }
+                    a8 = b8 ? a8 + a16 : a16;
+                }
+                a4 = b4 ? a4 + a8 : a8;
+            }
+            a2 = b2 ? a2 + a4 : a4;
+        }
+        a1 = b1 ? a1 + a2 : a2;
+    }
+    return a1;
+}
+
+__device__ double baz3_row_small(const RedParams& p, const double* lt, int nyb, int tl, int level, int jb) {
+    const double* r = p.rows + ((size_t)(tl * p.nl + level) * p.nyb_max + jb) * LEC_NSTAT;
+    const double Ts = r[LEC_S_MT] - area_mean_T_small(p, lt, nyb, tl, level);
+    return (2 * r[LEC_S_WT]) * Ts + r[LEC_S_MW] * (Ts * Ts);
+}
+
+// baz3_repaired for the small kernel (no `am` array: the area means of the other levels are re-formed)
+__device__ double baz3_repaired_small(const RedParams& p, const double* lt, int nyb, int tl, int k, int jb) {
+    int lo = k - 1, hi = k + 1;
+    double yl = 0.0, yr = 0.0;
+    for (; lo >= 0; --lo) { yl = baz3_row_small(p, lt, nyb, tl, lo, jb); if (!isnan(yl)) break; }
+    for (; hi < p.nl; ++hi) { yr = baz3_row_small(p, lt, nyb, tl, hi, jb); if (!isnan(yr)) break; }
+    if (lo < 0 || hi >= p.nl) return nan("");
+    const double xl = p.levtab2[4 * lo], xr = p.levtab2[4 * hi];
+    const double slope = (yr - yl) / (xr - xl);
+    return slope * (p.levtab2[4 * k] - xl) + yl;
+}
+
+// `acc[i] += x` of lec_level_row.inc, for a kernel in which every sum receives exactly one contribution per lane: the contribution goes
+// straight to the lane's slot of the reduction buffer instead of waiting in a register (rows below the box contribute 0)
+struct LaneSums {
+    double* slot0; int first; bool in;
+    struct Ref {
+        double* q; bool in;
+        __device__ __forceinline__ void operator+=(double x) const { *q = in ? x : 0.0; }
+    };
+    __device__ __forceinline__ Ref operator[](int i) const { return Ref{slot0 + (i - first) * kPartStride, in}; }
+};
+
+// grid (nl, t_count), block 64; requires nyb_max <= 64
+#ifndef LEC_SMALL_WAVES
+#define LEC_SMALL_WAVES 2       // 193 VGPRs: a cap of 168 (three waves per SIMD) spills and doubles the kernel's time
+#endif
+__global__ void __launch_bounds__(64, LEC_SMALL_WAVES) lec_level_small_kernel(const RedParams p) {
+    __shared__ double part[kSmallRound * kPartStride];
+    const int k = blockIdx.x, tl = blockIdx.y, lane = threadIdx.x;
+    const int nl = p.nl, nyb_max = p.nyb_max;
+    const int bi = (p.n_box == 1) ? 0 : tl;
+    const int km = k > 0 ? k - 1 : k, kp = k < nl - 1 ? k + 1 : k;
+    const size_t lstride = (size_t)nyb_max * LEC_NSTAT;
+    const double* lt = p.lattab2 + (size_t)bi * nyb_max * 8;
+    const double ps = p.phi_scale;
+    // every global load is addressed from the kernel arguments alone (rows below a lower box are zero records or are masked) ...
+    const int jb = lane, jbc = min(jb, nyb_max - 1);
+    const dbl2_t* rr = reinterpret_cast<const dbl2_t*>(p.rows + (size_t)(tl * nl + k) * lstride + (size_t)jbc * LEC_NSTAT);
+    constexpr int kUsed = LEC_S_SPARE / 2;                  // the four spare slots of a record are not read
+    dbl2_t R[kUsed];
+#pragma unroll
+    for (int i = 0; i < kUsed; ++i) R[i] = rr[i];
+    static_assert(LEC_S_MT == 0 && LEC_S_MU == 1 && LEC_S_MV == 2, "the neighbour rows' [T] [u] [v] are read as r[0..2]");
+    const dbl2_t km2 = *reinterpret_cast<const dbl2_t*>(p.rows + (size_t)(tl * nl + km) * lstride + (size_t)jbc * LEC_NSTAT);
+    const dbl2_t kp2 = *reinterpret_cast<const dbl2_t*>(p.rows + (size_t)(tl * nl + kp) * lstride + (size_t)jbc * LEC_NSTAT);
+    const dbl2_t* ll = reinterpret_cast<const dbl2_t*>(lt + (size_t)jbc * 8);
+    const dbl2_t L0 = ll[0], L1 = ll[1], L2 = ll[2], L3 = ll[3];
+    // ... and only now the values that arrive through the scalar cache
+    const int nyb = p.box[4 * bi + 3] - p.box[4 * bi + 2] + 1;
+    const double pk = p.levtab2[4 * k + 0], pa = p.levtab2[4 * k + 1], pb = p.levtab2[4 * k + 2], pc = p.levtab2[4 * k + 3];
+    const bool in = jb < nyb;
+
+    double r[LEC_S_SPARE];
+#pragma unroll
+    for (int i = 0; i < kUsed; ++i) { r[2 * i] = R[i].x; r[2 * i + 1] = R[i].y; }
+    const double cw = L0.x, wphi = L0.y, c = L1.x, tn = L1.y, gra = L2.x, grb = L2.y, grc = L3.x;
+
+    // area means: lec_area_means_kernel's products and butterfly ({[u]} and {[v]} are not used by any term)
+    const double aT = wave_sum(in ? cw * r[0] : 0.0);
+    const double aW = wave_sum(in ? cw * r[3] : 0.0);
+    const double aP = wave_sum(in ? cw * r[4] : 0.0) * ps;
+    const double aQ = wave_sum(in ? cw * r[5] : 0.0);
+    const double aTm = (km == k) ? aT : wave_sum(in ? cw * km2.x : 0.0);
+    const double aTp = (kp == k) ? aT : wave_sum(in ? cw * kp2.x : 0.0);
+
+    // rows j-1 / j+1 from the neighbouring lanes (the first and last row of the box see themselves, like the clamped indices of the
+    // general kernel)
+    const int lm = max(lane - 1, 0), lp = min(lane + 1, max(nyb - 1, 0));
+    double rjm[3], rjp[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) { rjm[s] = __shfl(r[s], lm); rjp[s] = __shfl(r[s], lp); }
+    const double cm = __shfl(c, lm), cp = __shfl(c, lp);
+
+    // static stability (thermodynamics.py:55-70)
+    double sig = kG * aT / kCp - (pk * kG / kRd) * (pa * aTm + pb * aT + pc * aTp);
+    sig = (sig > 0.03) ? sig : 0.03;
+
+    // The row's contributions (every lane computes; lanes below the box are masked where the sums are handed over), in two parts,
+    // each followed by its reduction through one small LDS buffer: lane s adds the 64 partials of sum s in four chains (the general
+    // kernel's order), applies the divisor and stores.
+    double* const out = p.levraw + (size_t)(tl * nl + k) * LEC_NLEVRAW;
+    auto reduce_round = [&](const int s0, const int ns) {
+        __syncthreads();
+        if (lane < ns) {
+            const int s = s0 + lane;
+            const double* q = part + lane * kPartStride;
+            double c0 = q[0], c1 = q[1], c2 = q[2], c3 = q[3];
+#pragma unroll
+            for (int l = 4; l < 64; l += 4) { c0 += q[l]; c1 += q[l + 1]; c2 += q[l + 2]; c3 += q[l + 3]; }
+            const double tot = (c0 + c1) + (c2 + c3);
+            double div = 1.0;
+            const int b = (s >= V_B1) ? (s - V_B1) % 6 : -1;         // boundary pieces: Az Ae | Kz Ke | PhiZ PhiE
+            if (s == V_AZ || s == V_AE || b == 0 || b == 1) div = 2 * sig;
+            else if (b == 2 || b == 3) div = 2 * kG;
+            else if (b == 4 || b == 5) div = kG;
+            else if (s == V_CA1) div = 2 * kRe * sig;
+            else if (s == V_CA2) div = sig;
+            else if (s == V_GZ || s == V_GE) div = kCp * sig;
+            out[s] = tot / div;
+        }
+        __syncthreads();
+    };
+    static_assert(V_B1 <= kSmallRound && V_SIG - V_B1 <= kSmallRound, "a reduction round must fit the buffer");
+#define LEC_BAZ3_REPAIR(jb_) (in ? baz3_repaired_small(p, lt, nyb, tl, k, (jb_)) : 0.0)
+#define LEC_ROW_COMMON
+#include "lec_level_row.inc"
+#undef LEC_ROW_COMMON
+    {
+        const LaneSums acc{part + lane, 0, in};
+#define LEC_ROW_PART_A
+#include "lec_level_row.inc"
+#undef LEC_ROW_PART_A
+    }
+    reduce_round(0, V_B1);
+    {
+#pragma unroll
+        for (int i = 0; i < V_SIG - V_B1; ++i) part[i * kPartStride + lane] = 0.0;      // the north-south sums take a row at either end only
+        const LaneSums acc{part + lane, V_B1, in};
+#define LEC_ROW_PART_B
+#include "lec_level_row.inc"
+#undef LEC_ROW_PART_B
+    }
+    reduce_round(V_B1, V_SIG - V_B1);
+#undef LEC_BAZ3_REPAIR
+    if (lane < LEC_NLEVRAW - V_SIG) out[V_SIG + lane] = (lane == 0) ? sig : 0.0;
 }
 
 // functions of level handled by lec_vertical_kernel (one lane each)
@@ -456,8 +584,12 @@ static int reduce_impl(const lec_reduce_args* a, bool mask_only, const char* who
     p.drop_any_time = (a->drop_any_time || mask_only) ? 1 : 0; p.dropmask = a->dropmask_d;
     hipStream_t st = (hipStream_t)a->stream;
     const dim3 grid2(a->nl, a->t_count);
-    hipLaunchKernelGGL(lec_area_means_kernel, grid2, dim3(64), 0, st, p);
-    hipLaunchKernelGGL(lec_level_terms_kernel, grid2, dim3(64), 0, st, p);
+    if (a->nyb_max <= kSmallRows) {
+        hipLaunchKernelGGL(lec_level_small_kernel, grid2, dim3(64), 0, st, p);       // forms its own area means; am_d is not used
+    } else {
+        hipLaunchKernelGGL(lec_area_means_kernel, grid2, dim3(64), 0, st, p);
+        hipLaunchKernelGGL(lec_level_terms_kernel, grid2, dim3(64), 0, st, p);
+    }
     if (mask_only || a->drop_any_time == 1) {
         if (hipMemsetAsync(p.dropmask, 0, sizeof(int) * F_COUNT * a->nl, st) != hipSuccess) return lec_set_error(LEC_ERR_LAUNCH, "lec_reduce: hipMemsetAsync failed");
         hipLaunchKernelGGL(lec_dropmask_kernel, dim3(a->t_count), dim3(64), 0, st, p);

@@ -273,6 +273,32 @@ def test_moving_boxes_of_mixed_widths_shard_bit_identically(nonuni):
         assert torch.equal(part.scalars, whole.scalars[a:b]), (a, b)
 
 
+@pytest.mark.parametrize("moving", [False, True])
+def test_small_box_level_kernel_gives_the_bits_of_the_general_one(moving):
+    """Stage 2 has a kernel for boxes of up to 64 rows (one row per lane, area means formed in place) and a general one (rows staged
+    64 at a time).  The same records in a buffer padded to 70 rows take the general path: every output must carry the same bits,
+    NaN repair included."""
+    nt, nl, ny, nx = 6, 8, 80, 60
+    dom = synthetic_domain(nt, nl, ny, nx, seed=91)
+    dom.tair[1:3, -1, 5:9, 10:20] = np.nan
+    dom.omega[1:3, 4, 12:15, 10:20] = np.nan
+    eng = _engine(dom)
+    f = [_dev(a) for a in (dom.tair, dom.u, dom.v, dom.omega, dom.geopt)]
+    boxes = [(3 + t, 50 + t, 2, 40 - t) for t in range(nt)] if moving else [(3, 55, 1, 41)]
+    kw = dict(time_s=dom.time_s, per_step_boxes=moving)
+    small = eng.compute(*f, boxes, keep_rows=True, **kw)
+    nyb = small.rows.shape[2]
+    assert nyb <= 64
+    padded = torch.zeros((nt, nl, 70, small.rows.shape[3]), dtype=torch.float64, device="cuda:0")
+    eng.rowstats(*f, boxes, rows_out=padded, **kw)
+    assert torch.equal(torch.nan_to_num(padded[:, :, :nyb], nan=-7.0), torch.nan_to_num(small.rows, nan=-7.0))
+    general = eng.reduce(padded, boxes, drop_any_time=not moving)
+    for name in ("scalars", "levels"):
+        a, b = getattr(small, name), getattr(general, name)
+        assert torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0)), name
+    assert torch.equal(small.nanflag, general.nanflag) and int(small.nanflag.sum()) > 0
+
+
 def test_random_domains_against_the_oracle():
     """Twelve random small domains (3..6 time steps on an uneven time axis, 3..9 levels, boxes of 3..70 columns x 3..18 rows, uniform
     or table longitudes, fp32 / fp64 storage): all 16 terms, budgets, residuals and 21 level tables of the fixed and of the moving
