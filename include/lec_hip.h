@@ -171,7 +171,7 @@ typedef struct lec_reduce_args {
                                       shard / chunk of the series and merged the masks (element-wise max) */
     int32_t reserved0;
     int32_t* dropmask_d;        /* [LEC_NLEVFUN][nl] (needed when drop_any_time): workspace zeroed by the call (mode 1), input (mode 2) */
-    double* am_d;               /* workspace [t_count][nl][8]  area means */
+    double* am_d;               /* workspace [t_count][nl][8]  area means (always required; left untouched when nyb_max <= 64) */
     double* levraw_d;           /* workspace [t_count][nl][LEC_NLEVRAW] */
     double* scalars_d;          /* out [t_count][LEC_NSCALAR] */
     double* levels_d;           /* out [t_count][LEC_NLEVTAB][nl] */
