@@ -23,6 +23,9 @@
  *                 (calc_averages.py:46-78), StaticStability (thermodynamics.py:26-73), the
  *                 differentiate("rlats"/level) calls, _handle_nans (energy_contents.py:190-208),
  *                 and the integrate(level) epilogues.
+ *   lec_track_diag  replaces MetPy's wind_speed / vorticity on the 850-hPa slice and get_position /
+ *                 find_extremum_coordinates of the moving framework
+ *                 (src/frameworks/lec_moving_framework.py:269-417,650-663; src/utils/tools.py:95-128).
  *
  * Conventions
  *   - All pointers named *_d are DEVICE pointers owned by the caller; the library allocates nothing.
