@@ -82,7 +82,8 @@ typedef struct lec_tuning {
     int32_t block_shape;   /* LEC_KERNEL_ROW_BLOCK: 100 bt + 10 bk + bj waves (time x level x latitude, each 1 or 2); 0 = 212 */
     int32_t order;         /* enum lec_order */
     int32_t tile_t, tile_j; /* tile extents of LEC_ORDER_XCD_TILED / of the row-block kernel (in blocks); box tiles: tile_t = time steps per
-                               workgroup group, tile_j = levels per wave (default: from the launch size); 0 = default; must be >= 0 */
+                               workgroup group, tile_j = levels per wave (default: from the launch size; at most 21, more is LEC_ERR_ARG);
+                               0 = default; must be >= 0 */
     int32_t f32_vec;       /* fp32 storage, one wave per row: 0 = float4 trips when the cubes are 16-byte aligned, 2 = float2 trips */
     int32_t reserved[2];   /* must be 0 */
 } lec_tuning;

@@ -60,6 +60,8 @@ constexpr int kSide = 16;            // per-row side values: 5 shifts, f of the 
 #endif
 constexpr int kLevelsFixed = LEC_BT_LEVELS;     // > 0: levels per wave fixed at build time (experiments); 0: p.jgroup, chosen per launch
 constexpr int kMinLevels = 5;                   // the T window's prologue (two extra level loads) is paid once per chunk of levels
+constexpr int kMaxLevels = 21;                  // a wave keeps its chunk's static-stability coefficients one per lane (3 per level: `levv`)
+static_assert(3 * kMaxLevels <= 64, "the level coefficients of a wave's chunk must fit one value per lane");
 constexpr int kLB = 4;               // levels whose rows are finished together (16 lanes: 4 levels x 4 rows)
 constexpr int kPS = 65;              // stride between the statistics of the partial-sum array (odd: conflict-free both ways)
 
@@ -167,7 +169,7 @@ __global__ void __launch_bounds__(64, 2) lec_boxtile_kernel(const RowParams p) {
     // with VECTOR loads followed by s_waitcnt vmcnt(0) -- draining the prefetched rows every time.  So they are loaded once, here,
     // spread over the lanes, and picked with v_readlane:
     //   latv: lane 4 i + j = coefficient j (d/dlat a, b, c; 1/dx) of the wave's row i;  levv: lane 3 kk + j = static-stability
-    //   coefficient j of level k0 + kk
+    //   coefficient j of level k0 + kk -- so a wave walks at most kMaxLevels = 21 levels (launch_tiles enforces it)
     double latv = 0.0, levv = 0.0;
     if (WITH_Q) {
         const int jrow = min(jb0 + ((lane >> 2) & 3), nyb - 1);
@@ -458,12 +460,14 @@ int launch_tiles(RowParams p, bool uniform, int mode, hipStream_t st) {
     // levels per wave: as many as still leave kTargetWaves one-wave workgroups (four rounds of the 2048 the chip holds at two per SIMD)
     // -- long level walks read best (profiles/r02_notes.md: 4 rows x 37 levels 6 % ahead of 4 x 10), short launches need the waves
     if (kLevelsFixed > 0) p.jgroup = kLevelsFixed;
+    if (p.jgroup > kMaxLevels) return LEC_ERR_ARG;       // never clamped: the caller asked for something the kernel cannot do
     if (p.jgroup < 1) {
         constexpr long long kTargetWaves = 8192;
         const long long per_chunk = 8LL * p.jchunk * n_rb;
         const long long want = (kTargetWaves + per_chunk - 1) / per_chunk;
-        const long long n_kc0 = want < 1 ? 1 : (want > (p.nl + kMinLevels - 1) / kMinLevels ? (p.nl + kMinLevels - 1) / kMinLevels : want);
-        p.jgroup = (int)((p.nl + n_kc0 - 1) / n_kc0);
+        const long long most = (p.nl + kMinLevels - 1) / kMinLevels, least = (p.nl + kMaxLevels - 1) / kMaxLevels;
+        const long long n_kc0 = want < least ? least : (want > most ? most : want);
+        p.jgroup = (int)((p.nl + n_kc0 - 1) / n_kc0);     // <= kMaxLevels: n_kc0 >= ceil(nl / kMaxLevels)
     }
     if (p.jgroup > p.nl) p.jgroup = p.nl;
     const long long n_kc = (p.nl + p.jgroup - 1) / p.jgroup;
@@ -487,7 +491,7 @@ int launch_tiles(RowParams p, bool uniform, int mode, hipStream_t st) {
 }  // namespace
 
 // mode: 0 no Q, 1 dT/dt from the cube's time neighbours per point, 2 dT/dt cube; p.tgroup: time steps per tile group, p.jgroup: levels
-// per wave (< 1: chosen here)
+// per wave (< 1: chosen here; more than 21: LEC_ERR_ARG)
 int lec_launch_boxtile(const lec::RowParams& p, int dtype, bool uniform, int mode, hipStream_t st) {
     return dtype == LEC_F64 ? launch_tiles<double>(p, uniform, mode, st) : launch_tiles<float>(p, uniform, mode, st);
 }

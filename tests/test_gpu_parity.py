@@ -248,6 +248,53 @@ def test_box_tile_kernel_random_geometries():
         assert torch.isfinite(a.rows).all(), case
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_box_tile_long_level_walks(dtype):
+    """The box-tile kernel with MANY levels per wave (a wave keeps its chunk's static-stability coefficients one per lane,
+    21 levels at most; every earlier moving test had <= 6 time steps, so the launch rule always picked 5-level chunks).  37 and 45
+    levels, Q from the time axis: level chunks of 5, 8, 19, 21 and the automatic choice give the SAME BITS, agree with the independent
+    one-wave-per-row kernel record by record and with the oracle; 22 levels per wave is refused."""
+    for nl in (37, 45):
+        nt = 3
+        dom = synthetic_domain(nt, nl, 30, 70, seed=300 + nl, dtype=dtype, dt_s=3600.0)
+        boxes = [(4 + t, 4 + t + 40, 3 + 2 * t, 3 + 2 * t + 17) for t in range(nt)]
+        limits = [(dom.lon[b[0]], dom.lon[b[1]], dom.lat[b[2]], dom.lat[b[3]]) for b in boxes]
+        eng = _engine(dom)
+        f = [_dev(a) for a in (dom.tair, dom.u, dom.v, dom.omega, dom.geopt)]
+        kw = dict(time_s=dom.time_s, keep_rows=True, per_step_boxes=True)
+        auto = eng.compute(*f, boxes, **kw)
+        for tj in (5, 8, 19, 21):
+            r = eng.compute(*f, boxes, tuning={"kernel": "box_tile", "tile_j": tj}, **kw)
+            assert torch.equal(r.rows, auto.rows), (nl, tj)
+            assert torch.equal(r.scalars, auto.scalars) and torch.equal(r.levels, auto.levels), (nl, tj)
+        sweep = eng.compute(*f, boxes, tuning={"kernel": "row_sweep"}, **kw)
+        _rows_close(auto, sweep, f"box tiles vs one wave per row, {nl} levels")
+        with pytest.raises(ValueError, match="21 levels"):
+            eng.compute(*f, boxes, tuning={"kernel": "box_tile", "tile_j": 22}, **kw)
+        if nl == 37:
+            ref_s, ref_l = o.lec_moving(as_f64(dom), limits)
+            compare(auto.scalars_dict(), auto.levels_dict(), ref_s, ref_l, TOL, f"long level walk {np.dtype(dtype).name}")
+
+
+def test_box_tile_launch_rule_at_long_series():
+    """A series long enough (2048 steps of a low box) for the launch rule to pick its LONGEST level walk (two chunks of 19 for 37
+    levels -- it used to pick one of 37 and read other levels' coefficients): same bits as 5-level chunks, and the one-wave-per-row
+    kernel agrees."""
+    nt, nl = 2048, 37
+    dom = synthetic_domain(4, nl, 20, 40, seed=77, dt_s=3600.0)
+    rep = lambda a: _dev(a).repeat((nt // 4, 1, 1, 1)).contiguous()
+    f = [rep(a) for a in (dom.tair, dom.u, dom.v, dom.omega, dom.geopt)]
+    f[0] += torch.linspace(0, 1, nt, dtype=torch.float64, device="cuda:0")[:, None, None, None]     # dT/dt differs per step
+    boxes = [(2 + t % 5, 2 + t % 5 + 30, 1 + t % 3, 1 + t % 3 + 15) for t in range(nt)]      # 16 rows: 8 x 256 x 4 = 8192 waves per level chunk
+    eng = _engine(dom)
+    kw = dict(time_s=np.arange(nt) * 3600.0, keep_rows=True, per_step_boxes=True)
+    auto = eng.compute(*f, boxes, **kw)
+    five = eng.compute(*f, boxes, tuning={"kernel": "box_tile", "tile_j": 5}, **kw)
+    assert torch.equal(auto.rows, five.rows) and torch.equal(auto.scalars, five.scalars)
+    sweep = eng.compute(*f, boxes, tuning={"kernel": "row_sweep"}, **kw)
+    _rows_close(auto, sweep, "2048-step series: box tiles vs one wave per row")
+
+
 @pytest.mark.parametrize("nonuni", [False, True])
 def test_moving_boxes_of_mixed_widths_shard_bit_identically(nonuni):
     """A track whose boxes are 40 to 90 columns wide.  The box-tile kernel keeps the level window in registers only when every row of
@@ -586,6 +633,8 @@ def test_tuning_is_validated():
             run_fixed(dom, limits, tuning=bad)
     with pytest.raises(ValueError):
         run_fixed(dom, limits, tuning={"kernel": "fastest"})
+    with pytest.raises(ValueError, match="21 levels"):          # the box-tile kernel's level walk is bounded by its coefficient register
+        run_fixed(dom, limits, tuning={"kernel": "box_tile", "tile_j": 22})
 
 
 def test_errors():
