@@ -54,12 +54,33 @@ def scale_err(a, r):
     return float(np.max(np.abs(a - r)) / den) if den > 0 else float(np.max(np.abs(a - r)))
 
 
-def compare(engine_scalars, engine_levels, ref_scalars, ref_levels, tol, what=""):
-    """Every integrated term and level table within `tol` of the oracle, relative to the term's scale."""
+BUDGETS = {"∂Az/∂t (finite diff.)": ("Az",), "∂Ae/∂t (finite diff.)": ("Ae",), "∂Kz/∂t (finite diff.)": ("Kz",), "∂Ke/∂t (finite diff.)": ("Ke",)}
+RESIDUALS = {"RGz": ("Az", "Cz", "Ca", "BAz"), "RKz": ("Kz", "Cz", "Ck", "BKz"), "RGe": ("Ae", "Ca", "Ce", "BAe"), "RKe": ("Ke", "Ce", "Ck", "BKe")}
+
+
+def compare(engine_scalars, engine_levels, ref_scalars, ref_levels, tol, what="", *, time_s):
+    """Every integrated term and level table within `tol` of the oracle, relative to the term's scale -- and the budget / residual
+    columns of the results CSV (calc_budget_and_residual.py:32-56,131-154): the product's host code (tables.budgets_and_residuals) on
+    the engine's series over `time_s` against the oracle's columns.  A budget is a difference of neighbouring energies over dt, so its
+    error is judged against max|X| / dt (the scale of what is subtracted), a residual's against the largest of its operands' scales."""
+    from lorenzcycletoolkit_amd import tables
     worst = {}
     for name in SCALARS:
         if name in ref_scalars:
             worst[name] = scale_err(engine_scalars[name], ref_scalars[name])
+    if len(time_s) >= 2:
+        has_res = "RGz" in ref_scalars
+        full = tables.budgets_and_residuals({k: np.asarray(v, dtype=np.float64) for k, v in engine_scalars.items()}, np.asarray(time_s), residuals=has_res)
+        dt = float(time_s[1] - time_s[0])
+        top = lambda n: float(np.nanmax(np.abs(np.asarray(ref_scalars[n], dtype=np.float64)))) if np.isfinite(np.asarray(ref_scalars[n], dtype=np.float64)).any() else 1.0
+        for col, ops in {**BUDGETS, **(RESIDUALS if has_res else {})}.items():
+            a, r = np.asarray(full[col], dtype=np.float64), np.asarray(ref_scalars[col], dtype=np.float64)
+            if not np.array_equal(np.isnan(a), np.isnan(r)):
+                worst["budget:" + col] = float("inf")
+                continue
+            ok = ~np.isnan(r)
+            scale = max([top(ops[0]) / dt] + [top(n) for n in ops[1:]])
+            worst["budget:" + col] = float(np.max(np.abs(a[ok] - r[ok])) / scale) if ok.any() else 0.0
     for name, ref in ref_levels.items():
         ref = np.asarray(ref, dtype=np.float64)
         got = engine_levels[name]

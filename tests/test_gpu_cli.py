@@ -235,3 +235,67 @@ def test_era5_style_fixed_and_track_cli(workdir, golden_dir):
     _main(["testdata_ERA5.nc", "-r", "-t", "--device-ingest"])
     for f, b in before.items():
         assert (tdir / f).read_bytes() == b, f
+
+
+def test_outputs_feed_the_reference_plot_readers(workdir, golden_dir):
+    """the reference's plot scripts consume only the CSVs, through four readers (src/plots/utils.py:79-193 of the
+    reference: read_results, read_track, read_box_limits, get_data_vertical_levels).  The readers are restated here as the pandas
+    calls they make and run over the -f and -t outputs and the *_trackfile: index types, column sets and headers are what the plot
+    code indexes by."""
+    import re
+    from glob import glob
+
+    def read_results(path):                                   # plots/utils.py:79-94
+        df = pd.read_csv(path, index_col=[0])
+        df["Datetime"] = pd.to_datetime(df.index)
+        return df.set_index("Datetime")
+
+    def read_track(path):                                     # plots/utils.py:110-121
+        return pd.read_csv(path, parse_dates=[0], delimiter=";", index_col="time")
+
+    def read_box_limits(path):                                # plots/utils.py:138-153
+        df = pd.read_csv(path, sep=";", index_col=0, header=None)
+        return df.loc[["min_lon", "max_lon", "min_lat", "max_lat"]]
+
+    def get_data_vertical_levels(results_subdirectory):      # plots/utils.py:156-193: split terms (Cz_1, Ck_3, ...) are skipped
+        files = [f for f in glob(os.path.join(results_subdirectory, "results_vertical_levels", "*.csv"))
+                 if not re.search(r"_[0-9]", os.path.basename(f))]
+        data = {}
+        for f in files:
+            term = os.path.splitext(os.path.basename(f))[0].split("_")[0]
+            data[term] = pd.read_csv(f, header=0, index_col=0, parse_dates=True)
+            data[term].columns = [float(x) for x in data[term].columns]
+        return data
+
+    (workdir / "inputs" / "box_limits").write_text("min_lon;-55\nmax_lon;-36\nmin_lat;-35\nmax_lat;-20\n")
+    _main([os.path.join(golden_dir, "Catarina_NCEP-R2.nc"), "-r", "-f"])
+    shutil.copy(os.path.join(golden_dir, "inputs", "track_testdata_NCEP-R2"), workdir / "inputs" / "track")
+    _main([os.path.join(golden_dir, "testdata_NCEP-R2.nc"), "-r", "-t"])
+    fixed, track = workdir / "LEC_Results" / "Catarina_NCEP-R2_fixed", workdir / "LEC_Results" / "testdata_NCEP-R2_track"
+
+    box = read_box_limits(workdir / "inputs" / "box_limits")
+    assert box.loc["min_lon"].iloc[0] == -55 and box.loc["max_lat"].iloc[0] == -20
+
+    ten = {"Az", "Ae", "Kz", "Ke", "Cz", "Ca", "Ck", "Ce", "Gz", "Ge"}
+    for out, name, nt, nl, extra in ((fixed, "Catarina_NCEP-R2_fixed_results.csv", 36, 17, set()),
+                                      (track, "testdata_NCEP-R2_track_results.csv", 5, 5, {"BΦZ", "BΦE"})):
+        df = read_results(out / name)
+        assert isinstance(df.index, pd.DatetimeIndex) and df.index.is_monotonic_increasing and len(df) == nt
+        # what timeseries / LEC-diagram / LPS plots index by (plots/plot_timeseries.py, plot_LEC.py, plot_LPS.py of the reference)
+        need = ten | {"BAz", "BAe", "BKz", "BKe", "RGz", "RKz", "RGe", "RKe"} | {f"∂{t}/∂t (finite diff.)" for t in ("Az", "Ae", "Kz", "Ke")} | extra
+        assert need <= set(df.columns) and all(df[c].dtype == np.float64 for c in df.columns)
+        lv = get_data_vertical_levels(str(out))
+        assert set(lv) == ten                               # one table per un-split term
+        for term, tab in lv.items():
+            assert tab.shape == (nt, nl) and tab.columns[0] < tab.columns[-1] and tab.columns[-1] == 100000.0, term      # Pa, top -> bottom
+            assert isinstance(tab.index, pd.DatetimeIndex) and list(tab.index) == list(df.index), term                # Hovmoller x-axis
+            assert np.isfinite(tab.values).all(), term
+        # integrating a level table over pressure reproduces the results column (what plot_hovmoller's users cross-check)
+        p = np.array(lv["Kz"].columns)
+        kz = np.trapz(lv["Kz"].values, p, axis=1) / (2 * o.G) if hasattr(np, "trapz") else np.trapezoid(lv["Kz"].values, p, axis=1) / (2 * o.G)
+        assert np.allclose(kz, df["Kz"].values, rtol=1e-12)
+
+    trk = read_track(track / "testdata_NCEP-R2_track_trackfile")
+    assert trk.index.name == "time" and len(trk) == 5
+    for col in ("Lat", "Lon", "length", "width", "min_lon", "max_lon", "min_lat", "max_lat", "min_max_zeta_850", "min_hgt_850", "max_wind_850"):
+        assert col in trk.columns and np.issubdtype(trk[col].dtype, np.number), col      # plot_track / plot_box_limits read these

@@ -52,7 +52,7 @@ def check_fixed(dom, limits, tol=TOL, what=""):
     res = run_fixed(dom, limits)
     assert int(res.nanflag.sum()) == 0
     ref_s, ref_l = o.lec_fixed(as_f64(dom), *limits)
-    return compare(res.scalars_dict(), res.levels_dict(), ref_s, ref_l, tol, what)
+    return compare(res.scalars_dict(), res.levels_dict(), ref_s, ref_l, tol, what, time_s=dom.time_s)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -88,7 +88,7 @@ def test_testdata_fixed_box_inside_domain(golden_dir):
     limits = (-60, -30, -42.5, -17.5)
     res = run_fixed(dom, limits)
     ref_s, ref_l = o.lec_fixed(o.crop_domain(dom, *limits), *limits)
-    compare(res.scalars_dict(), res.levels_dict(), ref_s, ref_l, TOL, "testdata fixed")
+    compare(res.scalars_dict(), res.levels_dict(), ref_s, ref_l, TOL, "testdata fixed", time_s=dom.time_s)
 
 
 def test_testdata_moving(golden_dir):
@@ -99,7 +99,7 @@ def test_testdata_moving(golden_dir):
     limits = [(lo - 7.5, lo + 7.5, la - 7.5, la + 7.5) for la, lo in zip(tr.Lat, tr.Lon)]
     res = run_moving(domt, limits)
     ref_s, ref_l = o.lec_moving(domt, limits)
-    compare(res.scalars_dict(), res.levels_dict(), ref_s, ref_l, TOL, "testdata moving")
+    compare(res.scalars_dict(), res.levels_dict(), ref_s, ref_l, TOL, "testdata moving", time_s=dom.time_s)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -159,7 +159,7 @@ def test_synthetic_moving_variable_boxes():
     limits = [(lo - w / 2, lo + w / 2, la - l / 2, la + l / 2) for (la, lo), (w, l) in zip(cen, size)]
     res = run_moving(dom, limits)
     ref_s, ref_l = o.lec_moving(dom, limits)
-    compare(res.scalars_dict(), res.levels_dict(), ref_s, ref_l, TOL, "moving variable boxes")
+    compare(res.scalars_dict(), res.levels_dict(), ref_s, ref_l, TOL, "moving variable boxes", time_s=dom.time_s)
 
 
 def _rows_close(a, b, what, tol=1e-11, scalar_rtol=1e-10):
@@ -188,7 +188,7 @@ def test_config5_shape_moving_boxes(dtype):
     res = eng.compute(*f, boxes, time_s=dom.time_s, keep_rows=True)
     torch.cuda.synchronize()
     ref_s, ref_l = o.lec_moving(as_f64(dom), limits)
-    compare(res.scalars_dict(), res.levels_dict(), ref_s, ref_l, TOL, f"config-5 shape {np.dtype(dtype).name}")
+    compare(res.scalars_dict(), res.levels_dict(), ref_s, ref_l, TOL, f"config-5 shape {np.dtype(dtype).name}", time_s=dom.time_s)
     # shards / chunks of the series (each sees the cube's time neighbours as its halo)
     for a, b in ((0, 2), (2, 5), (5, 6)):
         part = eng.compute(*f, boxes[a:b], time_s=dom.time_s, t_begin=a, t_count=b - a, keep_rows=True, per_step_boxes=True)
@@ -273,7 +273,7 @@ def test_box_tile_long_level_walks(dtype):
             eng.compute(*f, boxes, tuning={"kernel": "box_tile", "tile_j": 22}, **kw)
         if nl == 37:
             ref_s, ref_l = o.lec_moving(as_f64(dom), limits)
-            compare(auto.scalars_dict(), auto.levels_dict(), ref_s, ref_l, TOL, f"long level walk {np.dtype(dtype).name}")
+            compare(auto.scalars_dict(), auto.levels_dict(), ref_s, ref_l, TOL, f"long level walk {np.dtype(dtype).name}", time_s=dom.time_s)
 
 
 def test_box_tile_launch_rule_at_long_series():
@@ -312,7 +312,7 @@ def test_moving_boxes_of_mixed_widths_shard_bit_identically(nonuni):
     f = [_dev(a) for a in (dom.tair, dom.u, dom.v, dom.omega, dom.geopt)]
     whole = eng.compute(*f, boxes, time_s=dom.time_s, keep_rows=True)
     ref_s, ref_l = o.lec_moving(dom, limits)
-    compare(whole.scalars_dict(), whole.levels_dict(), ref_s, ref_l, TOL, "mixed widths")
+    compare(whole.scalars_dict(), whole.levels_dict(), ref_s, ref_l, TOL, "mixed widths", time_s=dom.time_s)
     for a, b in ((0, 1), (2, 4), (5, 6), (0, 3)):
         part = eng.compute(*f, boxes[a:b], time_s=dom.time_s, t_begin=a, t_count=b - a, keep_rows=True, per_step_boxes=True)
         ny = part.rows.shape[2]
@@ -371,7 +371,7 @@ def test_random_domains_against_the_oracle():
         res = eng.compute(*[_dev(a) for a in (dom.tair, dom.u, dom.v, dom.omega, dom.geopt)], [eng.box_from_limits(*lm) for lm in per_step],
                           time_s=dom.time_s)          # dT/dt over the series' time axis on the device, as the moving framework does
         ref_s, ref_l = o.lec_moving(as_f64(dom), per_step)
-        compare(res.scalars_dict(), res.levels_dict(), ref_s, ref_l, TOL, what + " moving")
+        compare(res.scalars_dict(), res.levels_dict(), ref_s, ref_l, TOL, what + " moving", time_s=dom.time_s)
 
 
 def test_fixed_box_kernels_random_geometries():
@@ -446,7 +446,7 @@ def test_box_tile_kernel_shapes(ny, nx, nonuni, dtype):
     limits = (dom.lon[1], dom.lon[nx], dom.lat[2], dom.lat[ny + 1])
     res = run_fixed(dom, limits, tuning={"kernel": "box_tile"}, keep_rows=True)
     ref_s, ref_l = o.lec_fixed(as_f64(o.crop_domain(dom, *limits)), *limits)
-    compare(res.scalars_dict(), res.levels_dict(), ref_s, ref_l, TOL, f"box tiles {ny}x{nx}")
+    compare(res.scalars_dict(), res.levels_dict(), ref_s, ref_l, TOL, f"box tiles {ny}x{nx}", time_s=dom.time_s)
     sweep = run_fixed(dom, limits, tuning={"kernel": "row_sweep"}, keep_rows=True)
     _rows_close(res, sweep, "box tiles vs one wave per row")
     eng = _engine(dom)
@@ -567,7 +567,7 @@ def test_nans_in_T_and_omega_follow_handle_nans(case):
     assert int(res.nanflag.max()) > 0
     with np.errstate(invalid="ignore"):
         ref_s, ref_l = o.lec_fixed(dom, *limits)
-    worst = compare(res.scalars_dict(), res.levels_dict(), ref_s, ref_l, 1e-9, f"NaN case {case}")
+    worst = compare(res.scalars_dict(), res.levels_dict(), ref_s, ref_l, 1e-9, f"NaN case {case}", time_s=dom.time_s)
     got = res.scalars_dict()
     assert all(np.isfinite(got[k]).all() for k in SCALARS), "every integrated term survives: levels were repaired or dropped"
     print(case, max(worst.values()))
@@ -674,7 +674,7 @@ def test_full_size_band_and_properties(dtype):
     dom = o.Domain(crop(f["tair"]), crop(f["u"]), crop(f["v"]), crop(f["omega"]), crop(f["geopt"]),
                    lat[js:jn + 1], lon[iw:ie + 1], level, time_s)
     ref_s, ref_l = o.lec_fixed(dom, lon[iw], lon[ie], lat[js], lat[jn])
-    compare(res.scalars_dict(), res.levels_dict(), ref_s, ref_l, 1e-8, "full-size band")
+    compare(res.scalars_dict(), res.levels_dict(), ref_s, ref_l, 1e-8, "full-size band", time_s=dom.time_s)
     # (2) whole grid without the polar rows: finite, shard-invariant, and energy scaling:
     #     doubling u and v multiplies Kz, Ke, BKz, BKe by 4 / 4 / 8 / 8 exactly (powers of two).
     box = eng.box_from_limits(-180, 179.75, -89.75, 89.75)
