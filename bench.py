@@ -58,6 +58,8 @@ def parse_args(argv=None):
     ap.add_argument("--moving", action="store_true", help="semi-Lagrangian configuration: one 15x15 degree box per time step "
                     "on a track-extent crop of the 0.25 degree grid (BASELINE config 5)")
     ap.add_argument("--tuning", type=str, default="", help="A/B runs: lec_tuning fields, e.g. kernel=row_sweep,tile_t=4 (default: the library's choice)")
+    ap.add_argument("--force-dist", action="store_true", help="with one rank: still create the process group and run the collectives "
+                    "(the N > 1 code path -- RCCL init, barrier, mask all_reduce, gather -- on a one-GPU box)")
     ap.add_argument("--ny", type=int, default=721)
     ap.add_argument("--nx", type=int, default=1440)
     return ap.parse_args(argv)
@@ -110,70 +112,125 @@ def launch_ranks(args) -> int:
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# CPU baseline: the NumPy oracle (the reference's eager op sequence) on the GPU box's host cores
+# CPU baseline + full-size parity: the NumPy oracle (the reference's eager op sequence) on the GPU box's host cores
 # ---------------------------------------------------------------------------------------------------------------------
-def _oracle_band(nt, ny, seed):
-    """Seconds the oracle needs for `nt` time steps of a 37 x ny x 1440 latitude band of the benchmark grid (all 16 terms)."""
+def _oracle_run(fields, lat, lon, level, time_s, limits):
+    """(seconds, scalars, levels) of the oracle's fixed framework (all 16 terms) on host cubes [nt, nl, ny, nx]."""
     from oracle import lec_oracle as o
+    dom = o.Domain(fields["tair"], fields["u"], fields["v"], fields["omega"], fields["geopt"], lat, lon, level, time_s)
+    t0 = time.perf_counter()
+    with np.errstate(all="ignore"):          # a box that holds the polar rows divides by cos(90 deg) in the reference too (SURVEY F7)
+        sc, lv = o.lec_fixed(dom, *limits)
+    return time.perf_counter() - t0, sc, lv
+
+
+def _synthetic_band_host(nt, ny, seed):
+    """Host copy of the synthetic recipe on a 37 x ny x 1440 latitude band (the all-cores figure: every worker makes its own)."""
     from lorenzcycletoolkit_amd.synthetic import era5_like_levels
+    from oracle import lec_oracle as o
     rng = np.random.default_rng(seed)
     nx = 1440
     level = era5_like_levels()
-    lat = (np.linspace(-90.0, 90.0, 721) if ny == 721 else -45.0 + 0.25 * np.arange(ny))
+    lat = -45.0 + 0.25 * np.arange(ny)
     lon = np.linspace(-180.0, 179.75, nx)
     p = level[None, :, None, None]
     phi, lam = np.deg2rad(lat)[None, None, :, None], np.deg2rad(lon)[None, None, None, :]
     shp = (nt, level.size, ny, nx)
-    T = 288.0 * (p / 1e5) ** 0.19 + 10.0 * np.cos(2 * phi) * (p / 1e5) + rng.standard_normal(shp)
-    u = 25.0 * np.cos(phi) * (1 - p / 1.2e5) + 5.0 * rng.standard_normal(shp)
-    v = 3.0 * np.sin(2 * lam) * np.cos(phi) + 3.0 * rng.standard_normal(shp)
-    w = 0.05 * np.sin(3 * lam) * np.cos(phi) + 0.1 * rng.standard_normal(shp)
-    ph = o.G * 7000.0 * np.log(1e5 / p) + 100.0 * rng.standard_normal(shp)
-    dom = o.Domain(T, u, v, w, ph, lat, lon, level, np.arange(nt) * 3600.0)
-    t0 = time.perf_counter()
-    with np.errstate(all="ignore"):          # the polar rows divide by cos(90 deg) in the reference too (SURVEY F7)
-        o.lec_fixed(dom, lon[0], lon[-1], lat[0], lat[-1])
-    return time.perf_counter() - t0
+    f = {"tair": 288.0 * (p / 1e5) ** 0.19 + 10.0 * np.cos(2 * phi) * (p / 1e5) + rng.standard_normal(shp),
+         "u": 25.0 * np.cos(phi) * (1 - p / 1.2e5) + 5.0 * rng.standard_normal(shp),
+         "v": 3.0 * np.sin(2 * lam) * np.cos(phi) + 3.0 * rng.standard_normal(shp),
+         "omega": 0.05 * np.sin(3 * lam) * np.cos(phi) + 0.1 * rng.standard_normal(shp),
+         "geopt": o.G * 7000.0 * np.log(1e5 / p) + 100.0 * rng.standard_normal(shp)}
+    return f, lat, lon, level
 
 
 def _oracle_band_worker(a):
-    return _oracle_band(*a)
+    nt, ny, seed = a
+    f, lat, lon, level = _synthetic_band_host(nt, ny, seed)
+    return _oracle_run(f, lat, lon, level, np.arange(nt) * 3600.0, (lon[0], lon[-1], lat[0], lat[-1]))[0]
 
 
-def cpu_baseline(kind):
-    """kind "full": (a) ONE thread, like the reference: 3 repetitions of 2 time steps at the full 37 x 721 x 1440, median;
-    (b) all host cores this process may use (at most 16): one worker process per core, each 2 time steps of a 181-row band,
-    scaled by 721/181 -- a best-effort figure (memory bound: the oracle materialises every 4-D temporary like the reference).
-    kind "quick": 2 steps of a 31-row band, one thread (contract tests)."""
+def _scale_err(a, r):
+    a, r = np.asarray(a, dtype=np.float64), np.asarray(r, dtype=np.float64)
+    if not np.array_equal(np.isnan(a), np.isnan(r)):
+        return float("inf")
+    ok = ~np.isnan(r)
+    if not ok.any():
+        return 0.0
+    den = float(np.max(np.abs(r[ok])))
+    return float(np.max(np.abs(a[ok] - r[ok])) / den) if den > 0 else float(np.max(np.abs(a[ok] - r[ok])))
+
+
+def cpu_baseline_and_parity(kind, eng, held, lat, lon, level, time_s, device):
+    """The CPU leg of the N = 1 line.  The oracle evaluates the FIRST `nt` TIME STEPS OF THE RESIDENT SYNTHETIC CUBE -- the data the
+    GPU has just been timed on -- copied to the host, on the box without the polar rows (the reference divides by
+    cos 90 deg there); the engine runs the same sub-cube and every one of the 16 terms and 21 level tables is compared
+    (`parity`).  The oracle's wall time on exactly that call is the one-thread CPU baseline (`cpu_baseline`, kind "port").
+    kind "full": nt = 3 at the benchmark's size, two repetitions (the first also yields the parity), plus a best-effort all-cores figure;
+    kind "quick" (tests): nt = 2, one repetition."""
     import multiprocessing as mp
+    import torch
+    from oracle import lec_oracle as o
     ncpu = os.cpu_count() or 1
     try:
         usable = len(os.sched_getaffinity(0))
     except AttributeError:
         usable = ncpu
-    if kind == "quick":
-        dt = _oracle_band(2, 31, 1)
-        return {"value": 2 / (dt * 721 / 31), "unit": "timesteps/s", "cores": 1, "kind": "port", "host_cpu_count": ncpu,
-                "sample": f"NumPy fp64 oracle, 1 thread, 2 time steps of a 37x31x1440 band in {dt:.2f} s, scaled by 721/31 (quick mode)"}
-    reps = [_oracle_band(2, 721, 10 + r) for r in range(3)]
-    med = float(np.median(reps))
-    out = {"value": 2 / med, "unit": "timesteps/s", "cores": 1, "kind": "port", "host_cpu_count": ncpu, "usable_cores": usable,
-           "seconds_per_timestep": med / 2,
-           "sample": f"NumPy fp64 oracle (the reference's eager op order), 1 thread, 2 time steps at the full 37x721x1440, "
-                     f"3 repetitions: {', '.join(f'{r:.1f}' for r in reps)} s, median"}
-    workers = max(1, min(usable, 16))
-    try:
-        ctx = mp.get_context("spawn")
-        t0 = time.perf_counter()
-        with ctx.Pool(workers) as pool:
-            pool.map(_oracle_band_worker, [(2, 181, 100 + i) for i in range(workers)])
-        wall = time.perf_counter() - t0
-        out["all_cores"] = {"value": workers * 2 * (181.0 / 721.0) / wall, "unit": "timesteps/s", "cores": workers,
-                            "sample": f"{workers} worker processes (one per usable core, capped at 16), each 2 time steps of a "
-                                      f"37x181x1440 band, in {wall:.1f} s wall incl. process start, scaled by 181/721"}
-    except Exception as e:      # a host that cannot fork workers still reports the one-thread figure
-        out["all_cores"] = {"value": None, "error": repr(e)}
-    return out
+    h0, h1, f = held
+    nt = min(3 if kind == "full" else 2, h1 - h0)
+    ny, nx = lat.size, lon.size
+    south, north = (lat[1], lat[-2]) if abs(lat[0]) >= 90.0 - 1e-9 else (lat[0], lat[-1])
+    limits = (lon[0], lon[-1], south, north)
+    sub = {k: (None if v is None else v[:nt]) for k, v in f.items()}
+    ts = time_s[h0:h0 + nt]
+    box = eng.box_from_limits(*limits)
+    res = eng.compute(sub["tair"], sub["u"], sub["v"], sub["omega"], sub["geopt"], [box], time_s=ts)
+    torch.cuda.synchronize(device)
+    got_s, got_l = res.scalars_dict(), res.levels_dict()
+    host = {k: np.ascontiguousarray(v.double().cpu().numpy()) for k, v in sub.items()}
+    reps = []
+    for rep in range(2 if kind == "full" else 1):
+        dt, ref_s, ref_l = _oracle_run(host, lat, lon, level, ts, limits)
+        reps.append(dt)
+    worst, worst_term = 0.0, ""
+    for name in ("Az", "Ae", "Kz", "Ke", "Cz", "Ca", "Ck", "Ce", "BAz", "BAe", "BKz", "BKe", "Gz", "Ge"):     # lec_fixed drops BPhiZ / BPhiE
+        e = _scale_err(got_s[name], ref_s[name])
+        if e > worst:
+            worst, worst_term = e, name
+    lworst, lworst_term = 0.0, ""
+    for name, ref in ref_l.items():
+        ref = np.asarray(ref, dtype=np.float64)
+        if ref.ndim == 1:
+            ref = np.broadcast_to(ref, got_l[name].shape)
+        e = _scale_err(got_l[name], ref)
+        if e > lworst:
+            lworst, lworst_term = e, name
+    parity = {"worst_rel_to_scale": worst, "term": worst_term, "levels_worst_rel_to_scale": lworst, "levels_term": lworst_term,
+              "steps": nt, "terms_compared": 14, "level_tables_compared": len(ref_l),
+              "box": f"lon [{limits[0]}, {limits[1]}] lat [{limits[2]}, {limits[3]}] ({box[3] - box[2] + 1} x {box[1] - box[0] + 1} points)",
+              "data": "the first %d time steps of the resident synthetic cube the GPU was timed on, copied to the host" % nt,
+              "checker": "oracle/lec_oracle.py (NumPy fp64 restatement of the reference's un-factored formulas)", "tolerance": 1e-9,
+              "ok": bool(worst <= 1e-9 and lworst <= 1e-9)}
+    best = float(np.median(reps))
+    out = {"value": nt / best, "unit": "timesteps/s", "cores": 1, "kind": "port", "host_cpu_count": ncpu, "usable_cores": usable,
+           "seconds_per_timestep": best / nt,
+           "sample": f"NumPy fp64 oracle (the reference's eager op order), 1 thread, {nt} time steps of the resident cube at 37x{box[3] - box[2] + 1}x{nx} "
+                     f"(box without the polar rows), {len(reps)} repetition(s): {', '.join(f'{r:.1f}' for r in reps)} s, median; the same call gives `parity`"}
+    if kind == "full":
+        workers = max(1, min(usable, 32))
+        try:
+            ctx = mp.get_context("spawn")
+            t0 = time.perf_counter()
+            with ctx.Pool(workers) as pool:
+                pool.map(_oracle_band_worker, [(2, 91, 100 + i) for i in range(workers)])
+            wall = time.perf_counter() - t0
+            out["all_cores"] = {"value": workers * 2 * (91.0 / 721.0) / wall, "unit": "timesteps/s", "cores": workers,
+                                "sample": f"{workers} worker processes (one per usable core, at most 32: each holds ~2.5 GB of 4-D temporaries like the "
+                                          f"reference), each 2 time steps of its own 37x91x1440 band, {wall:.1f} s wall incl. process start and data "
+                                          f"generation, scaled by 91/721"}
+        except Exception as e:      # a host that cannot fork workers still reports the one-thread figure
+            out["all_cores"] = {"value": None, "error": repr(e)}
+    return out, parity
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -195,12 +252,15 @@ def run_rank(args):
     local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist          # --force-dist: the N > 1 code path (process group, collectives) with ONE rank
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)      # the rank's GPU is already current
 
     from lorenzcycletoolkit_amd.engine import LECEngine
-    from lorenzcycletoolkit_amd.parallel import gather_result, halo_range, merge_dropmask, shard_range
+    from lorenzcycletoolkit_amd.parallel import SeriesGatherer, halo_range, merge_dropmask, shard_range
     from lorenzcycletoolkit_amd.synthetic import era5_like_levels, synthetic_cube
 
     level = era5_like_levels()
@@ -259,8 +319,13 @@ def run_rank(args):
         return h0, h1, f
 
     held = generate(*chunks[0]) if resident else None
-    rows = None if resident else torch.empty((T_local, nl, nyb_max, 32), dtype=torch.float64, device=device)
-    merge = (lambda m: merge_dropmask(m)) if (world > 1 and not args.moving) else None
+    # Everything a pass writes is allocated ONCE, here: the row records, the NaN counters, and (SeriesGatherer) the send / receive
+    # buffers of the gather in two pipeline slots.  lec_reduce writes its packed [T_local, 16 + 21 nl] records straight into the
+    # slot's send buffer; the gather of pass i is waited for when its slot comes round again, so it overlaps the kernels of pass i + 1.
+    rows = torch.empty((T_local, nl, nyb_max, 32), dtype=torch.float64, device=device)
+    nanflag = torch.empty((T_local,), dtype=torch.int32, device=device)
+    gat = SeriesGatherer(T_global, LECEngine.packed_width(nl), device, dst=0, slots=2, force=args.force_dist)
+    merge = (lambda m: merge_dropmask(m)) if (use_dist and not args.moving) else None
     kernel_ms = []
     gen_s = [0.0]
     tuning = None
@@ -275,66 +340,144 @@ def run_rank(args):
             dist.barrier()
 
     def sync(with_barrier=True):
-        if world > 1 and with_barrier:
+        if use_dist and with_barrier:
             barrier()
         torch.cuda.synchronize()
 
-    def one_pass(record):
-        """One pass over this rank's shard; returns (result, seconds inside the timed region)."""
+    pass_no = [0]
+    last = {}
+
+    def one_pass(record, seg=None):
+        """One pass over this rank's shard: stage 1 (per chunk), stage 2 into the gather's send buffer, gather started.
+        Returns the seconds inside the timed region for the streamed mode (None when resident: the caller's wall clock counts).
+        `seg`: a dict that receives the seconds of every segment of this pass, each closed by a device synchronisation
+        (the instrumented passes after the timed loop; the timed passes never synchronise inside)."""
+        slot = pass_no[0] % gat.slots
+        pass_no[0] += 1
+        last["slot"] = slot
         timed = 0.0
+        tick = [time.perf_counter()]
+
+        def mark(name):
+            if seg is not None:
+                torch.cuda.synchronize()
+                now = time.perf_counter()
+                seg[name] = seg.get(name, 0.0) + (now - tick[0])
+                tick[0] = now
+
+        if gat._pending[slot]:
+            last["series"] = gat.finish(slot)         # the exchange of the pass that used this slot two passes ago
+        out = gat.send(slot)
+        mark("gather_finish_previous")
         if resident:
             h0, h1, f = held
             timing = [] if record else None
-            r = eng.rowstats(f["tair"], f["u"], f["v"], f["omega"], f["geopt"], all_boxes, time_s=time_s[h0:h1] if with_q else None,
-                             t_begin=t0 - h0, t_count=T_local, timing=timing, **stage1)
-            res = eng.reduce(r, all_boxes, merge_dropmask=merge, drop_any_time=not args.moving)
-            if world > 1:
-                gather_result(res, T_global)      # the job's only collective besides the mask (RCCL all_gather over xGMI)
+            eng.rowstats(f["tair"], f["u"], f["v"], f["omega"], f["geopt"], all_boxes, time_s=time_s[h0:h1] if with_q else None,
+                         t_begin=t0 - h0, t_count=T_local, timing=timing, rows_out=rows, **stage1)
             if record:
                 kernel_ms.extend(timing)
-            return res, None                      # resident passes are timed by the caller's wall clock around all K of them
-        for (a, b) in chunks:
-            g0 = time.perf_counter()
-            h0, h1, f = generate(a, b)
-            torch.cuda.synchronize()
-            gen_s[0] += time.perf_counter() - g0
-            timing = [] if record else None
-            tic = time.perf_counter()
-            eng.rowstats(f["tair"], f["u"], f["v"], f["omega"], f["geopt"], chunk_boxes[(a, b)], time_s=time_s[h0:h1] if with_q else None,
-                         t_begin=a - h0, t_count=b - a, timing=timing, rows_out=rows[a - t0:b - t0], **stage1)
-            torch.cuda.synchronize()
-            timed += time.perf_counter() - tic
-            if record:
-                kernel_ms.extend(timing)
-            del f
-        sync()
+            mark("stage1")
+        else:
+            for (a, b) in chunks:
+                g0 = time.perf_counter()
+                h0, h1, f = generate(a, b)
+                torch.cuda.synchronize()
+                gen_s[0] += time.perf_counter() - g0
+                timing = [] if record else None
+                tic = time.perf_counter()
+                eng.rowstats(f["tair"], f["u"], f["v"], f["omega"], f["geopt"], chunk_boxes[(a, b)], time_s=time_s[h0:h1] if with_q else None,
+                             t_begin=a - h0, t_count=b - a, timing=timing, rows_out=rows[a - t0:b - t0], **stage1)
+                torch.cuda.synchronize()
+                timed += time.perf_counter() - tic
+                if record:
+                    kernel_ms.extend(timing)
+                del f
+            sync()
+            tick[0] = time.perf_counter()
         tic = time.perf_counter()
-        res = eng.reduce(rows, all_boxes, merge_dropmask=merge, drop_any_time=not args.moving)
-        if world > 1:
-            gather_result(res, T_global)
+        mask_s = [0.0]
+        mg = merge
+        if seg is not None and merge is not None:
+            def mg(m):
+                torch.cuda.synchronize()
+                a = time.perf_counter()
+                merge(m)
+                torch.cuda.synchronize()
+                mask_s[0] = time.perf_counter() - a
+        res = eng.reduce(rows, all_boxes, merge_dropmask=mg, drop_any_time=not args.moving, out=out, nanflag_out=nanflag)
+        last["res"] = res
+        mark("stage2")
+        if seg is not None and merge is not None:
+            seg["stage2"] -= mask_s[0]
+            seg["mask_all_reduce"] = seg.get("mask_all_reduce", 0.0) + mask_s[0]
+        gat.profile = {} if seg is not None else None
+        gat.start(slot)                               # the job's only collective besides the mask: RCCL gather to rank 0 over xGMI
+        if seg is not None:
+            last["series"] = gat.finish(slot)
+            mark("gather")
+            for k, v in gat.profile.items():
+                seg["gather." + k] = seg.get("gather." + k, 0.0) + v
+            gat.profile = None
+        if resident:
+            return None
         sync()
         timed += time.perf_counter() - tic
-        return res, timed
+        return timed
+
+    def drain():
+        """Completes the exchanges still in flight, oldest first: last["series"] ends as the series of the LAST pass (as last["res"])."""
+        newest = last.get("slot", 0)
+        for sl in [x for x in range(gat.slots) if x != newest] + [newest]:
+            if gat._pending[sl]:
+                last["series"] = gat.finish(sl)
 
     for _ in range(args.warmup):
         one_pass(False)
+    drain()
     sync()
     gen_s[0] = 0.0
     tic = time.perf_counter()
     timed_total = 0.0
     for _ in range(args.steps):
-        res, timed = one_pass(True)
+        timed = one_pass(True)
         if timed is not None:
             timed_total += timed
+    drain()                                           # every pass's series has arrived on rank 0 inside the timed region
     sync()
     wall = time.perf_counter() - tic
     elapsed = wall if resident else timed_total
-    if world > 1:
+    if use_dist:
         el = torch.tensor([elapsed, wall], dtype=torch.float64, device=device)
         if backend == "gloo":
             el = el.cpu()
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed, wall = float(el[0]), float(el[1])
+    res = last["res"]
+    series = last.get("series")
+
+    # Where a pass's time goes: three instrumented passes (every segment closed by a device synchronisation, the gather completed
+    # inside its pass), median per segment.  Reported beside the timed figure, never inside it.
+    seg_runs = []
+    if resident:
+        for _ in range(3):
+            sync()
+            sg = {}
+            a = time.perf_counter()
+            one_pass(False, seg=sg)
+            sg["pass_total_synchronised"] = time.perf_counter() - a
+            seg_runs.append(sg)
+        sync()
+    segments = None
+    if seg_runs:
+        keys = sorted({k for sg in seg_runs for k in sg})
+        med = {k: float(np.median([sg.get(k, 0.0) for sg in seg_runs])) * 1e3 for k in keys}
+        if use_dist:      # the slowest rank's figure per segment
+            tt = torch.tensor([med[k] for k in keys], dtype=torch.float64, device=device)
+            if backend == "gloo":
+                tt = tt.cpu()
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            med = {k: float(v) for k, v in zip(keys, tt)}
+        segments = med
 
     # the BASELINE target configuration (conversion terms: T, u, v, omega) on the same resident fields, rank 0
     conv = None
@@ -343,7 +486,7 @@ def run_rank(args):
         ev = []
         for i in range(2 + 5):
             tm = [] if i >= 2 else None
-            eng.rowstats(f["tair"], f["u"], f["v"], f["omega"], None, [box], t_begin=t0 - h0, t_count=T_local, with_q=False, timing=tm)
+            eng.rowstats(f["tair"], f["u"], f["v"], f["omega"], None, [box], t_begin=t0 - h0, t_count=T_local, with_q=False, timing=tm, rows_out=rows)
             if tm:
                 ev.extend(tm)
         torch.cuda.synchronize()
@@ -353,8 +496,29 @@ def run_rank(args):
                 "algorithmic_bytes_per_launch": cbytes, "timesteps_per_s": T_local / (ms * 1e-3),
                 "kernel": "lec_rowsweep_kernel (T, u, v, omega; the fused conversion-terms configuration of BASELINE.json's target)"}
 
+    # moving boxes: the shipped kernel family (box tiles) against the independent one-wave-per-row formulation on the first steps of the
+    # resident shard -- record by record and term by term (finite is not a check: wrong coefficients give finite numbers too)
+    moving_check = None
+    if rank == 0 and resident and args.moving:
+        h0, h1, f = held
+        n = min(T_local, 8)
+        bx = [all_boxes.boxes[i] for i in range(n)]
+        kw = dict(time_s=time_s[h0:h1] if with_q else None, t_begin=t0 - h0, t_count=n, with_q=with_q, per_step_boxes=True, keep_rows=True)
+        a = eng.compute(f["tair"], f["u"], f["v"], f["omega"], f["geopt"], bx, **kw)
+        b = eng.compute(f["tair"], f["u"], f["v"], f["omega"], f["geopt"], bx, tuning={"kernel": "row_sweep"}, **kw)
+        torch.cuda.synchronize()
+        ra, rb = a.rows[..., :28], b.rows[..., :28]
+        rec = float(((ra - rb).abs().amax(dim=(0, 1, 2)) / rb.abs().amax(dim=(0, 1, 2)).clamp_min(1e-300)).max())
+        sc = float(((a.scalars - b.scalars).abs().amax(dim=0) / b.scalars.abs().amax(dim=0).clamp_min(1e-300)).max())
+        same = bool(torch.equal(a.scalars, res.scalars[:n]))       # and the timed pass produced exactly these numbers
+        moving_check = {"steps": n, "row_records_max_rel_diff_vs_row_sweep": rec, "terms_max_rel_diff_vs_row_sweep": sc,
+                        "timed_pass_bit_identical": same, "ok": bool(rec <= 1e-10 and sc <= 1e-9 and same)}
+
     if rank == 0:
         finite = bool(torch.isfinite(res.scalars).all().item())
+        gathered_ok = None
+        if series is not None and gat.active:       # rank 0's block of the gathered series is what its own stage 2 wrote
+            gathered_ok = bool(torch.equal(series[t0:t1], res.packed)) and tuple(series.shape) == (T_global, LECEngine.packed_width(nl))
         bytes_per_step_t = nfields * nl * lat.size * lon.size * esz        # algorithmic bytes per time step
         if args.moving:
             bytes_per_step_t = nfields * nl * 61 * 61 * esz                # only the box is read
@@ -362,18 +526,20 @@ def run_rank(args):
         avg_launch_ms = float(np.mean(launch_ms))
         steps_per_launch = T_local if resident else float(np.mean([b - a for a, b in chunks]))
         achieved = bytes_per_step_t * steps_per_launch / (avg_launch_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if os.path.exists(pmc) and (args.ny, args.nx) == (721, 1440):
             try:
                 key = ("rowstats_moving_hbm_bytes_per_timestep" if args.moving else
                        f"rowstats_{args.storage}_{'noq' if args.no_q else 'all'}_hbm_bytes_per_timestep")
-                per_t = json.load(open(pmc)).get(key)
+                summ = json.load(open(pmc))
+                per_t = summ.get(key)
                 traffic = None if per_t is None else per_t * steps_per_launch
+                traffic_src = summ.get(key.replace("_hbm_bytes_per_timestep", "_source"))
             except Exception:
                 traffic = None
         if args.moving:
-            kname = "lec_boxtile_kernel (one wave per four box rows x ten levels of a time step; six values per point transposed through LDS)"
+            kname = "lec_boxtile_kernel (one wave per four box rows x a chunk of levels of a time step; six values per point transposed through LDS)"
         elif args.no_q or args.storage == "f32":
             kname = "lec_rowsweep_kernel (one wave per row)" + ("" if args.no_q else " + lec_qtime_kernel")
         else:
@@ -399,20 +565,39 @@ def run_rank(args):
             "config": {
                 "workload": workload,
                 "timesteps_per_gpu": T_local, "timesteps_global": T_global, "world_size": world,
-                "backend": (dist.get_backend() if world > 1 else "none"),
-                "parallelism": f"time-sharded x{world}, no data-path collective; RCCL all_reduce of the NaN-level mask + all_gather of per-time-step results",
-                "timed_region": ("wall clock around all passes, inputs resident in HBM" if resident else
+                "backend": (dist.get_backend() if use_dist else "none"),
+                "parallelism": f"time-sharded x{world}, no data-path collective; RCCL all_reduce of the NaN-level mask (fixed box) + one gather of the "
+                               "packed per-time-step records to rank 0 (a send per peer, each over its own xGMI link), double-buffered: "
+                               "the gather of pass i overlaps the kernels of pass i + 1",
+                "timed_region": ("wall clock around all passes (stage 1 + stage 2 + collectives, every pass's series delivered to rank 0), inputs resident in HBM"
+                                 if resident else
                                  "lec_rowstats per chunk + lec_reduce + collectives (synchronised segments); synthetic generation excluded"),
                 "results_finite": finite,
+                **({"gathered_series_ok": gathered_ok} if gathered_ok is not None else {}),
                 **({"tuning": args.tuning} if args.tuning else {}),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_source": (None if traffic is None else f"{traffic_src}: rocprofv3 --pmc FETCH_SIZE pass of this command on an MI355X box, "
+                                   "corrected per MI355X_MICROARCH.md, per launch; a stored measurement, not re-measured in this run"),
                 "kernel": kname, "avg_launch_ms": avg_launch_ms,
                 "algorithmic_bytes_per_launch": bytes_per_step_t * steps_per_launch,
             },
         }
+        if segments is not None:
+            k1 = avg_launch_ms
+            pass_ms = elapsed / args.steps * 1e3
+            segments["pass_timed_unsynchronised"] = pass_ms
+            segments["stage1_kernels_hip_events"] = k1
+            # what a pass costs beyond its kernels, in the timed (pipelined) loop: host gaps + whatever of the collective is not hidden
+            segments["fixed_cost_per_pass"] = pass_ms - k1 - segments.get("stage2", 0.0)
+            out["config"]["segments_ms"] = segments
+            out["config"]["segments_note"] = ("median of 3 instrumented passes (a device synchronisation closes every segment; max over ranks); "
+                                              "stage2 includes its launch and host time; fixed_cost_per_pass = pass_timed_unsynchronised - "
+                                              "stage1_kernels_hip_events - stage2")
+        if moving_check is not None:
+            out["config"]["moving_check"] = moving_check
         if not resident:
             out["config"]["chunk"] = chunk
             out["config"]["wall_ms_per_step_incl_generation"] = wall / args.steps * 1e3
@@ -428,10 +613,10 @@ def run_rank(args):
             out["config"]["speedup_vs_n1"] = None if not n1 else out["value"] / n1
             out["config"]["n1_value"] = n1
         kind = "none" if args.no_cpu_baseline else args.cpu_baseline
-        if world == 1 and kind != "none":
-            out["cpu_baseline"] = cpu_baseline(kind)
+        if world == 1 and kind != "none" and resident and with_q and not args.moving:
+            out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(kind, eng, held, lat, lon, level, time_s, device)
         print(json.dumps(out, ensure_ascii=False), flush=True)
-    if world > 1:
+    if use_dist:
         barrier()
         dist.destroy_process_group()
 

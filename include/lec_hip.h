@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define LEC_ABI_VERSION 5
+#define LEC_ABI_VERSION 6
 
 /* number of fp64 values per (time, level, lat) row record written by lec_rowstats */
 #define LEC_NSTAT 32
@@ -181,6 +181,10 @@ typedef struct lec_reduce_args {
     double* levels_d;           /* out [t_count][LEC_NLEVTAB][nl] */
     int32_t* nanflag_d;         /* out [t_count] number of NaN level values repaired/dropped (0 = clean) */
     void* stream;
+    int64_t scalars_stride;     /* doubles between the scalars of consecutive time steps; 0 = dense (LEC_NSCALAR) */
+    int64_t levels_stride;      /* doubles between the level tables of consecutive time steps; 0 = dense (LEC_NLEVTAB * nl).  With
+                                   scalars_d = buf, levels_d = buf + LEC_NSCALAR and both strides = LEC_NSCALAR + LEC_NLEVTAB * nl the call
+                                   writes one packed record per time step: the send buffer of the time-sharded gather, no repacking */
 } lec_reduce_args;
 
 /*

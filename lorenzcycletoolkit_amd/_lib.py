@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # LEC_LIB: alternative build of the same ABI (kernel experiments only)
 LIB_PATH = os.environ.get("LEC_LIB") or os.path.join(_HERE, "liblec_hip.so")
 
-LEC_ABI_VERSION = 5
+LEC_ABI_VERSION = 6
 LEC_NSTAT = 32
 LEC_NLEVRAW = 40
 LEC_NSCALAR = 16
@@ -60,6 +60,7 @@ class ReduceArgs(C.Structure):
         ("drop_any_time", C.c_int32), ("reserved0", C.c_int32), ("dropmask_d", C.c_void_p),
         ("am_d", C.c_void_p), ("levraw_d", C.c_void_p), ("scalars_d", C.c_void_p), ("levels_d", C.c_void_p),
         ("nanflag_d", C.c_void_p), ("stream", C.c_void_p),
+        ("scalars_stride", C.c_int64), ("levels_stride", C.c_int64),
     ]
 
 

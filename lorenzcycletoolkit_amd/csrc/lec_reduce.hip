@@ -56,6 +56,7 @@ struct RedParams {
     double* scalars;
     double* levels;
     int* nanflag;
+    long long sstride, lstride;     // doubles between consecutive time steps of `scalars` / `levels`
 };
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -514,7 +515,7 @@ __global__ void __launch_bounds__(64) lec_vertical_kernel(const RedParams p) {
 
     if (lane == 0) {
         const double c1 = p.boxtab2[4 * bi + 0], c2 = p.boxtab2[4 * bi + 1];
-        double* s = p.scalars + (size_t)tl * LEC_NSCALAR;
+        double* s = p.scalars + (size_t)tl * (size_t)p.sstride;
         s[0] = res[F_AZ];
         s[1] = res[F_AE];
         s[2] = res[F_KZ] / (2 * kG);
@@ -532,7 +533,7 @@ __global__ void __launch_bounds__(64) lec_vertical_kernel(const RedParams p) {
     }
 
     // per-level tables, order of lec_fixed_framework.py:172-194
-    double* L = p.levels + (size_t)tl * LEC_NLEVTAB * nl;
+    double* L = p.levels + (size_t)tl * (size_t)p.lstride;
     for (int k = lane; k < nl; k += 64) {
         const double* o = raw + (size_t)k * LEC_NLEVRAW;
         const double c1k = kRd / (lv[4 * k] * kG);
@@ -574,6 +575,9 @@ static int reduce_impl(const lec_reduce_args* a, bool mask_only, const char* who
     if (a->drop_any_time < 0 || a->drop_any_time > 2) return lec_set_error(LEC_ERR_ARG, "lec_reduce: drop_any_time must be 0, 1 or 2");
     if ((reinterpret_cast<uintptr_t>(a->rows_d) | reinterpret_cast<uintptr_t>(a->lattab2_d)) & 15)
         return lec_set_error(LEC_ERR_ARG, "lec_reduce / lec_dropmask: rows_d and lattab2_d must be 16-byte aligned");
+    if (a->scalars_stride < 0 || a->levels_stride < 0 || (a->scalars_stride && a->scalars_stride < LEC_NSCALAR) ||
+        (a->levels_stride && a->levels_stride < (long long)LEC_NLEVTAB * a->nl))
+        return lec_set_error(LEC_ERR_ARG, "lec_reduce: scalars_stride / levels_stride must be 0 (dense) or at least one record long");
     if ((a->drop_any_time || mask_only) && !a->dropmask_d) return lec_set_error(LEC_ERR_ARG, "lec_reduce / lec_dropmask: drop_any_time needs dropmask_d");
     (void)who;
     RedParams p;
@@ -581,6 +585,8 @@ static int reduce_impl(const lec_reduce_args* a, bool mask_only, const char* who
     p.box = a->box_d; p.boxtab2 = a->boxtab2_d; p.lattab2 = a->lattab2_d; p.levtab2 = a->levtab2_d;
     p.phi_scale = a->phi_scale; p.am = a->am_d; p.levraw = a->levraw_d; p.scalars = a->scalars_d;
     p.levels = a->levels_d; p.nanflag = a->nanflag_d;
+    p.sstride = a->scalars_stride ? a->scalars_stride : LEC_NSCALAR;
+    p.lstride = a->levels_stride ? a->levels_stride : (long long)LEC_NLEVTAB * a->nl;
     p.drop_any_time = (a->drop_any_time || mask_only) ? 1 : 0; p.dropmask = a->dropmask_d;
     hipStream_t st = (hipStream_t)a->stream;
     const dim3 grid2(a->nl, a->t_count);

@@ -21,11 +21,13 @@ from .constants import LEVEL_TERMS, SCALAR_TERMS
 
 @dataclass
 class LECResult:
-    """Per-time-step outputs (device tensors) of one engine call."""
+    """Per-time-step outputs (device tensors) of one engine call.  ``scalars`` and ``levels`` are views of ``packed``: one record of
+    16 + 21 nl doubles per time step, written by ``lec_reduce`` in place -- the unit the time-sharded gather moves (parallel.py)."""
     scalars: torch.Tensor      # [t_count, 16] fp64, columns = constants.SCALAR_TERMS
     levels: torch.Tensor       # [t_count, 21, nl] fp64, tables = constants.LEVEL_TERMS
     nanflag: torch.Tensor      # [t_count] int32: NaN level values repaired/dropped by _handle_nans
     rows: Optional[torch.Tensor] = None   # [t_count, nl, nyb_max, 32] row records (kept on request)
+    packed: Optional[torch.Tensor] = None  # [t_count, 16 + 21 nl] fp64
 
     def scalars_dict(self) -> Dict[str, np.ndarray]:
         s = self.scalars.cpu().numpy()
@@ -151,7 +153,8 @@ class LECEngine:
                 keep_rows: bool = False, timing: Optional[list] = None,
                 drop_any_time: Optional[bool] = None,
                 merge_dropmask: Optional[Callable[[torch.Tensor], None]] = None,
-                tuning: Optional[dict] = None, per_step_boxes: Optional[bool] = None) -> LECResult:
+                tuning: Optional[dict] = None, per_step_boxes: Optional[bool] = None,
+                out: Optional[torch.Tensor] = None) -> LECResult:
         """All LEC terms for time steps [t_begin, t_begin + t_count) of the cubes: ``rowstats`` then ``reduce``.
 
         ``boxes``: one (iw, ie, js, jn) quadruple (fixed framework) or one per processed time step
@@ -171,7 +174,7 @@ class LECEngine:
         if drop_any_time is None and per_step_boxes:
             drop_any_time = False
         return self.reduce(rows, boxes, phi_scale=phi_scale, drop_any_time=drop_any_time, merge_dropmask=merge_dropmask,
-                           keep_rows=keep_rows)
+                           keep_rows=keep_rows, out=out)
 
     def rowstats(self, tair: torch.Tensor, u: torch.Tensor, v: torch.Tensor, omega: torch.Tensor,
                  geopt: Optional[torch.Tensor], boxes: Sequence[Sequence[int]], *,
@@ -244,10 +247,20 @@ class LECEngine:
                 timing.append((ev0, ev1))
         return rows
 
+    @staticmethod
+    def packed_width(nl: int) -> int:
+        """Doubles per time step of a packed result record: 16 scalars + 21 level tables."""
+        return _lib.LEC_NSCALAR + _lib.LEC_NLEVTAB * int(nl)
+
     def reduce(self, rows: torch.Tensor, boxes: Sequence[Sequence[int]], *, phi_scale: float = 1.0,
                drop_any_time: Optional[bool] = None, merge_dropmask: Optional[Callable[[torch.Tensor], None]] = None,
-               keep_rows: bool = False) -> LECResult:
+               keep_rows: bool = False, out: Optional[torch.Tensor] = None,
+               nanflag_out: Optional[torch.Tensor] = None) -> LECResult:
         """Stage 2 on row records [t_count, nl, nyb_max, 32] (``lec_reduce``).
+
+        ``out``: a caller-owned fp64 [t_count, 16 + 21 nl] tensor (rows may be strided, columns contiguous) that receives the packed
+        records -- e.g. the send buffer of the time-sharded gather (``parallel.SeriesGatherer``), so a pass allocates nothing and
+        repacks nothing; ``nanflag_out``: int32 [t_count].  Default: fresh tensors.
 
         ``merge_dropmask``: for a series processed in shards -- called with this shard's any-time NaN-level mask
         (int32 [28, nl], non-zero = drop) and must merge it in place with the other shards' masks (element-wise
@@ -262,16 +275,28 @@ class LECEngine:
         f64 = dict(dtype=torch.float64, device=rows.device)
         # the two workspaces are scratch of this call only (stream-ordered: the next call on the stream may reuse them); the outputs
         # are fresh tensors, they belong to the caller
-        wkey = (t_count, nl, str(rows.device))
+        # keyed by the stream too: two reduce calls of one shape on different streams must not share scratch (or the dropmask)
+        wkey = (t_count, nl, str(rows.device), int(torch.cuda.current_stream(rows.device).cuda_stream))
         if wkey not in self._work:
             if len(self._work) > 4:
                 self._work.clear()
             self._work[wkey] = (torch.empty((t_count, nl, 8), **f64), torch.empty((t_count, nl, _lib.LEC_NLEVRAW), **f64),
                                 torch.empty((_lib.LEC_NLEVFUN, nl), dtype=torch.int32, device=rows.device))
         am, levraw, dropmask_ws = self._work[wkey]
-        scalars = torch.empty((t_count, _lib.LEC_NSCALAR), **f64)
-        levels = torch.empty((t_count, _lib.LEC_NLEVTAB, nl), **f64)
-        nanflag = torch.empty((t_count,), dtype=torch.int32, device=rows.device)
+        width = self.packed_width(nl)
+        if out is None:
+            out = torch.empty((t_count, width), **f64)
+        elif (out.shape != (t_count, width) or out.dtype != torch.float64 or out.device != rows.device or out.stride(1) != 1
+              or out.stride(0) < width or out.data_ptr() % 8):
+            raise ValueError(f"out must be an fp64 [t_count, {width}] tensor on the rows' device with contiguous columns")
+        scalars = out[:, :_lib.LEC_NSCALAR]
+        levels = out[:, _lib.LEC_NSCALAR:].unflatten(1, (_lib.LEC_NLEVTAB, nl))
+        if nanflag_out is None:
+            nanflag = torch.empty((t_count,), dtype=torch.int32, device=rows.device)
+        else:
+            nanflag = nanflag_out
+            if nanflag.shape != (t_count,) or nanflag.dtype != torch.int32 or nanflag.device != rows.device or not nanflag.is_contiguous():
+                raise ValueError("nanflag_out must be a contiguous int32 [t_count] tensor on the rows' device")
         if drop_any_time is None:
             drop_any_time = len(boxes) == 1
         dropmask = dropmask_ws if drop_any_time else None
@@ -283,10 +308,10 @@ class LECEngine:
             levtab2_d=_ptr(self._levtab2), phi_scale=float(phi_scale),
             drop_any_time=mode, reserved0=0, dropmask_d=_ptr(dropmask),
             am_d=_ptr(am), levraw_d=_ptr(levraw), scalars_d=_ptr(scalars), levels_d=_ptr(levels),
-            nanflag_d=_ptr(nanflag), stream=stream)
+            nanflag_d=_ptr(nanflag), stream=stream, scalars_stride=int(out.stride(0)), levels_stride=int(out.stride(0)))
         with torch.cuda.device(rows.device):
             if mode == 2:
                 _lib.check(self.lib.lec_dropmask(C.byref(rd)), "lec_dropmask")
                 merge_dropmask(dropmask)
             _lib.check(self.lib.lec_reduce(C.byref(rd)), "lec_reduce")
-        return LECResult(scalars=scalars, levels=levels, nanflag=nanflag, rows=rows if keep_rows else None)
+        return LECResult(scalars=scalars, levels=levels, nanflag=nanflag, rows=rows if keep_rows else None, packed=out)

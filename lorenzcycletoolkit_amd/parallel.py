@@ -4,13 +4,23 @@ The LEC path shards embarrassingly: every time step is independent except dT/dt,
 neighbouring time steps of T (thermodynamics.py:109-110 of the reference) -- a one-step halo that
 each rank loads/generates itself, so the data path has no collective.  The exchanges are one tiny all_reduce
 of the NaN-level mask ([28, L] int32; it only matters for fields with below-ground NaNs) and one
-all_gather of the per-time-step results ([T_local, 16 + 21 L] fp64, a few KB per step) over
-RCCL/xGMI (backend "nccl"; "gloo" in the CPU tests); budgets and residuals are then O(T) host work
-on the gathered series (calc_budget_and_residual.py:32-56,131-154).
+gather of the per-time-step results ([T_local, 16 + 21 L] fp64, 6.3 KB per step at L = 37) over
+RCCL/xGMI (backend "nccl"; "gloo" in the CPU tests and the one-GPU rehearsals); budgets and residuals are
+then O(T) host work on the gathered series (calc_budget_and_residual.py:32-56,131-154).
+
+The gather is built for the fabric it runs on.  xGMI is point-to-point (every GPU has its own link to every
+other), so the series goes to the rank that writes the CSVs as ONE send per peer, all in flight at once, each
+over its own link (``dist.gather`` = a grouped ncclSend / ncclRecv) -- not around a ring that would carry
+world - 1 hops over single links; ``to_all=True`` asks for the all_gather where every rank needs the series.
+``SeriesGatherer`` owns every buffer of that exchange (allocated once, two pipeline slots): ``lec_reduce``
+writes its packed records straight into the send buffer, the collective is started asynchronously and only
+waited for when its slot is reused, so a pass allocates nothing, repacks nothing and the collective of pass i
+overlaps the kernels of pass i + 1.
 """
 from __future__ import annotations
 
-from typing import Tuple
+import time
+from typing import Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -30,34 +40,154 @@ def halo_range(t0: int, t1: int, n_steps: int) -> Tuple[int, int]:
     return max(t0 - 1, 0), min(t1 + 1, n_steps)
 
 
+def _dist_on(group=None) -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+
+class SeriesGatherer:
+    """Allocation-free gather of per-time-step records [T_local, ncol] into the series [n_steps, ncol].
+
+    ``dst``: the rank that receives the series (default 0: it writes the CSVs); ``to_all=True``: every rank receives it.
+    Shards may differ by one step; every rank sends ``width = ceil(n_steps / world)`` rows (the spare row stays zero).
+
+        g = SeriesGatherer(n_steps, ncol, device)
+        buf = g.send(slot)          # [T_local, ncol] view of the slot's send buffer: hand it to LECEngine.reduce(out=...)
+        g.start(slot)               # asynchronous: the collective waits for the stream's work on `buf`, the host does not
+        series = g.finish(slot)     # [n_steps, ncol] on the receiving rank(s) (a view of the slot's buffers), else None
+
+    With one process (no process group, or world 1 and ``force=False``) ``finish`` returns the send buffer itself.
+    Backend "gloo" with device tensors (the one-GPU rehearsal of the N > 1 path) stages through pinned host buffers that are
+    allocated once here; ``profile`` (a dict) then receives the seconds spent per leg.
+    """
+
+    def __init__(self, n_steps: int, ncol: int, device, group=None, dst: int = 0, to_all: bool = False, slots: int = 2,
+                 dtype=torch.float64, force: bool = False):
+        self.n_steps, self.ncol, self.group, self.dst, self.to_all = int(n_steps), int(ncol), group, int(dst), bool(to_all)
+        self.device = torch.device(device)
+        self.active = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force)
+        self.world = dist.get_world_size(group) if self.active else 1
+        self.rank = dist.get_rank(group) if self.active else 0
+        self.t0, self.t1 = shard_range(self.n_steps, self.world, self.rank)
+        self.width = (self.n_steps + self.world - 1) // self.world
+        self.receives = (not self.active) or self.to_all or self.rank == self.dst
+        self.slots = int(slots)
+        kw = dict(dtype=dtype, device=self.device)
+        self._send = [torch.zeros((self.width, self.ncol), **kw) for _ in range(self.slots)]
+        self._work = [None] * self.slots
+        self._pending = [False] * self.slots
+        self.profile: Optional[dict] = None
+        self.backend = dist.get_backend(group) if self.active else "none"
+        self.staged = self.active and self.backend == "gloo" and self.device.type == "cuda"
+        self.even = self.n_steps % self.world == 0
+        if not self.active:
+            return
+        hostkw = dict(dtype=dtype, device="cpu", pin_memory=self.device.type == "cuda")
+        if self.receives:
+            self._recv = [torch.empty((self.world, self.width, self.ncol), **kw) for _ in range(self.slots)]
+            if not self.even:
+                idx = [r * self.width + i for r in range(self.world) for i in range(shard_range(self.n_steps, self.world, r)[1]
+                                                                                   - shard_range(self.n_steps, self.world, r)[0])]
+                self._idx = torch.tensor(idx, dtype=torch.int64, device=self.device)
+                self._series = [torch.empty((self.n_steps, self.ncol), **kw) for _ in range(self.slots)]
+        if self.staged:
+            self._hsend = [torch.zeros((self.width, self.ncol), **hostkw) for _ in range(self.slots)]
+            self._staged_ev = [torch.cuda.Event() for _ in range(self.slots)]
+            if self.receives:
+                self._hrecv = [torch.empty((self.world, self.width, self.ncol), **hostkw) for _ in range(self.slots)]
+
+    # -- buffers ------------------------------------------------------------------------------------------------------------
+    def send(self, slot: int = 0) -> torch.Tensor:
+        """The slot's send buffer, this rank's own rows.  Waits (on the stream, not the host) for the collective that last read it."""
+        self.wait(slot)
+        return self._send[slot][: self.t1 - self.t0]
+
+    def wait(self, slot: int = 0) -> None:
+        w = self._work[slot]
+        if w is not None:
+            w.wait()               # nccl: the current stream waits for the collective; gloo: the host does
+            self._work[slot] = None
+
+    def _tick(self, key: str, t0: float) -> float:
+        if self.profile is not None:
+            if self.device.type == "cuda":
+                torch.cuda.synchronize(self.device)
+            now = time.perf_counter()
+            self.profile[key] = self.profile.get(key, 0.0) + (now - t0)
+            return now
+        return t0
+
+    # -- the exchange -------------------------------------------------------------------------------------------------------
+    def start(self, slot: int = 0) -> None:
+        """Launches the slot's collective.  The send buffer must not be written again before ``send(slot)`` / ``finish(slot)``."""
+        self._pending[slot] = True
+        if not self.active:
+            return
+        t = time.perf_counter() if self.profile is not None else 0.0
+        src = self._send[slot]
+        if self.staged:
+            self._hsend[slot].copy_(src, non_blocking=True)
+            self._staged_ev[slot].record(torch.cuda.current_stream(self.device))
+            self._staged_ev[slot].synchronize()                     # gloo reads host memory: the copy must have landed
+            t = self._tick("staging_d2h", t)
+            src = self._hsend[slot]
+        dstbuf = None
+        if self.receives:
+            dstbuf = self._hrecv[slot] if self.staged else self._recv[slot]
+        if self.to_all:
+            self._work[slot] = dist.all_gather_into_tensor(dstbuf.view(self.world * self.width, self.ncol), src, group=self.group, async_op=True)
+        else:
+            glist = list(dstbuf.unbind(0)) if self.rank == self.dst else None
+            dst_global = dist.get_global_rank(self.group, self.dst) if self.group is not None else self.dst
+            self._work[slot] = dist.gather(src, glist, dst=dst_global, group=self.group, async_op=True)
+        if self.profile is not None:
+            self._work[slot].wait()
+            self._work[slot] = None
+            self._tick("collective", t)
+
+    def finish(self, slot: int = 0) -> Optional[torch.Tensor]:
+        """Completes the slot's exchange; the series [n_steps, ncol] on the receiving rank(s) -- valid until the slot is used again."""
+        if not self._pending[slot]:
+            raise RuntimeError("finish() without start()")
+        self._pending[slot] = False
+        if not self.active:
+            return self._send[slot][: self.n_steps]
+        t = time.perf_counter() if self.profile is not None else 0.0
+        self.wait(slot)
+        t = self._tick("collective", t)
+        if not self.receives:
+            return None
+        buf = self._recv[slot]
+        if self.staged:
+            buf.copy_(self._hrecv[slot], non_blocking=True)
+            t = self._tick("staging_h2d", t)
+        flat = buf.view(self.world * self.width, self.ncol)
+        if self.even:
+            return flat
+        torch.index_select(flat, 0, self._idx, out=self._series[slot])
+        self._tick("unpack", t)
+        return self._series[slot]
+
+
 def gather_timeseries(local: torch.Tensor, n_steps: int, group=None) -> torch.Tensor:
-    """all_gather of per-time-step rows [T_local, n] into the full series [n_steps, n] on every rank.
-    Shards may differ by one step; they are padded to the largest shard for the collective."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    """One-shot form: per-time-step rows [T_local, n] of every rank -> the full series [n_steps, n] on EVERY rank
+    (``SeriesGatherer`` with ``to_all``; buffers made for this call).  CPU tensors over gloo, device tensors over nccl / gloo."""
+    if not _dist_on(group):
         if local.shape[0] != n_steps:
             raise ValueError("single process: local series must be the whole series")
         return local
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    t0, t1 = shard_range(n_steps, world, rank)
-    if local.shape[0] != t1 - t0:
-        raise ValueError(f"rank {rank}: expected {t1 - t0} local steps, got {local.shape[0]}")
-    width = (n_steps + world - 1) // world
-    pad = torch.zeros((width, local.shape[1]), dtype=local.dtype, device=local.device)
-    pad[: t1 - t0] = local
-    out = torch.empty((world * width, local.shape[1]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, pad.contiguous(), group=group)
-    parts = []
-    for r in range(world):
-        a, b = shard_range(n_steps, world, r)
-        parts.append(out[r * width: r * width + (b - a)])
-    return torch.cat(parts, dim=0)
+    g = SeriesGatherer(n_steps, local.shape[1], local.device, group=group, to_all=True, slots=1, dtype=local.dtype)
+    if local.shape[0] != g.t1 - g.t0:
+        raise ValueError(f"rank {g.rank}: expected {g.t1 - g.t0} local steps, got {local.shape[0]}")
+    g.send(0).copy_(local)
+    g.start(0)
+    return g.finish(0).clone()
 
 
 def merge_dropmask(mask: torch.Tensor, group=None) -> None:
     """Element-wise max of every rank's any-time NaN-level mask, in place (a [28, nl] int32 all_reduce): a level
     that stays NaN at any time step of ANY shard is dropped from the pressure integrals of every time step, as
     the reference's dropna(dim=level) on the whole [time, level] array does (energy_contents.py:203-207)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not _dist_on(group):
         return
     if dist.get_backend(group) == "gloo" and mask.is_cuda:      # CPU rehearsal: stage through host memory
         host = mask.cpu()
@@ -68,27 +198,25 @@ def merge_dropmask(mask: torch.Tensor, group=None) -> None:
 
 
 def compute_shard(engine, fields, time_s_global, n_steps: int, world: int, rank: int, box, *, with_q=True,
-                  phi_scale=1.0, timing=None, group=None):
+                  phi_scale=1.0, timing=None, group=None, out=None):
     """Runs the engine on this rank's contiguous block of time steps.
 
     ``fields``: dict with this rank's cubes (tair, u, v, omega, geopt) covering the HALO range
     ``halo_range(*shard_range(...))`` of the global series -- every rank holds its own steps plus one
     step either side, so dT/dt (np.gradient over the global time axis) needs no exchange.
-    ``time_s_global``: seconds of all n_steps.  Returns the LECResult of the rank's own steps."""
+    ``time_s_global``: seconds of all n_steps.  ``out``: where the packed records go (``SeriesGatherer.send``).
+    Returns the LECResult of the rank's own steps."""
     t0, t1 = shard_range(n_steps, world, rank)
     h0, h1 = halo_range(t0, t1, n_steps)
     if fields["tair"].shape[0] != h1 - h0:
         raise ValueError(f"rank {rank}: cube must hold time steps [{h0}, {h1}) (own steps plus halo)")
     return engine.compute(fields["tair"], fields["u"], fields["v"], fields["omega"], fields.get("geopt"), [box],
                           time_s=time_s_global[h0:h1] if with_q else None, t_begin=t0 - h0, t_count=t1 - t0,
-                          with_q=with_q, phi_scale=phi_scale, timing=timing,
+                          with_q=with_q, phi_scale=phi_scale, timing=timing, out=out,
                           merge_dropmask=(lambda m: merge_dropmask(m, group)) if world > 1 else None)
 
 
 def gather_result(res, n_steps: int, group=None):
-    """One collective: [T_local, 16 + 21 nl] rows of every rank -> full series on every rank.
-    With the gloo backend (CPU rehearsal) the rows are staged through host memory."""
-    local = torch.cat([res.scalars, res.levels.reshape(res.levels.shape[0], -1)], dim=1)
-    if dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "gloo":
-        return gather_timeseries(local.cpu(), n_steps, group).to(local.device)
+    """One-shot form: the packed records [T_local, 16 + 21 nl] of every rank -> the full series on every rank."""
+    local = res.packed if res.packed is not None else torch.cat([res.scalars, res.levels.reshape(res.levels.shape[0], -1)], dim=1)
     return gather_timeseries(local, n_steps, group)

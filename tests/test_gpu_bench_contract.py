@@ -42,6 +42,14 @@ def test_bench_json_contract():
     assert ct["achieved"] > 0 and abs(ct["frac"] - ct["achieved"] / 8000.0) < 1e-12 and ct["algorithmic_bytes_per_launch"] == 4 * 37 * 61 * 128 * 8 * 3
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["unit"] == "timesteps/s" and cb["sample"] and cb["host_cpu_count"] >= 1
+    # the CPU leg is also the line's parity check: the oracle evaluated steps of the cube the GPU was timed on
+    pr = d["parity"]
+    assert pr["ok"] is True and pr["worst_rel_to_scale"] <= 1e-9 and pr["levels_worst_rel_to_scale"] <= 1e-9
+    assert pr["steps"] == 2 and pr["terms_compared"] == 14 and pr["level_tables_compared"] == 21 and "59 x 128" in pr["box"]     # polar rows left out
+    # where a pass's time goes
+    sg = d["config"]["segments_ms"]
+    for k in ("stage1", "stage2", "gather", "pass_total_synchronised", "pass_timed_unsynchronised", "stage1_kernels_hip_events", "fixed_cost_per_pass"):
+        assert k in sg and sg[k] >= 0 or k == "fixed_cost_per_pass", k
 
 
 def test_bench_starts_its_own_ranks_and_counts_them():
@@ -52,7 +60,27 @@ def test_bench_starts_its_own_ranks_and_counts_them():
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["world_size"] == 2 and d["config"]["timesteps_global"] == 6 and d["scaling"] == "weak"
-    assert d["config"]["backend"] == "gloo" and d["config"]["results_finite"] is True
+    assert d["config"]["backend"] == "gloo" and d["config"]["results_finite"] is True and d["config"]["gathered_series_ok"] is True
+    sg = d["config"]["segments_ms"]
+    for k in ("stage1", "stage2", "mask_all_reduce", "gather", "gather.staging_d2h", "gather.collective", "gather.staging_h2d", "fixed_cost_per_pass"):
+        assert k in sg, k
+
+
+def test_bench_runs_the_rccl_code_path_with_one_rank():
+    """--force-dist: process group over backend "nccl" (= RCCL), barrier, the mask all_reduce and the gather run with world size 1 --
+    the N > 1 code path of the product on the one GPU this box has (more RCCL ranks need more GPUs)."""
+    r, lines = _bench(["--force-dist", "--timesteps", "3", "--cpu-baseline", "none"] + SMALL)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["backend"] == "nccl" and d["config"]["results_finite"] is True and d["config"]["gathered_series_ok"] is True
+    assert "mask_all_reduce" in d["config"]["segments_ms"] and "gather.collective" in d["config"]["segments_ms"]
+
+
+def test_bench_moving_checks_its_kernel_against_the_independent_one():
+    r, lines = _bench(["--moving", "--timesteps", "12", "--cpu-baseline", "none", "--steps", "2", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    mc = json.loads(lines[0])["config"]["moving_check"]
+    assert mc["ok"] is True and mc["steps"] == 8 and mc["timed_pass_bit_identical"] is True and mc["terms_max_rel_diff_vs_row_sweep"] <= 1e-9
 
 
 def test_bench_refuses_what_it_cannot_launch():

@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from lorenzcycletoolkit_amd.parallel import gather_timeseries, halo_range, merge_dropmask, shard_range
+from lorenzcycletoolkit_amd.parallel import SeriesGatherer, gather_timeseries, halo_range, merge_dropmask, shard_range
 from lorenzcycletoolkit_amd.tables import budgets_and_residuals
 
 
@@ -54,6 +54,29 @@ def _worker(rank, world, port, n_steps, out_dir):
         mask[27, 5] = rank + 1
         merge_dropmask(mask)
         np.save(os.path.join(out_dir, f"mask_{rank}.npy"), mask.numpy())
+        # the allocation-free form the product uses: records written in place into the send buffer of a pipeline slot, the series
+        # gathered to rank 0 only; three passes through two slots -- pass p carries p in its fourth column
+        g = SeriesGatherer(n_steps, 4, "cpu", dst=0, slots=2)
+        assert (g.t0, g.t1) == (t0, t1) and g.receives == (rank == 0)
+        ptrs = [g.send(sl).data_ptr() for sl in range(2)]
+        got = []
+        for p in range(3):
+            sl = p % 2
+            if p >= 2:
+                got.append(g.finish(sl))
+                got[-1] = None if got[-1] is None else got[-1].clone()
+            buf = g.send(sl)
+            assert buf.data_ptr() == ptrs[sl] and buf.shape == (t1 - t0, 4)      # the same buffer every pass: nothing is allocated
+            buf[:, :3] = local
+            buf[:, 3] = float(p)
+            g.start(sl)
+        for p in (1, 2):
+            r = g.finish(p % 2)
+            got.append(None if r is None else r.clone())
+        if rank == 0:
+            np.save(os.path.join(out_dir, "passes.npy"), np.stack([x.numpy() for x in got]))
+        else:
+            assert all(x is None for x in got)
     finally:
         dist.destroy_process_group()
 
@@ -71,6 +94,21 @@ def test_gather_timeseries_gloo(tmp_path, world, n_steps):
     for r in range(world):
         assert np.array_equal(np.load(tmp_path / f"full_{r}.npy"), want)
         assert np.array_equal(np.load(tmp_path / f"mask_{r}.npy"), want_mask)
+    passes = np.load(tmp_path / "passes.npy")
+    assert passes.shape == (3, n_steps, 4)
+    for p in range(3):
+        assert np.array_equal(passes[p, :, :3], want) and np.all(passes[p, :, 3] == p)
+
+
+def test_series_gatherer_single_process():
+    g = SeriesGatherer(5, 3, "cpu")
+    assert not g.active and g.receives and (g.t0, g.t1) == (0, 5)
+    g.send(0)[:] = 7.0
+    g.start(0)
+    s = g.finish(0)
+    assert s.shape == (5, 3) and s.data_ptr() == g.send(0).data_ptr() and torch.all(s == 7.0)
+    with pytest.raises(RuntimeError):
+        g.finish(0)
 
 
 def test_merge_dropmask_single_process_is_a_no_op():
