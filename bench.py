@@ -469,7 +469,10 @@ def run_rank(args):
         sync()
     segments = None
     if seg_runs:
-        keys = sorted({k for sg in seg_runs for k in sg})
+        # one key list on every rank (the receiving rank has legs the others lack): the all_reduce below needs equal shapes
+        keys = ["gather_finish_previous", "stage1", "stage2", "mask_all_reduce", "gather", "gather.staging_d2h", "gather.collective",
+                "gather.staging_h2d", "gather.unpack", "pass_total_synchronised"]
+        assert all(k in keys for sg in seg_runs for k in sg)
         med = {k: float(np.median([sg.get(k, 0.0) for sg in seg_runs])) * 1e3 for k in keys}
         if use_dist:      # the slowest rank's figure per segment
             tt = torch.tensor([med[k] for k in keys], dtype=torch.float64, device=device)

@@ -6,6 +6,11 @@ Same flags, same ``inputs/namelist`` / ``inputs/box_limits`` / track files, same
 ``./LEC_Results/<infile>_<method>/`` tree and CSV schema; the numerics run as HIP kernels on the GPU
 (``lorenzcycletoolkit_amd``).  Out of scope: plots (-p), the interactive
 domain chooser (-c), CDS-API downloads (--cdsapi).
+
+Several GPUs of one node: ``python lorenzcycletoolkit.py <file> -r -f --gpus N`` (this process starts N rank processes, one per
+GPU) or ``python -m torch.distributed.run --nproc-per-node N lorenzcycletoolkit.py <file> -r -f``.  The time steps are sharded
+over the ranks (each reads, decodes and computes only its own block plus a one-step halo of T), rank 0 gathers the per-step
+results over RCCL and writes the very same files as the one-GPU run.
 """
 import argparse
 import logging
@@ -41,6 +46,8 @@ def create_arg_parser():
     parser.add_argument("--box_limits", type=str, default="inputs/box_limits", help="box-limits file for -f (default: inputs/box_limits)")
     parser.add_argument("--device-ingest", action="store_true", help="stream the file's bytes to the GPU in chunks and decode / sort / crop them "
                         "there, instead of preparing the whole data set on the host (same results, bit for bit)")
+    parser.add_argument("--gpus", type=int, default=1, help="shard the time steps over this many GPUs of the node (one process per GPU, "
+                        "results gathered over RCCL; same output files).  Under torch.distributed.run the launcher's WORLD_SIZE counts")
     parser.add_argument("-o", "--outname", type=str, help="name of the results CSV (fixed framework)")
     return parser
 
@@ -57,13 +64,21 @@ def setup_results_directory(args, method):
 
 
 def initialize_logging(results_subdirectory, args):
-    """Reference src/utils/tools.py:32-73: logger "lorenzcycletoolkit", file log.<stem> + console."""
+    """Reference src/utils/tools.py:32-73: logger "lorenzcycletoolkit", file log.<stem> + console.  In a time-sharded run only
+    rank 0 logs to the file; the other ranks report warnings and errors on the console."""
     level = logging.DEBUG if args.verbosity else logging.INFO
     logger = logging.getLogger("lorenzcycletoolkit")
     logger.setLevel(level)
     for h in list(logger.handlers):
         logger.removeHandler(h)
     fmt = logging.Formatter("%(asctime)s - %(name)s - %(levelname)s - %(message)s")
+    shard = getattr(args, "shard", None)
+    if shard is not None and not shard.root:
+        ch = logging.StreamHandler()
+        ch.setFormatter(logging.Formatter(f"%(asctime)s - rank {shard.rank} - %(levelname)s - %(message)s"))
+        ch.setLevel(logging.WARNING)
+        logger.addHandler(ch)
+        return logger
     stem = os.path.basename(args.infile).split(".nc")[0]
     fh = logging.FileHandler(os.path.join(results_subdirectory, f"log.{stem}"), mode="w")
     fh.setFormatter(fmt)
@@ -89,12 +104,31 @@ def run_lec_analysis(data, args, results_subdirectory, figures_directory, result
 
 
 def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
     args = create_arg_parser().parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        # this process only starts the ranks (before anything touches a GPU) and waits for them
+        from lorenzcycletoolkit_amd.parallel import launch_local_ranks
+        sys.exit(launch_local_ranks(__file__, argv, args.gpus))
+    if env_world is not None and args.gpus > 1 and int(env_world) != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} contradicts WORLD_SIZE={env_world}")
+    from lorenzcycletoolkit_amd.parallel import shard_from_env
+    args.shard = shard_from_env()                      # None: the ordinary one-process run
     method = "fixed" if args.fixed else ("track" if args.track else "choose")
-    results_subdirectory, figures_directory, results_subdirectory_vertical_levels = setup_results_directory(args, method)
+    if args.shard is None or args.shard.root:
+        results_subdirectory, figures_directory, results_subdirectory_vertical_levels = setup_results_directory(args, method)
+    else:                                              # the paths only: rank 0 creates the tree and writes every file
+        results_subdirectory = os.path.join("./LEC_Results/", "".join(args.infile.split("/")[-1].split(".nc")) + "_" + method)
+        results_subdirectory_vertical_levels = os.path.join(results_subdirectory, "results_vertical_levels")
+        figures_directory = os.path.join(results_subdirectory, "Figures")
     app_logger = initialize_logging(results_subdirectory, args)
     app_logger.info("Starting LEC analysis")
     app_logger.info(f"Command line arguments: {args}")
+    if args.shard is not None:
+        app_logger.info(f"Time-sharded run: {args.shard.world} ranks (backend {args.shard.backend}), one GPU each; rank 0 writes the results")
     try:
         if args.device_ingest:
             from lorenzcycletoolkit_amd.ingest import prepare_streamed
@@ -109,6 +143,11 @@ def main(argv=None):
     except Exception:
         app_logger.exception("LEC analysis failed")
         raise
+    finally:
+        if args.shard is not None:
+            import torch.distributed as dist
+            if dist.is_initialized():
+                dist.destroy_process_group()
 
 
 if __name__ == "__main__":

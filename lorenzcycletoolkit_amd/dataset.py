@@ -41,6 +41,7 @@ class LECDataset:
     time: np.ndarray                  # datetime64[ns]
     names: Dict[str, str] = field(default_factory=dict)   # role -> variable / coordinate name
     level_units: Optional[str] = None
+    t_held: Optional[tuple] = None    # time-sharded run: the variables hold only the steps [h0, h1) of `time` (own steps + T halo)
 
     @property
     def time_s(self) -> np.ndarray:
@@ -51,8 +52,16 @@ class LECDataset:
         t = slice(None) if t is None else t
         j = slice(None) if j is None else j
         i = slice(None) if i is None else i
+        if self.t_held is not None and not (isinstance(t, slice) and t == slice(None)):
+            raise ValueError("a time-sharded data set cannot be re-sliced in time")
         v = {k: np.ascontiguousarray(a[t][:, :, j][:, :, :, i]) for k, a in self.variables.items()}
-        return LECDataset(v, self.lat[j], self.lon[i], self.level, self.time[t], dict(self.names), self.level_units)
+        return LECDataset(v, self.lat[j], self.lon[i], self.level, self.time[t], dict(self.names), self.level_units, self.t_held)
+
+    def held_steps(self, t_held) -> "LECDataset":
+        """The same data set holding only the time steps [h0, h1) of its (unchanged) time axis: a rank's share of a sharded run."""
+        h0, h1 = t_held
+        v = {k: np.ascontiguousarray(a[h0:h1]) for k, a in self.variables.items()}
+        return LECDataset(v, self.lat, self.lon, self.level, self.time, dict(self.names), self.level_units, (int(h0), int(h1)))
 
 
 # --------------------------------------------------------------------------------------------
@@ -479,16 +488,18 @@ def make_plan(raw: "RawDataset", args, app_logger=None) -> IngestPlan:
 
 
 
-def gather_on_host(var: RawVariable, plan: IngestPlan) -> np.ndarray:
+def gather_on_host(var: RawVariable, plan: IngestPlan, t_range=None) -> np.ndarray:
     """The analysis-domain cube of one raw variable, decoded -- what lec_ingest does on the GPU, one time step at a time
-    on the host, so that only the selected time steps and the cropped domain are ever read from a large file."""
+    on the host, so that only the selected time steps and the cropped domain are ever read from a large file.
+    ``t_range``: only the processed time steps [a, b) (a rank's share of a time-sharded run)."""
     out = None
-    for n, ft in enumerate(plan.tsel):
+    tsel = plan.tsel if t_range is None else plan.tsel[t_range[0]: t_range[1]]
+    for n, ft in enumerate(tsel):
         raw = np.asarray(var.data[int(ft)])[plan.kmap][:, plan.jmap][:, :, plan.imap]
         raw = raw.astype(raw.dtype.newbyteorder("="))
         a = decode_values(raw, var.scale_factor, var.add_offset, var.fill_value)
         if out is None:
-            out = np.empty((len(plan.tsel),) + a.shape, dtype=a.dtype)
+            out = np.empty((len(tsel),) + a.shape, dtype=a.dtype)
         out[n] = a
     return out
 
@@ -501,16 +512,19 @@ def prepare_data(args, varlist: str = "inputs/namelist", app_logger=None) -> LEC
     if getattr(args, "cdsapi", False):
         raise NotImplementedError("--cdsapi downloads need network access and are out of scope")
     variable_list_df = read_namelist(varlist, app_logger)
+    shard = getattr(args, "shard", None)          # time-sharded run (parallel.ShardContext): this rank decodes its own steps + halo only
     try:
         raw = open_raw(args.infile, variable_list_df)
     except ValueError as e:
         if "order" not in str(e) and "device ingest reads" not in str(e):
             raise
         data = open_dataset(args.infile, variable_list_df)
-        return slice_domain(process_data(data, args, variable_list_df, app_logger), args, variable_list_df)
+        data = slice_domain(process_data(data, args, variable_list_df, app_logger), args, variable_list_df)
+        return data if shard is None else data.held_steps(shard.ranges(len(data.time))[2:])
     try:
         plan = make_plan(raw, args, app_logger)
-        variables = {name: gather_on_host(var, plan) for name, var in raw.variables.items()}
-        return LECDataset(variables, plan.lat, plan.lon, plan.level, plan.time, dict(raw.names), "Pa")
+        held = None if shard is None else shard.ranges(len(plan.tsel))[2:]
+        variables = {name: gather_on_host(var, plan, held) for name, var in raw.variables.items()}
+        return LECDataset(variables, plan.lat, plan.lon, plan.level, plan.time, dict(raw.names), "Pa", held)
     finally:
         raw.close()

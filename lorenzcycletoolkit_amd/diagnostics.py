@@ -136,24 +136,40 @@ def positions(val, pos, lat_deg, lon_deg, limits, track_row=None, use_track_zeta
     }
 
 
-def track_diagnostics(data, variable_list_df, limits_per_step, track=None, use_track_zeta=False, device="cuda:0"):
-    """All time steps: u, v, geopotential height at 85000 Pa -> list of position dicts."""
+_POSITION_KEYS = ["min_max_zeta_850_lat", "min_max_zeta_850_lon", "min_max_zeta_850", "min_hgt_850_lat", "min_hgt_850_lon", "min_hgt_850",
+                  "max_wind_850_lat", "max_wind_850_lon", "max_wind_850"]
+
+
+def track_diagnostics(data, variable_list_df, limits_per_step, track=None, use_track_zeta=False, device="cuda:0", shard=None):
+    """All time steps: u, v, geopotential height at 85000 Pa -> list of position dicts.  ``shard`` (parallel.ShardContext): every
+    rank evaluates its own time steps (each is independent), one gather of nine numbers per step brings them to rank 0; the other
+    ranks get None."""
+    import torch
+    n_steps = len(limits_per_step)
+    t0, t1 = (0, n_steps) if shard is None else shard.ranges(n_steps)[:2]
     k850 = int(np.flatnonzero(data.level == 85000.0)[0])
     name = lambda role: str(variable_list_df.loc[role]["Variable"])
     if hasattr(data, "level_slice"):          # streamed data set: three level slices decoded from the mapped file
-        get = lambda role: data.level_slice(role, 85000.0)
+        get = lambda role: data.level_slice(role, 85000.0, (t0, t1))
     else:
-        get = lambda role: data.variables[name(role)][:, k850]
+        h0 = (getattr(data, "t_held", None) or (0, n_steps))[0]          # the variables start at step h0 of the time axis
+        get = lambda role: data.variables[name(role)][t0 - h0: t1 - h0, k850]
     u, v = get("Eastward Wind Component"), get("Northward Wind Component")
     if "Geopotential Height" in variable_list_df.index:
         hgt = get("Geopotential Height").astype(np.float64)
     else:
         hgt = get("Geopotential").astype(np.float64) / G       # -> gpm
-    val, pos = device_extrema(u, v, hgt, data.lat, data.lon, limits_per_step, device=device)
+    val, pos = device_extrema(u, v, hgt, data.lat, data.lon, limits_per_step[t0:t1], device=device)
     out = []
-    for t, lim in enumerate(limits_per_step):
+    for t in range(t0, t1):
         row = None
         if track is not None:
             row = track.iloc[int(np.argmin(np.abs(track.index - data.time[t])))]
-        out.append(positions(val[t], pos[t], data.lat, data.lon, lim, row, use_track_zeta))
-    return out
+        out.append(positions(val[t - t0], pos[t - t0], data.lat, data.lon, limits_per_step[t], row, use_track_zeta))
+    if shard is None:
+        return out
+    local = torch.tensor([[d[k] for k in _POSITION_KEYS] for d in out], dtype=torch.float64, device=device)
+    full = shard.gather_rows(local, n_steps)
+    if full is None:
+        return None
+    return [dict(zip(_POSITION_KEYS, (float(x) for x in row))) for row in full.cpu().numpy()]

@@ -30,7 +30,8 @@ MOVING_COLUMNS = ["Az", "Ae", "Kz", "Ke", "Cz", "Ca", "Ck", "Ce", "BAz", "BAe", 
 
 
 def _device(args=None):
-    dev = getattr(args, "device", None) or os.environ.get("LEC_DEVICE", "cuda:0")
+    shard = getattr(args, "shard", None)
+    dev = shard.device if shard is not None else (getattr(args, "device", None) or os.environ.get("LEC_DEVICE", "cuda:0"))
     if not torch.cuda.is_available():
         raise RuntimeError("lorenzcycletoolkit_amd needs an AMD GPU (PyTorch-ROCm): there is no CPU path")
     return torch.device(dev)
@@ -43,6 +44,11 @@ class BoxData:
     Moving framework: pass ``boxes_limits`` = one (west, east, south, north) per time step (the four
     scalar limits are then ignored); ``dTdt`` may be None (differentiated on the device, as
     lorenzcycletoolkit.py:184-186 does over the same time axis) or a host cube.
+
+    Time-sharded runs (``args.shard``, a parallel.ShardContext: one process per GPU): every rank computes its contiguous block of
+    time steps from the steps it holds (own + one-step T halo; ``data.t_held``), the any-time NaN-level mask is merged across the
+    ranks, and ONE gather brings the packed per-step records to rank 0, whose BoxData then looks exactly like the one-process one;
+    on the other ranks ``result`` / ``scalars`` / ``levels`` are None.
     """
 
     def __init__(self, data: ds.LECDataset, variable_list_df: pd.DataFrame, western_limit=None, eastern_limit=None,
@@ -70,6 +76,19 @@ class BoxData:
         self.western_limit, self.eastern_limit = float(data.lon[iw]), float(data.lon[ie])
         self.southern_limit, self.northern_limit = float(data.lat[js]), float(data.lat[jn])
 
+        n_steps, nl = len(data.time), len(data.level)
+        shard = self.shard = getattr(args, "shard", None)
+        t0, t1, h0, h1 = (0, n_steps, 0, n_steps) if shard is None else shard.ranges(n_steps)
+        self.t_own, self.t_held = (t0, t1), (h0, h1)
+        width = LECEngine.packed_width(nl)
+        out, merge, gat = None, None, None
+        if shard is not None:
+            # one extra column carries the NaN counter of the step, so that ONE gather moves everything rank 0 needs
+            from .parallel import SeriesGatherer
+            gat = SeriesGatherer(n_steps, width + 1, dev, group=shard.group, dst=0, slots=1, force=True)
+            out = gat.send(0)[:, :width]
+            merge = shard.merge_dropmask if not self.per_step_boxes else None
+
         from .ingest import StreamedDataset, lec_streamed
         if isinstance(data, StreamedDataset):
             # device ingest: the file bytes are streamed, decoded, sorted and cropped on the GPU (ingest.py); in the moving
@@ -78,16 +97,35 @@ class BoxData:
                 raise NotImplementedError("the device ingest differentiates T in time itself; do not pass a dTdt cube")
             self.ingest_stats = {}
             self.result: LECResult = lec_streamed(data.raw, data.plan, variable_list_df, limits, per_step_boxes=boxes_limits is not None,
-                                                  device=dev, chunk_steps=data.chunk_steps, stats=self.ingest_stats)
+                                                  device=dev, chunk_steps=data.chunk_steps, stats=self.ingest_stats,
+                                                  t_range=None if shard is None else (t0, t1), merge_dropmask=merge, out=out)
         else:
-            self.result = self._compute_resident(data, variable_list_df, dev, dTdt)
+            self.result = self._compute_resident(data, variable_list_df, dev, dTdt, merge, out)
+        if shard is not None:
+            gat.send(0)[:, width] = self.result.nanflag.to(torch.float64)
+            gat.start(0)
+            series = gat.finish(0)
+            torch.cuda.synchronize(dev)
+            if series is None:                   # not the rank that writes the results
+                self.result = self.scalars = self.levels = self.nanflag = None
+                return
+            self.result = LECResult(scalars=series[:, :16], levels=series[:, 16:width].unflatten(1, (21, nl)),
+                                    nanflag=series[:, width].to(torch.int32), packed=series[:, :width])
         torch.cuda.synchronize(dev)
         self.scalars = self.result.scalars_dict()
         self.levels = self.result.levels_dict()
         self.nanflag = self.result.nanflag.cpu().numpy()
 
-    def _compute_resident(self, data: ds.LECDataset, variable_list_df: pd.DataFrame, dev, dTdt) -> LECResult:
-        """Host-prepared cubes, uploaded whole."""
+    def _compute_resident(self, data: ds.LECDataset, variable_list_df: pd.DataFrame, dev, dTdt, merge=None, out=None) -> LECResult:
+        """Host-prepared cubes, uploaded whole (a time-sharded rank: the steps it holds)."""
+        (t0, t1), (h0, h1) = self.t_own, self.t_held
+        n_steps = len(data.time)
+        held = getattr(data, "t_held", None) or (0, n_steps)
+        if self.shard is not None and tuple(held) == (0, n_steps) and (h0, h1) != (0, n_steps):
+            data = data.held_steps((h0, h1))         # a whole data set handed to a sharded BoxData: keep this rank's steps only
+            held = (h0, h1)
+        if tuple(held) != (h0, h1):
+            raise ValueError(f"data set holds time steps {held}, this rank needs {(h0, h1)}")
         geo_role = "Geopotential" if "Geopotential" in variable_list_df.index else "Geopotential Height"
         roles = ["Air Temperature", "Eastward Wind Component", "Northward Wind Component", "Omega Velocity", geo_role]
         arrays = []
@@ -104,10 +142,21 @@ class BoxData:
         common = np.result_type(*[a.dtype for a in arrays])
         cubes = [torch.as_tensor(np.ascontiguousarray(a, dtype=common)).to(dev) for a in arrays]
         phi_scale = ds.field_scale(variable_list_df, geo_role)
-        dTdt_dev = None if dTdt is None else torch.as_tensor(np.ascontiguousarray(dTdt, dtype=cubes[0].cpu().numpy().dtype)).to(dev)
-        return self.engine.compute(cubes[0], cubes[1], cubes[2], cubes[3], cubes[4], self.boxes,
-                                   time_s=data.time_s if dTdt is None else None, dTdt=dTdt_dev, phi_scale=phi_scale,
-                                   per_step_boxes=self.per_step_boxes)
+        dTdt_dev = None
+        if dTdt is not None:
+            dTdt = np.asarray(dTdt)
+            if dTdt.shape[0] == n_steps and (h0, h1) != (0, n_steps):
+                dTdt = dTdt[h0:h1]
+            dTdt_dev = torch.as_tensor(np.ascontiguousarray(dTdt, dtype=common)).to(dev)
+        boxes = self.boxes[t0:t1] if self.per_step_boxes else self.boxes
+        if self.per_step_boxes and self.shard is not None:
+            # the records of every rank have the row count of the tallest box of the WHOLE series (as the one-process run's)
+            nyb = max(b[3] - b[2] + 1 for b in self.boxes)
+            boxes = self.engine.prepare_boxes(boxes, nyb_min=nyb)
+        return self.engine.compute(cubes[0], cubes[1], cubes[2], cubes[3], cubes[4], boxes,
+                                   time_s=data.time_s[h0:h1] if dTdt is None else None, dTdt=dTdt_dev, phi_scale=phi_scale,
+                                   t_begin=t0 - h0, t_count=t1 - t0, per_step_boxes=self.per_step_boxes,
+                                   drop_any_time=not self.per_step_boxes, merge_dropmask=merge, out=out)
 
 
 class _Terms:
@@ -207,13 +256,18 @@ def lec_fixed(data: ds.LECDataset, variable_list_df: pd.DataFrame, results_subdi
     time_name = variable_list_df.loc["Time"]["Variable"]
     vert_name = variable_list_df.loc["Vertical Level"]["Variable"]
     app_logger.info(f"Bounding box: lon=[{min_lon}, {max_lon}], lat=[{min_lat}, {max_lat}]")
-    _create_level_csvs(results_subdirectory_vertical_levels, time_name, vert_name, data.level)
+    shard = getattr(args, "shard", None)
+    root = shard is None or shard.root
+    if root:
+        _create_level_csvs(results_subdirectory_vertical_levels, time_name, vert_name, data.level)
     try:
         box_obj = BoxData(data, variable_list_df, min_lon, max_lon, min_lat, max_lat, args, results_subdirectory,
                           results_subdirectory_vertical_levels)
     except Exception:
         app_logger.exception("An exception occurred while creating BoxData object")
         raise
+    if box_obj.result is None:              # time-sharded run: rank 0 holds the gathered series and writes every file
+        return None
     if int(box_obj.nanflag.sum()):
         app_logger.warning("NaN level values were interpolated/dropped per time step (_handle_nans semantics)")
     terms = _compute_all(box_obj, "fixed", app_logger)
@@ -258,7 +312,10 @@ def lec_moving(data: ds.LECDataset, variable_list_df: pd.DataFrame, dTdt, result
         raise NotImplementedError("only -t/--track is supported; -c/--choose needs an interactive map")
     time_name = variable_list_df.loc["Time"]["Variable"]
     vert_name = variable_list_df.loc["Vertical Level"]["Variable"]
-    _create_level_csvs(results_subdirectory_vertical_levels, time_name, vert_name, data.level)
+    shard = getattr(args, "shard", None)
+    root = shard is None or shard.root
+    if root:
+        _create_level_csvs(results_subdirectory_vertical_levels, time_name, vert_name, data.level)
     times = pd.DatetimeIndex(data.time)
     track = ds.read_track(args.trackfile, app_logger)
     # handle_track_file (lec_moving_framework.py:58-160)
@@ -277,6 +334,12 @@ def lec_moving(data: ds.LECDataset, variable_list_df: pd.DataFrame, dTdt, result
     box_obj = BoxData(data, variable_list_df, args=args, results_subdirectory=results_subdirectory,
                       results_subdirectory_vertical_levels=results_subdirectory_vertical_levels, dTdt=dTdt,
                       boxes_limits=boxes)
+    # 850-hPa diagnostics of every box (lec_moving_framework.py:650-709); a time-sharded rank does its own steps, rank 0 gets them all
+    from .diagnostics import track_diagnostics
+    positions = track_diagnostics(data, variable_list_df, limits, track, use_track_zeta=bool(getattr(args, "zeta", False)),
+                                  device=_device(args), shard=shard)
+    if box_obj.result is None:              # time-sharded run: rank 0 holds the gathered series and writes every file
+        return None
     terms = _compute_all(box_obj, "moving", app_logger)
     df = pd.DataFrame({c: terms[c] for c in MOVING_COLUMNS}, index=times, dtype=float)
     full = budgets_and_residuals({c: df[c].values for c in df.columns}, data.time_s,
@@ -292,9 +355,6 @@ def lec_moving(data: ds.LECDataset, variable_list_df: pd.DataFrame, dTdt, result
     # 850-hPa diagnostics of every box (lec_moving_framework.py:650-709); parity unpinned, see diagnostics.py
     app_logger.info("850 hPa track diagnostics (min_max_zeta_850, min_hgt_850, max_wind_850): spherical three-point vorticity on the "
                     "GPU (lec_track_diag); NOT pinned against MetPy 1.6.2's vorticity (geodesic grid distances), expect agreement to a few 1e-3 relative")
-    from .diagnostics import track_diagnostics
-    positions = track_diagnostics(data, variable_list_df, limits, track, use_track_zeta=bool(getattr(args, "zeta", False)),
-                                  device=_device(args))
     out_track = pd.DataFrame([{**l, **p} for l, p in zip(limits, positions)])
     out_track = out_track.rename(columns={"datestr": "time", "central_lat": "Lat", "central_lon": "Lon"})
     out_track.to_csv(os.path.join(results_subdirectory, f"{infile_name}_{method}_trackfile"), index=False, sep=";")

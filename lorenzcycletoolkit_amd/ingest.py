@@ -46,13 +46,13 @@ class StreamedDataset:
     plan: IngestPlan
     chunk_steps: int = 8
 
-    def level_slice(self, role: str, level_pa: float) -> np.ndarray:
+    def level_slice(self, role: str, level_pa: float, t_range=None) -> np.ndarray:
         """[time, lat, lon] of one role at one level, decoded on the host from the mapped file (the 850-hPa track diagnostics
-        need three such slices: 3 / (5 * levels) of the data)."""
+        need three such slices: 3 / (5 * levels) of the data).  ``t_range``: only the processed steps [a, b)."""
         k = int(np.flatnonzero(self.plan.level == level_pa)[0])
         sub = ds.IngestPlan(self.plan.tsel, self.plan.kmap[k:k + 1], self.plan.jmap, self.plan.imap, self.plan.lat, self.plan.lon,
                             self.plan.level[k:k + 1], self.plan.time)
-        return ds.gather_on_host(self.raw.variables[self.raw.names[role]], sub)[:, 0]
+        return ds.gather_on_host(self.raw.variables[self.raw.names[role]], sub, t_range)[:, 0]
 
     lat = property(lambda self: self.plan.lat)
     lon = property(lambda self: self.plan.lon)
@@ -205,12 +205,15 @@ def device_cube(var: ds.RawVariable, plan: IngestPlan, device="cuda:0", unit: fl
 
 
 def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_limits, *, per_step_boxes: bool = False,
-                 device="cuda:0", chunk_steps: int = 8, with_q: bool = True, stats: Optional[dict] = None) -> LECResult:
+                 device="cuda:0", chunk_steps: int = 8, with_q: bool = True, stats: Optional[dict] = None,
+                 t_range=None, merge_dropmask=None, out=None) -> LECResult:
     """All LEC terms for the whole series, streamed from the memory-mapped file.
 
     ``boxes_limits``: one (west, east, south, north) in degrees (fixed framework, as inputs/box_limits) or one per time step
     (``per_step_boxes``: the moving framework; dT/dt is differentiated over the plan's time axis on the device).
     ``chunk_steps`` time steps are resident per pipeline slot (two slots).  ``stats`` receives counters: bytes moved, chunks, dtype.
+    ``t_range`` = (t0, t1): a rank's share of a time-sharded run -- only those steps (and their one-step T halo) are staged, copied
+    and computed, so N ranks move 1/N of the bytes each, over N host links; ``merge_dropmask`` / ``out``: see ``LECEngine.reduce``.
     """
     lib = _lib.load()
     dev = torch.device(device)
@@ -223,7 +226,10 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
         raise ValueError("boxes_limits: one box, or one per time step with per_step_boxes")
     if with_q and nt < 2:
         raise ValueError("dT/dt by finite differences needs at least 2 time steps")
-    chunk_steps = max(1, min(int(chunk_steps), nt))
+    t0, t1 = (0, nt) if t_range is None else (int(t_range[0]), int(t_range[1]))
+    if not (0 <= t0 < t1 <= nt):
+        raise ValueError("t_range outside the series")
+    chunk_steps = max(1, min(int(chunk_steps), t1 - t0))
     geo_role = raw.geo_role
     roles = list(_ROLE_KEYS) + [geo_role]
     keys = {**_ROLE_KEYS, geo_role: "geopt"}
@@ -240,8 +246,11 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
     cubes = [{keys[r]: torch.empty((span, nl, ny, nx), dtype=out_dtype, device=dev) for r in roles} for _ in range(slots)]
     up = lambda a: torch.as_tensor(a, dtype=torch.int32).to(dev)
     maps = (up(np.searchsorted(file_levels, plan.kmap)), up(plan.jmap - j0), up(plan.imap))   # maps into the staged sub-cube
-    bt, _ = engine._box_tables(boxes)
-    rows = torch.empty((nt, nl, bt.nyb_max, _lib.LEC_NSTAT), dtype=torch.float64, device=dev)
+    own_boxes = boxes[t0:t1] if per_step_boxes else boxes
+    bt, _ = engine._box_tables(boxes)            # the row count of the records is the tallest box of the WHOLE series, on every rank
+    if per_step_boxes:
+        own_boxes = engine.prepare_boxes(own_boxes, nyb_min=bt.nyb_max)
+    rows = torch.empty((t1 - t0, nl, bt.nyb_max, _lib.LEC_NSTAT), dtype=torch.float64, device=dev)
     time_s = plan.time_s
     phi_scale = ds.field_scale(variable_list_df, geo_role)
 
@@ -251,10 +260,10 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
     consumed = [torch.cuda.Event() for _ in range(slots)]      # the slot's raw buffers have been decoded
     used = [False] * slots
     moved, host_s = 0, 0.0
-    n_chunks = (nt + chunk_steps - 1) // chunk_steps
+    n_chunks = (t1 - t0 + chunk_steps - 1) // chunk_steps
     for c in range(n_chunks):
         slot = c % slots
-        c0, c1 = c * chunk_steps, min((c + 1) * chunk_steps, nt)
+        c0, c1 = t0 + c * chunk_steps, min(t0 + (c + 1) * chunk_steps, t1)
         h0, h1 = (max(c0 - 1, 0), min(c1 + 1, nt)) if with_q else (c0, c1)
         if used[slot]:
             copied[slot].synchronize()          # the pinned buffers of this slot may be overwritten now
@@ -284,9 +293,9 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
         f = {k: t[: h1 - h0] for k, t in cubes[slot].items()}
         engine.rowstats(f["tair"], f["u"], f["v"], f["omega"], f["geopt"], boxes[c0:c1] if per_step_boxes else boxes,
                         time_s=time_s[h0:h1] if with_q else None, t_begin=c0 - h0, t_count=c1 - c0, with_q=with_q,
-                        rows_out=rows[c0:c1], per_step_boxes=per_step_boxes)
+                        rows_out=rows[c0 - t0:c1 - t0], per_step_boxes=per_step_boxes)
         used[slot] = True
-    res = engine.reduce(rows, boxes, phi_scale=phi_scale, drop_any_time=not per_step_boxes)
+    res = engine.reduce(rows, own_boxes, phi_scale=phi_scale, drop_any_time=not per_step_boxes, merge_dropmask=merge_dropmask, out=out)
     if stats is not None:
         stats.update(bytes_moved=moved, host_staging_seconds=host_s, chunks=n_chunks, chunk_steps=chunk_steps, storage=str(out_dtype).replace("torch.", ""),
                      decode={keys[r]: str(d) for r, d in decode.items()}, box=tuple(int(x) for x in boxes[0]), domain=(nt, nl, ny, nx))

@@ -40,6 +40,108 @@ def halo_range(t0: int, t1: int, n_steps: int) -> Tuple[int, int]:
     return max(t0 - 1, 0), min(t1 + 1, n_steps)
 
 
+class ShardContext:
+    """This process's place in a time-sharded run of the drop-in CLI / frameworks (one process per GPU): which steps of an
+    n-step series it computes (``ranges``), on which device, and how the ranks talk (backend "nccl" = RCCL; "gloo" for
+    rehearsals of the N > 1 path on one GPU).  ``args.shard`` carries it through the reference's call signatures."""
+
+    def __init__(self, world: int, rank: int, device, backend: str, group=None):
+        self.world, self.rank, self.device, self.backend, self.group = int(world), int(rank), torch.device(device), backend, group
+
+    @property
+    def root(self) -> bool:
+        return self.rank == 0
+
+    def ranges(self, n_steps: int) -> Tuple[int, int, int, int]:
+        """(t0, t1, h0, h1): the rank's own steps [t0, t1) and the steps it must hold [h0, h1) (own + one-step T halo)."""
+        if n_steps < self.world:
+            raise ValueError(f"{n_steps} time steps cannot be sharded over {self.world} ranks: use at most one rank per time step")
+        t0, t1 = shard_range(n_steps, self.world, self.rank)
+        return (t0, t1) + halo_range(t0, t1, n_steps)
+
+    def merge_dropmask(self, mask: torch.Tensor) -> None:
+        merge_dropmask(mask, self.group)
+
+    def gather_rows(self, local: torch.Tensor, n_steps: int) -> Optional[torch.Tensor]:
+        """[T_local, n] rows of every rank -> [n_steps, n] on rank 0 (None elsewhere): one gather."""
+        g = SeriesGatherer(n_steps, local.shape[1], local.device, group=self.group, dst=0, slots=1, dtype=local.dtype, force=True)
+        g.send(0).copy_(local)
+        g.start(0)
+        out = g.finish(0)
+        return None if out is None else out.clone()
+
+    def barrier(self) -> None:
+        if self.backend == "nccl":
+            dist.barrier(group=self.group, device_ids=[self.device.index])
+        else:
+            dist.barrier(group=self.group)
+
+
+def shard_from_env() -> Optional[ShardContext]:
+    """The shard context of a process started by ``python -m torch.distributed.run`` (or by ``lorenzcycletoolkit.py --gpus N``):
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment, one GPU per rank (LOCAL_RANK), process group over
+    LEC_DIST_BACKEND (default "nccl" = RCCL).  None when WORLD_SIZE is absent or 1: the ordinary one-process run."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return None
+    rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("LEC_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise RuntimeError("lorenzcycletoolkit_amd needs an AMD GPU (PyTorch-ROCm): there is no CPU path")
+    if backend == "nccl" and world > ndev:
+        raise RuntimeError(f"{world} ranks but {ndev} GPU(s): RCCL needs one GPU per rank")
+    device = torch.device("cuda", local % ndev)
+    torch.cuda.set_device(device)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if not dist.is_initialized():
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return ShardContext(world, rank, device, backend)
+
+
+def launch_local_ranks(script: str, argv, n: int) -> int:
+    """Starts ``n`` rank processes of ``script`` on this node (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous on
+    127.0.0.1) and returns the job's exit code.  Nothing here initialises a GPU (``torch.cuda.device_count()`` does not), so the
+    children are ordinary child processes of a GPU-free parent."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    backend = os.environ.get("LEC_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and ndev < n:
+        print(f"--gpus {n} asked but this node shows {ndev} GPU(s); one rank per GPU is required", file=sys.stderr)
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(script)] + list(argv), env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for pr in list(pending):
+                code = pr.poll()
+                if code is None:
+                    continue
+                pending.remove(pr)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for other in pending:        # one rank failed: the others would wait in a collective for ever
+                        other.terminate()
+            time.sleep(0.05)
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    return rc
+
+
 def _dist_on(group=None) -> bool:
     return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
 

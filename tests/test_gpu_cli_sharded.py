@@ -1,0 +1,148 @@
+"""The time shard behind the drop-in command line (SURVEY 8e / VERDICT r2 row e'): ``lorenzcycletoolkit.py ... --gpus N`` and
+``python -m torch.distributed.run --nproc-per-node N lorenzcycletoolkit.py ...`` shard the time steps over N rank processes, gather
+the per-step results on rank 0 and must write the SAME BYTES as the one-process run -- every results CSV, every per-level table and
+the trackfile.  On this box the ranks share the one GPU and rendezvous over gloo (LEC_DIST_BACKEND=gloo); RCCL needs a GPU per rank
+(the nccl variant below runs where there are at least two)."""
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import pandas as pd
+import pytest
+
+torch = pytest.importorskip("torch")
+
+pytestmark = pytest.mark.gpu
+
+from tests.helpers import write_packed_era5_style
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "lorenzcycletoolkit.py")
+
+
+@pytest.fixture
+def workdir(tmp_path, golden_dir, monkeypatch):
+    os.makedirs(tmp_path / "inputs")
+    shutil.copy(os.path.join(golden_dir, "inputs", "namelist_NCEP-R2"), tmp_path / "inputs" / "namelist")
+    monkeypatch.chdir(tmp_path)
+    return tmp_path
+
+
+def _run(argv, backend="gloo", launcher=None, timeout=600):
+    env = dict(os.environ, LEC_DIST_BACKEND=backend)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, CLI] + argv if launcher is None else launcher + [CLI] + argv
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    return r
+
+
+def _tree(d):
+    """{relative path: bytes} of every result file (the log carries time stamps and the command line)."""
+    out = {}
+    for base, _, files in os.walk(d):
+        for f in files:
+            if not f.startswith("log."):
+                p = os.path.join(base, f)
+                out[os.path.relpath(p, d)] = open(p, "rb").read()
+    return out
+
+
+def _same_tree(one, many, what):
+    assert sorted(one) == sorted(many), what
+    for k in one:
+        assert one[k] == many[k], f"{what}: {k} differs from the one-process run"
+
+
+def _fresh(results):
+    if os.path.isdir(results):
+        shutil.rmtree(results)
+
+
+@pytest.mark.parametrize("ingest", [[], ["--device-ingest"]])
+def test_fixed_framework_sharded_writes_identical_files(workdir, golden_dir, ingest):
+    (workdir / "inputs" / "box_limits").write_text("min_lon;-55\nmax_lon;-36\nmin_lat;-35\nmax_lat;-20\n")
+    infile = os.path.join(golden_dir, "Catarina_NCEP-R2.nc")
+    results = workdir / "LEC_Results" / "Catarina_NCEP-R2_fixed"
+    _run([infile, "-r", "-f"] + ingest)
+    one = _tree(results)
+    assert len(one) == 22 and "Catarina_NCEP-R2_fixed_results.csv" in one        # results + 21 per-level tables
+    for n in (2, 3):
+        _fresh(results)
+        r = _run([infile, "-r", "-f", "--gpus", str(n)] + ingest)
+        _same_tree(one, _tree(results), f"-f {ingest} on {n} ranks")
+        assert f"Time-sharded run: {n} ranks" in open(results / "log.Catarina_NCEP-R2").read()
+
+
+@pytest.mark.parametrize("ingest", [[], ["--device-ingest"]])
+def test_moving_framework_sharded_writes_identical_files(workdir, golden_dir, ingest):
+    shutil.copy(os.path.join(golden_dir, "inputs", "track_testdata_NCEP-R2"), workdir / "inputs" / "track")
+    infile = os.path.join(golden_dir, "testdata_NCEP-R2.nc")
+    results = workdir / "LEC_Results" / "testdata_NCEP-R2_track"
+    _run([infile, "-r", "-t"] + ingest)
+    one = _tree(results)
+    assert "testdata_NCEP-R2_track_results.csv" in one and "testdata_NCEP-R2_track_trackfile" in one
+    for n in (2, 3):
+        _fresh(results)
+        _run([infile, "-r", "-t", "--gpus", str(n)] + ingest)
+        _same_tree(one, _tree(results), f"-t {ingest} on {n} ranks")
+
+
+@pytest.mark.parametrize("ingest", [[], ["--device-ingest"]])
+def test_nan_levels_are_dropped_across_shards(workdir, ingest):
+    """An int16-packed file whose fill values make the TOP kept level NaN at ONE time step (step 2) and one interior point NaN at
+    another: the reference's dropna(dim=level) on the [time, level] arrays drops that level for EVERY time step, so the rank that
+    holds step 2 must tell the others (the [28, L] mask all_reduce); bytes equal to the one-process run, on 2 and 3 ranks."""
+    path = str(workdir / "packed.nc")
+    write_packed_era5_style(path)
+    (workdir / "inputs" / "namelist").write_text(
+        ";Variable;Units\nAir Temperature;t;K\nGeopotential;z;m**2/s**2\nOmega Velocity;w;Pa/s\n"
+        "Eastward Wind Component;u;m/s\nNorthward Wind Component;v;m/s\nLongitude;longitude\nLatitude;latitude\n"
+        "Time;time\nVertical Level;level\n")
+    (workdir / "inputs" / "box_limits").write_text("min_lon;-60\nmax_lon;20\nmin_lat;-45\nmax_lat;30\n")
+    results = workdir / "LEC_Results" / "packed_fixed"
+    _run([path, "-r", "-f"] + ingest)
+    one = _tree(results)
+    df = pd.read_csv(results / "packed_fixed_results.csv", index_col=0)
+    assert len(df) == 7 and np.isfinite(df[["Az", "Ae", "Kz", "Ke"]].values).all()
+    assert "NaN level values" in open(results / "log.packed").read()
+    for n in (2, 3):
+        _fresh(results)
+        _run([path, "-r", "-f", "--gpus", str(n)] + ingest)
+        _same_tree(one, _tree(results), f"NaN sample {ingest} on {n} ranks")
+
+
+def test_under_the_torch_launcher(workdir, golden_dir):
+    """python -m torch.distributed.run --nproc-per-node 2 lorenzcycletoolkit.py ...: the launcher's environment names the ranks."""
+    (workdir / "inputs" / "box_limits").write_text("min_lon;-55\nmax_lon;-36\nmin_lat;-35\nmax_lat;-20\n")
+    infile = os.path.join(golden_dir, "Catarina_NCEP-R2.nc")
+    results = workdir / "LEC_Results" / "Catarina_NCEP-R2_fixed"
+    _run([infile, "-r", "-f", "-o", "one"])
+    one = open(results / "one.csv", "rb").read()
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", "29731"]
+    _run([infile, "-r", "-f", "-o", "two"], launcher=launcher)
+    assert open(results / "two.csv", "rb").read() == one
+
+
+def test_more_ranks_than_time_steps_is_refused(workdir, golden_dir):
+    (workdir / "inputs" / "track").write_text("time;Lat;Lon\n2005-08-08-0000;-22.5;-45\n2005-08-08-0600;-22.5;-45\n")      # two time steps
+    env = dict(os.environ, LEC_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, CLI, os.path.join(golden_dir, "testdata_NCEP-R2.nc"), "-r", "-t", "--gpus", "3"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0 and "cannot be sharded over 3 ranks" in r.stderr
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank: runs on a node with >= 2 GPUs")
+def test_sharded_over_rccl(workdir, golden_dir):
+    (workdir / "inputs" / "box_limits").write_text("min_lon;-55\nmax_lon;-36\nmin_lat;-35\nmax_lat;-20\n")
+    infile = os.path.join(golden_dir, "Catarina_NCEP-R2.nc")
+    results = workdir / "LEC_Results" / "Catarina_NCEP-R2_fixed"
+    _run([infile, "-r", "-f"])
+    one = _tree(results)
+    _fresh(results)
+    _run([infile, "-r", "-f", "--gpus", str(min(torch.cuda.device_count(), 4))], backend="nccl")
+    _same_tree(one, _tree(results), "RCCL")
