@@ -59,7 +59,9 @@ enum lec_dtype { LEC_F64 = 0, LEC_F32 = 1, LEC_I16 = 2 /* lec_ingest source only
 
 /* Stage-1 kernel families (lec_tuning.kernel).  Every family writes the same row records; AUTO is what is
  * measured and shipped, the others exist for cross-checks and A/B measurements.  The library reads NO
- * environment variables: everything that steers it is in the argument structs. */
+ * environment variables: everything that steers it is in the argument structs.
+ * The workgroup orders assume the MI355X's 8 XCDs (workgroups are dealt to them round-robin, so blockIdx % 8 labels the XCD); on a
+ * part with another count the results are the same and only the locality differs. */
 enum lec_kernel {
     LEC_KERNEL_AUTO = 0,       /* box tiles for per-time-step boxes, row blocks for all terms on one fixed fp64 box, else one wave per row */
     LEC_KERNEL_TWO_SWEEP = 1,  /* lec_rowstats.hip: the reference's own order (deviation from the zonal mean, then products); rows <= lec_max_row() */
@@ -223,10 +225,14 @@ typedef struct lec_ingest_args {
  *   lec_moving_framework.py:650-663  wind_speed(u, v), vorticity(u, v) on the whole 850-hPa slice
  *   lec_moving_framework.py:269-417  get_position: the extrema inside the box (inclusive label slices)
  *   tools.py:95-128                  find_extremum_coordinates
- * zeta = 1 / (Re cos(phi)) dv/dlambda - 1 / Re du/dphi + u tan(phi) / Re with three-point derivatives on the (possibly uneven)
- * coordinates, second order also at the ends of the domain (the stencil of metpy.calc.first_derivative); the host supplies the
- * stencils as tables.  NaN (below-ground points) is skipped, values and positions alike; among equal values the first in
- * row-major order of the box wins (numpy's argmin / argmax).  Parity of the vorticity against MetPy itself is unpinned.
+ * zeta(j, i) = sum_k xcoef[j][i][k] v[j][i0 + k] - sum_k ycoef[j][k] u[j0 + k][i] + curv[j] u[j][i],  i0 = clamp(i - 1, 0, nx - 3),
+ * j0 = clamp(j - 1, 0, ny - 3): three-point derivatives, second order also at the ends of the slice (the stencil of
+ * metpy.calc.first_derivative).  The FORMULATION is the caller's: the coefficient tables carry the metric (1/m).  The Python host
+ * builds two (diagnostics.vorticity_tables): "metpy_no_crs" -- what MetPy 1.6.2 evaluates for DataArrays without a CRS, as the
+ * reference passes them: plain dv/dx - du/dy, distances = great-circle arcs between neighbouring grid points on pyproj's default
+ * sphere (a = 6,370,997 m), curv = 0 -- and "spherical": dx = Re cos(phi) dlambda, dy = Re dphi, curv = tan(phi) / Re.
+ * NaN (below-ground points) is skipped, values and positions alike; among equal values the first in row-major order of the box
+ * wins (numpy's argmin / argmax).  Parity of the vorticity against MetPy itself is unpinned.
  */
 typedef struct lec_diag_args {
     const double* u_d;          /* [nt][ny][nx] eastward wind at 850 hPa (m/s) */
@@ -234,8 +240,9 @@ typedef struct lec_diag_args {
     const double* hgt_d;        /* [nt][ny][nx] geopotential height (gpm) */
     int32_t nt, ny, nx, reserved0;
     const int32_t* box_d;       /* [nt][6]  iw, ie, js, jn: inclusive index ranges of the box; jc, ic: the grid point nearest its centre */
-    const double* lontab_d;     /* [nx][4]  first index of the point's three-point stencil (as a double), d/dlambda coefficients (1/rad) */
-    const double* lattab_d;     /* [ny][6]  first index of the stencil, d/dphi coefficients (1/rad), cos(phi), tan(phi) */
+    const double* xcoef_d;      /* [ny][nx][3]  d/dx coefficients of point (j, i) along its row (1/m) */
+    const double* ycoef_d;      /* [ny][3]      d/dy coefficients of row j along a column (1/m) */
+    const double* curv_d;       /* [ny]         coefficient of u (1/m): tan(phi) / Re on the sphere, 0 for the plain Cartesian form */
     double* val_d;              /* [nt][5]  zeta minimum, zeta maximum, height minimum, wind-speed maximum, zeta at (jc, ic);
                                             NaN when the box holds no finite value */
     int32_t* pos_d;             /* [nt][8]  (j, i) grid indices of the four extrema, in that order; -1 when there is none */
@@ -259,6 +266,18 @@ int lec_reduce(const lec_reduce_args* args);
 int lec_dropmask(const lec_reduce_args* args);
 
 int lec_track_diag(const lec_diag_args* args);
+
+/*
+ * What the library cannot see at launch: indices that live in DEVICE memory.  lec_rowstats validates every scalar argument, but a
+ * quadruple of box_d outside [0, nx) x [0, ny), with ie < iw + 1 / jn < js + 1, or wider / higher than nxb_max / nyb_max would be
+ * an out-of-bounds read; likewise an entry of the three ingest maps outside the source extents.  The Python host checks its boxes
+ * before it uploads them (tables.box_indices; the reference validates its box the same way, lec_fixed_framework.py:98-154); a
+ * plain-C caller calls these first.  One small kernel on args->stream scans the table(s), the call WAITS for it (the only
+ * synchronous entry points) and returns LEC_OK, or LEC_ERR_ARG with the first offending entry in lec_last_error().
+ * status_d: caller-owned device scratch of 4 int32.
+ */
+int lec_check_boxes(const lec_rowstats_args* args, int32_t* status_d);
+int lec_check_maps(const lec_ingest_args* args, int32_t* status_d);
 
 #ifdef __cplusplus
 }

@@ -46,6 +46,8 @@ def create_arg_parser():
     parser.add_argument("--box_limits", type=str, default="inputs/box_limits", help="box-limits file for -f (default: inputs/box_limits)")
     parser.add_argument("--device-ingest", action="store_true", help="stream the file's bytes to the GPU in chunks and decode / sort / crop them "
                         "there, instead of preparing the whole data set on the host (same results, bit for bit)")
+    parser.add_argument("--vorticity-form", choices=["metpy_no_crs", "spherical"], default="metpy_no_crs", help="with -t: formulation of the 850-hPa "
+                        "relative vorticity in the trackfile (default: what MetPy 1.6.2 evaluates for data without a CRS, as the reference passes them)")
     parser.add_argument("--gpus", type=int, default=1, help="shard the time steps over this many GPUs of the node (one process per GPU, "
                         "results gathered over RCCL; same output files).  Under torch.distributed.run the launcher's WORLD_SIZE counts")
     parser.add_argument("-o", "--outname", type=str, help="name of the results CSV (fixed framework)")

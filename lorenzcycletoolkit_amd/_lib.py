@@ -22,7 +22,8 @@ LEC_F64, LEC_F32, LEC_I16 = 0, 1, 2
 KERNEL_AUTO, KERNEL_TWO_SWEEP, KERNEL_ROW_SWEEP, KERNEL_ROW_BLOCK, KERNEL_BOX_TILE = 0, 1, 2, 3, 4
 ORDER_AUTO, ORDER_MEMORY, ORDER_XCD_LAT, ORDER_XCD_TILED = 0, 1, 2, 7
 
-EXPORTS = ["lec_version", "lec_last_error", "lec_max_row", "lec_rowstats", "lec_reduce", "lec_dropmask", "lec_ingest", "lec_track_diag"]
+EXPORTS = ["lec_version", "lec_last_error", "lec_max_row", "lec_rowstats", "lec_reduce", "lec_dropmask", "lec_ingest", "lec_track_diag",
+           "lec_check_boxes", "lec_check_maps"]
 
 
 class Tuning(C.Structure):
@@ -86,7 +87,7 @@ class DiagArgs(C.Structure):
     """struct lec_diag_args (include/lec_hip.h)."""
     _fields_ = [("u_d", C.c_void_p), ("v_d", C.c_void_p), ("hgt_d", C.c_void_p),
                 ("nt", C.c_int32), ("ny", C.c_int32), ("nx", C.c_int32), ("reserved0", C.c_int32),
-                ("box_d", C.c_void_p), ("lontab_d", C.c_void_p), ("lattab_d", C.c_void_p),
+                ("box_d", C.c_void_p), ("xcoef_d", C.c_void_p), ("ycoef_d", C.c_void_p), ("curv_d", C.c_void_p),
                 ("val_d", C.c_void_p), ("pos_d", C.c_void_p), ("stream", C.c_void_p)]
 
 
@@ -122,6 +123,10 @@ def load():
     lib.lec_ingest.argtypes = [C.POINTER(IngestArgs)]
     lib.lec_track_diag.restype = C.c_int
     lib.lec_track_diag.argtypes = [C.POINTER(DiagArgs)]
+    lib.lec_check_boxes.restype = C.c_int
+    lib.lec_check_boxes.argtypes = [C.POINTER(RowstatsArgs), C.c_void_p]
+    lib.lec_check_maps.restype = C.c_int
+    lib.lec_check_maps.argtypes = [C.POINTER(IngestArgs), C.c_void_p]
     if lib.lec_version() != LEC_ABI_VERSION:
         raise LecLibraryError(f"liblec_hip.so ABI {lib.lec_version()} != expected {LEC_ABI_VERSION}")
     _lib = lib

@@ -12,15 +12,15 @@
 
 namespace {
 
-constexpr double kRe = LEC_RE;
 constexpr int kThreads = 256;
 
 struct DiagParams {
     const double* u; const double* v; const double* h;
     int nt, ny, nx;
     const int* box;
-    const double* lontab;
-    const double* lattab;
+    const double* xcoef;    // [ny][nx][3]
+    const double* ycoef;    // [ny][3]
+    const double* curv;     // [ny]
     double* val;
     int* pos;
 };
@@ -32,16 +32,18 @@ struct Best {
     __device__ __forceinline__ void take_max(double x, int m) { if (x > v || (x == v && m < n)) { v = x; n = m; } }
 };
 
+// zeta = dv/dx - du/dy + curv u with the three-point stencils of metpy.calc.first_derivative: the parabola through the point and its
+// two neighbours (the three points nearest the edge at either end of the slice), coefficients in 1/m from the host's tables -- which
+// metric the distances follow (and whether the sphere's curvature term is there) is the caller's choice, not the kernel's
 __device__ __forceinline__ double zeta_at(const DiagParams& p, const double* u, const double* v, int j, int i) {
-    const double* lo = p.lontab + 4 * (size_t)i;
-    const double* la = p.lattab + 6 * (size_t)j;
-    const int i0 = min(max((int)lo[0], 0), p.nx - 3), j0 = min(max((int)la[0], 0), p.ny - 3);     // tables come from device memory: never index past the slice
+    const int i0 = min(max(i - 1, 0), p.nx - 3), j0 = min(max(j - 1, 0), p.ny - 3);
+    const double* cx = p.xcoef + 3 * ((size_t)j * p.nx + i);
+    const double* cy = p.ycoef + 3 * (size_t)j;
     const double* vr = v + (size_t)j * p.nx + i0;
-    const double dv = lo[1] * vr[0] + lo[2] * vr[1] + lo[3] * vr[2];
+    const double dv = cx[0] * vr[0] + cx[1] * vr[1] + cx[2] * vr[2];
     const double* uc = u + (size_t)j0 * p.nx + i;
-    const double du = la[1] * uc[0] + la[2] * uc[p.nx] + la[3] * uc[2 * (size_t)p.nx];
-    const double uu = u[(size_t)j * p.nx + i];
-    return dv / (kRe * la[4]) - du / kRe + (uu / kRe) * la[5];
+    const double du = cy[0] * uc[0] + cy[1] * uc[p.nx] + cy[2] * uc[2 * (size_t)p.nx];
+    return dv - du + p.curv[j] * u[(size_t)j * p.nx + i];
 }
 
 // grid nt, block kThreads
@@ -100,14 +102,14 @@ __global__ void __launch_bounds__(kThreads) lec_diag_kernel(const DiagParams p) 
 
 extern "C" int lec_track_diag(const lec_diag_args* a) {
     if (!a) return lec_set_error(LEC_ERR_ARG, "lec_track_diag: null args");
-    if (!a->u_d || !a->v_d || !a->hgt_d || !a->box_d || !a->lontab_d || !a->lattab_d || !a->val_d || !a->pos_d)
+    if (!a->u_d || !a->v_d || !a->hgt_d || !a->box_d || !a->xcoef_d || !a->ycoef_d || !a->curv_d || !a->val_d || !a->pos_d)
         return lec_set_error(LEC_ERR_ARG, "lec_track_diag: null pointer argument");
     if (a->nt < 1 || a->ny < 3 || a->nx < 3) return lec_set_error(LEC_ERR_ARG, "lec_track_diag: needs nt >= 1 and at least 3 x 3 grid points");
     if (a->reserved0 != 0) return lec_set_error(LEC_ERR_ARG, "lec_track_diag: reserved0 must be 0");
     if ((unsigned long long)a->ny * (unsigned long long)a->nx > 0x7fffffffULL) return lec_set_error(LEC_ERR_UNSUPPORTED, "lec_track_diag: slice too large");
     DiagParams p;
     p.u = a->u_d; p.v = a->v_d; p.h = a->hgt_d; p.nt = a->nt; p.ny = a->ny; p.nx = a->nx;
-    p.box = a->box_d; p.lontab = a->lontab_d; p.lattab = a->lattab_d; p.val = a->val_d; p.pos = a->pos_d;
+    p.box = a->box_d; p.xcoef = a->xcoef_d; p.ycoef = a->ycoef_d; p.curv = a->curv_d; p.val = a->val_d; p.pos = a->pos_d;
     hipStream_t st = (hipStream_t)a->stream;
     hipLaunchKernelGGL(lec_diag_kernel, dim3(a->nt), dim3(kThreads), 0, st, p);
     const hipError_t e = hipGetLastError();

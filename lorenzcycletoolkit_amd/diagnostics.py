@@ -10,17 +10,22 @@ precedence rules (``positions``).  There is no host evaluation of the fields.
 Parity UNPINNED against MetPy: the reference calls MetPy's ``vorticity`` / ``wind_speed`` and its only
 sample trackfile has these columns empty; the kernel is checked against an independent restatement (oracle/track_diagnostics.py,
 tests/test_gpu_diagnostics.py), the box / extremum logic against the reference's own get_position.  One deliberate difference:
-extremum POSITIONS skip NaN like the values do (the reference's argmin / argmax land on a NaN cell).  Vorticity is the spherical
-form zeta = dv/dx - du/dy + (u/Re) tan(phi) with dx = Re cos(phi) d(lambda), dy = Re d(phi) and MetPy-style three-point
-derivatives (second order, also at the edges); MetPy's default geodesic uses the WGS84 ellipsoid, so values can differ by a few
-1e-3 relative.
+extremum POSITIONS skip NaN like the values do (the reference's argmin / argmax land on a NaN cell; INTEGRATION.md lists it).
 
-What a maintainer with MetPy 1.6.2 at hand should check first: the reference opens its files with plain ``xr.open_dataset`` (no
-``parse_cf`` / ``assign_crs`` anywhere in it), and MetPy's ``parse_grid_arguments`` falls back to the plain Cartesian
-``dv/dx - du/dy`` on geodesic grid distances when a DataArray carries no CRS -- i.e. WITHOUT the curvature term u tan(phi) / Re that the
-spherical form here (and MetPy's own map-factor path for data WITH a CRS) includes.  If that is what the reference's runs do, their zeta
-differs from this module's by that term (about 1 % of a cyclone's extremum at 30 degrees latitude, more poleward); the positions of the
-extrema and the two other columns (height minimum, wind maximum) are unaffected.
+The vorticity FORMULATION is an argument (``vorticity_tables``; the kernel only applies three-point stencils whose coefficients
+carry the metric), because what the reference's runs evaluate cannot be executed here:
+
+* ``"metpy_no_crs"`` (the default): the reference opens its files with plain ``xr.open_dataset`` (no ``parse_cf`` /
+  ``assign_crs`` anywhere in it) and hands MetPy 1.6.2 DataArrays WITHOUT a CRS (lec_moving_framework.py:660-663).  MetPy's
+  ``parse_grid_arguments`` then falls back to the plain Cartesian ``dv/dx - du/dy`` ("basic cartesian calculation if we don't have
+  a CRS"): no map factors, no curvature term, grid distances from ``lat_lon_grid_deltas`` = geodesic arcs between neighbouring
+  grid points on pyproj's default sphere (a = 6,370,997 m), three-point ``first_derivative`` on those distances.
+* ``"spherical"``: zeta = dv/dx - du/dy + (u / Re) tan(phi) with dx = Re cos(phi) d(lambda), dy = Re d(phi) -- what MetPy's
+  map-factor path gives for data WITH a CRS, and the textbook form.  The two differ by the curvature term (about 1 % of a
+  cyclone's extremum at 30 degrees latitude, more poleward), by 1.2e-6 in the radius and by the chord-versus-parallel arc
+  (a few 1e-6 at 0.25 degrees); positions of extrema and the two other columns (height minimum, wind maximum) are the same.
+
+The log states which one ran; ``--vorticity-form spherical`` on the command line selects the other.
 """
 from __future__ import annotations
 
@@ -55,13 +60,67 @@ def _three_point(x: np.ndarray) -> np.ndarray:
 
 
 def stencil_tables(lat_deg, lon_deg):
-    """(lontab [nx][4], lattab [ny][6]) of struct lec_diag_args: d/dlambda and d/dphi stencils in 1/rad, cos(phi), tan(phi)."""
+    """(lontab [nx][4], lattab [ny][6]): d/dlambda and d/dphi stencils in 1/rad (first index, three coefficients), cos(phi), tan(phi)."""
     phi = np.deg2rad(np.asarray(lat_deg, dtype=np.float64))
     lam = np.deg2rad(np.asarray(lon_deg, dtype=np.float64))
     lattab = np.empty((phi.size, 6))
     lattab[:, :4] = _three_point(phi)
     lattab[:, 4], lattab[:, 5] = np.cos(phi), np.tan(phi)
     return np.ascontiguousarray(_three_point(lam)), lattab
+
+
+FORMULATIONS = ("metpy_no_crs", "spherical")
+PYPROJ_SPHERE_RADIUS = 6370997.0        # pyproj's Geod(ellps="sphere"): what metpy.calc.lat_lon_grid_deltas measures with when there is no CRS
+
+
+def _three_point_rows(d: np.ndarray) -> np.ndarray:
+    """[ny][nx][3]: ``_three_point`` coefficients for every row of a [ny][nx - 1] array of spacings (metpy.calc.first_derivative with
+    ``delta=``: the point positions of a row are the running sum of its spacings)."""
+    d = np.asarray(d, dtype=np.float64)
+    ny, nx = d.shape[0], d.shape[1] + 1
+    if nx < 3:
+        raise ValueError("three-point derivatives need at least 3 points")
+    co = np.empty((ny, nx, 3))
+    d0, d1 = d[:, :-1], d[:, 1:]
+    co[:, 1:-1, 0] = -d1 / (d0 * (d0 + d1))
+    co[:, 1:-1, 1] = (d1 - d0) / (d0 * d1)
+    co[:, 1:-1, 2] = d0 / (d1 * (d0 + d1))
+    a, b = d[:, 0], d[:, 1]
+    co[:, 0, 0], co[:, 0, 1], co[:, 0, 2] = -(2 * a + b) / (a * (a + b)), (a + b) / (a * b), -a / (b * (a + b))
+    a, b = d[:, -2], d[:, -1]
+    co[:, -1, 0], co[:, -1, 1], co[:, -1, 2] = b / (a * (a + b)), -(a + b) / (a * b), (a + 2 * b) / (b * (a + b))
+    return co
+
+
+def great_circle_arc(phi1, lam1, phi2, lam2, radius):
+    """Geodesic distance on a sphere (what pyproj's Geod.inv returns for an ellipsoid with a = b), in the numerically safe
+    atan2 form of the central angle."""
+    dl = lam2 - lam1
+    y = np.hypot(np.cos(phi2) * np.sin(dl), np.cos(phi1) * np.sin(phi2) - np.sin(phi1) * np.cos(phi2) * np.cos(dl))
+    x = np.sin(phi1) * np.sin(phi2) + np.cos(phi1) * np.cos(phi2) * np.cos(dl)
+    return radius * np.arctan2(y, x)
+
+
+def vorticity_tables(lat_deg, lon_deg, formulation: str = "metpy_no_crs"):
+    """(xcoef [ny][nx][3], ycoef [ny][3], curv [ny]) of struct lec_diag_args for one of FORMULATIONS (module docstring)."""
+    if formulation not in FORMULATIONS:
+        raise ValueError(f"vorticity formulation must be one of {FORMULATIONS}, not {formulation!r}")
+    phi = np.deg2rad(np.asarray(lat_deg, dtype=np.float64))
+    lam = np.deg2rad(np.asarray(lon_deg, dtype=np.float64))
+    ny, nx = phi.size, lam.size
+    if formulation == "spherical":
+        from .constants import RE
+        xc = _three_point(lam)[None, :, 1:] / (RE * np.cos(phi))[:, None, None]
+        yc = _three_point(phi)[:, 1:] / RE
+        curv = np.tan(phi) / RE
+    else:
+        a = PYPROJ_SPHERE_RADIUS
+        dx = great_circle_arc(phi[:, None], lam[None, :-1], phi[:, None], lam[None, 1:], a)        # [ny][nx - 1], along each row
+        xc = _three_point_rows(dx)
+        dy = great_circle_arc(phi[:-1], 0.0, phi[1:], 0.0, a)                                         # [ny - 1]: the same for every column
+        yc = _three_point_rows(dy[None, :])[0]
+        curv = np.zeros(ny)
+    return np.ascontiguousarray(xc), np.ascontiguousarray(yc), np.ascontiguousarray(curv)
 
 
 def box_ranges(lat_deg, lon_deg, limits) -> tuple:
@@ -77,7 +136,7 @@ def box_ranges(lat_deg, lon_deg, limits) -> tuple:
     return int(ii[0]), int(ii[-1]), int(jj[0]), int(jj[-1]), jc, ic
 
 
-def device_extrema(u850, v850, hgt850, lat_deg, lon_deg, limits_per_step, device="cuda:0"):
+def device_extrema(u850, v850, hgt850, lat_deg, lon_deg, limits_per_step, device="cuda:0", formulation="metpy_no_crs"):
     """``lec_track_diag`` on [time, lat, lon] slices (host arrays or device tensors): returns (val [nt][5], pos [nt][8]) as NumPy
     arrays -- zeta minimum, zeta maximum, height minimum, wind maximum, zeta at the box centre; (j, i) of the four extrema."""
     import torch
@@ -92,14 +151,15 @@ def device_extrema(u850, v850, hgt850, lat_deg, lon_deg, limits_per_step, device
     nt, ny, nx = (int(x) for x in u.shape)
     if (ny, nx) != (np.asarray(lat_deg).size, np.asarray(lon_deg).size) or len(limits_per_step) != nt:
         raise ValueError("slices, coordinates and boxes do not match")
-    lontab, lattab = stencil_tables(lat_deg, lon_deg)
+    xcoef, ycoef, curv = vorticity_tables(lat_deg, lon_deg, formulation)
     box = np.array([box_ranges(lat_deg, lon_deg, lim) for lim in limits_per_step], dtype=np.int32).reshape(nt, 6)
-    box_d, lon_d, lat_d = torch.as_tensor(box).to(dev), torch.as_tensor(lontab).to(dev), torch.as_tensor(lattab).to(dev)
+    box_d, xc_d, yc_d, cv_d = torch.as_tensor(box).to(dev), torch.as_tensor(xcoef).to(dev), torch.as_tensor(ycoef).to(dev), torch.as_tensor(curv).to(dev)
     val = torch.empty((nt, 5), dtype=torch.float64, device=dev)
     pos = torch.empty((nt, 8), dtype=torch.int32, device=dev)
     ptr = lambda t: C.c_void_p(t.data_ptr())
-    args = _lib.DiagArgs(u_d=ptr(u), v_d=ptr(v), hgt_d=ptr(h), nt=nt, ny=ny, nx=nx, reserved0=0, box_d=ptr(box_d), lontab_d=ptr(lon_d),
-                         lattab_d=ptr(lat_d), val_d=ptr(val), pos_d=ptr(pos), stream=C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    args = _lib.DiagArgs(u_d=ptr(u), v_d=ptr(v), hgt_d=ptr(h), nt=nt, ny=ny, nx=nx, reserved0=0, box_d=ptr(box_d), xcoef_d=ptr(xc_d),
+                         ycoef_d=ptr(yc_d), curv_d=ptr(cv_d), val_d=ptr(val), pos_d=ptr(pos),
+                         stream=C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
     with torch.cuda.device(dev):
         _lib.check(lib.lec_track_diag(C.byref(args)), "lec_track_diag")
     return val.cpu().numpy(), pos.cpu().numpy()
@@ -140,7 +200,8 @@ _POSITION_KEYS = ["min_max_zeta_850_lat", "min_max_zeta_850_lon", "min_max_zeta_
                   "max_wind_850_lat", "max_wind_850_lon", "max_wind_850"]
 
 
-def track_diagnostics(data, variable_list_df, limits_per_step, track=None, use_track_zeta=False, device="cuda:0", shard=None):
+def track_diagnostics(data, variable_list_df, limits_per_step, track=None, use_track_zeta=False, device="cuda:0", shard=None,
+                      formulation="metpy_no_crs"):
     """All time steps: u, v, geopotential height at 85000 Pa -> list of position dicts.  ``shard`` (parallel.ShardContext): every
     rank evaluates its own time steps (each is independent), one gather of nine numbers per step brings them to rank 0; the other
     ranks get None."""
@@ -159,7 +220,7 @@ def track_diagnostics(data, variable_list_df, limits_per_step, track=None, use_t
         hgt = get("Geopotential Height").astype(np.float64)
     else:
         hgt = get("Geopotential").astype(np.float64) / G       # -> gpm
-    val, pos = device_extrema(u, v, hgt, data.lat, data.lon, limits_per_step[t0:t1], device=device)
+    val, pos = device_extrema(u, v, hgt, data.lat, data.lon, limits_per_step[t0:t1], device=device, formulation=formulation)
     out = []
     for t in range(t0, t1):
         row = None

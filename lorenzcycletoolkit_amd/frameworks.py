@@ -336,8 +336,9 @@ def lec_moving(data: ds.LECDataset, variable_list_df: pd.DataFrame, dTdt, result
                       boxes_limits=boxes)
     # 850-hPa diagnostics of every box (lec_moving_framework.py:650-709); a time-sharded rank does its own steps, rank 0 gets them all
     from .diagnostics import track_diagnostics
+    form = getattr(args, "vorticity_form", None) or "metpy_no_crs"
     positions = track_diagnostics(data, variable_list_df, limits, track, use_track_zeta=bool(getattr(args, "zeta", False)),
-                                  device=_device(args), shard=shard)
+                                  device=_device(args), shard=shard, formulation=form)
     if box_obj.result is None:              # time-sharded run: rank 0 holds the gathered series and writes every file
         return None
     terms = _compute_all(box_obj, "moving", app_logger)
@@ -353,8 +354,10 @@ def lec_moving(data: ds.LECDataset, variable_list_df: pd.DataFrame, dTdt, result
     df.to_csv(results_file)
     app_logger.info(f"Results saved to {results_file}")
     # 850-hPa diagnostics of every box (lec_moving_framework.py:650-709); parity unpinned, see diagnostics.py
-    app_logger.info("850 hPa track diagnostics (min_max_zeta_850, min_hgt_850, max_wind_850): spherical three-point vorticity on the "
-                    "GPU (lec_track_diag); NOT pinned against MetPy 1.6.2's vorticity (geodesic grid distances), expect agreement to a few 1e-3 relative")
+    app_logger.info(f"850 hPa track diagnostics (min_max_zeta_850, min_hgt_850, max_wind_850) on the GPU (lec_track_diag), vorticity formulation "
+                    f"'{form}' (" + ("plain dv/dx - du/dy on great-circle grid distances, a = 6370997 m: MetPy 1.6.2 for DataArrays without a CRS, as the "
+                                     "reference passes them" if form == "metpy_no_crs" else "spherical: dv/dx - du/dy + u tan(phi) / Re") +
+                    "); NOT pinned against MetPy itself (--vorticity-form selects the other formulation)")
     out_track = pd.DataFrame([{**l, **p} for l, p in zip(limits, positions)])
     out_track = out_track.rename(columns={"datestr": "time", "central_lat": "Lat", "central_lon": "Lon"})
     out_track.to_csv(os.path.join(results_subdirectory, f"{infile_name}_{method}_trackfile"), index=False, sep=";")

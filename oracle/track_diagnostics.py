@@ -11,11 +11,13 @@ Restates, independently of lorenzcycletoolkit_amd/diagnostics.py:
 * the two MetPy 1.6.2 calls that feed it (``lec_moving_framework.py:660-663``): ``wind_speed`` = sqrt(u^2 + v^2) and
   ``vorticity`` on a latitude / longitude grid.  MetPy is a third-party dependency that is neither vendored in /root/reference
   nor installed here, so its published algorithm is restated: three-point finite differences on unequally spaced
-  coordinates, second order also at the ends (``metpy.calc.first_derivative``), applied to the spherical form
-      zeta = 1 / (a cos(phi)) dv/dlambda - 1 / a du/dphi + u tan(phi) / a
-  (what MetPy >= 1.5 evaluates on lat/lon grids through its parallel / meridional scale factors).  MetPy measures grid
-  distances with a pyproj geodesic whose ellipsoid depends on the data's CRS attribute; on a sphere of radius a the
-  expression above is exact.  **Parity unpinned** for these three columns: the reference's only sample trackfile has them
+  points, second order also at the ends (``metpy.calc.first_derivative``), in the two forms MetPy >= 1.5 has:
+    - ``vorticity_no_crs``: DataArrays WITHOUT a CRS (what the reference passes: plain xr.open_dataset): plain
+      dv/dx - du/dy, the spacings from ``lat_lon_grid_deltas`` = geodesic arcs between neighbouring grid points on
+      pyproj's default sphere (a = 6,370,997 m) -- evaluated here point by point, row by row;
+    - ``vorticity_sphere``: data WITH a CRS, through the parallel / meridional scale factors:
+      zeta = 1 / (a cos(phi)) dv/dlambda - 1 / a du/dphi + u tan(phi) / a.
+  **Parity unpinned** for these three columns: the reference's only sample trackfile has them
   empty (tests/golden/Reg1_track/*_trackfile) and MetPy cannot be run here.
 """
 from __future__ import annotations
@@ -58,6 +60,26 @@ def vorticity_sphere(u, v, lat_deg, lon_deg, radius=RE):
     du_dphi = first_derivative_3pt(u, phi, -2)
     c, t = np.cos(phi)[:, None], np.tan(phi)[:, None]
     return dv_dlam / (radius * c) - du_dphi / radius + u * t / radius
+
+
+def vorticity_no_crs(u, v, lat_deg, lon_deg, radius=6370997.0):
+    """Plain dv/dx - du/dy of [..., lat, lon] fields with MetPy's grid distances for data without a CRS: dx[j][i] = the great-circle
+    arc from (lon_i, lat_j) to (lon_i+1, lat_j), dy[j] = the arc from lat_j to lat_j+1 along a meridian (sphere of pyproj's default
+    radius), and first_derivative on the running sums of those spacings, one row / one column at a time."""
+    phi, lam = np.deg2rad(np.asarray(lat_deg, dtype=np.float64)), np.deg2rad(np.asarray(lon_deg, dtype=np.float64))
+    u, v = np.asarray(u, dtype=np.float64), np.asarray(v, dtype=np.float64)
+
+    def arc(p1, l1, p2, l2):       # central angle by the haversine formula (an independent form of the product's atan2 one)
+        h = np.sin((p2 - p1) / 2) ** 2 + np.cos(p1) * np.cos(p2) * np.sin((l2 - l1) / 2) ** 2
+        return 2 * radius * np.arcsin(np.sqrt(h))
+
+    dvdx = np.empty_like(v)
+    for j in range(phi.size):
+        x = np.concatenate([[0.0], np.cumsum([arc(phi[j], lam[i], phi[j], lam[i + 1]) for i in range(lam.size - 1)])])
+        dvdx[..., j, :] = first_derivative_3pt(v[..., j, :], x, -1)
+    y = np.concatenate([[0.0], np.cumsum([arc(phi[j], 0.0, phi[j + 1], 0.0) for j in range(phi.size - 1)])])
+    dudy = first_derivative_3pt(u, y, -2)
+    return dvdx - dudy
 
 
 def wind_speed(u, v):

@@ -69,6 +69,37 @@ int main(int argc, char** argv) {
     ra.rows_d = rows;
     ra.stream = NULL;                                  /* the default stream */
     ra.tuning.kernel = LEC_KERNEL_AUTO;                /* all-zero tuning = the library's defaults; nothing is read from the environment */
+
+    /* box_d lives in device memory: the library cannot see it when it validates the arguments, so a C caller that fills the
+     * table itself asks for the scan first (the Python host checks its boxes before uploading them) */
+    int32_t* status;
+    CHECK_HIP(hipMalloc((void**)&status, 4 * sizeof(int32_t)));
+    if (lec_check_boxes(&ra, status) != LEC_OK) { fprintf(stderr, "lec_check_boxes: %s\n", lec_last_error()); return 10; }
+    {   /* ... and a table with a box beyond the grid (and one that is too wide for nxb_max) is refused, naming the first */
+        lec_rowstats_args chk = ra;
+        int32_t three[12] = {0, 1, 0, 1,   0, nx, 0, 1,   0, nxb, 0, 1};        /* ok | ie == nx: outside | nxb + 1 columns: wider than nxb_max */
+        int32_t* three_d;
+        CHECK_HIP(hipMalloc((void**)&three_d, sizeof three));
+        CHECK_HIP(hipMemcpy(three_d, three, sizeof three, hipMemcpyHostToDevice));
+        chk.box_d = three_d; chk.n_box = 3;
+        if (lec_check_boxes(&chk, status) != LEC_ERR_ARG || strstr(lec_last_error(), "first: box 1") == NULL || strstr(lec_last_error(), "2 of 3") == NULL) {
+            fprintf(stderr, "lec_check_boxes missed a bad box: %s\n", lec_last_error()); return 11;
+        }
+        lec_ingest_args ga;
+        memset(&ga, 0, sizeof ga);
+        int32_t maps[6] = {0, 1, 2, 0, 5, 1};           /* kmap {0,1,2} of 3 source levels: fine; jmap {0,5} of 4 source rows: jmap[1] is outside */
+        int32_t* maps_d;
+        CHECK_HIP(hipMalloc((void**)&maps_d, sizeof maps));
+        CHECK_HIP(hipMemcpy(maps_d, maps, sizeof maps, hipMemcpyHostToDevice));
+        ga.nl_in = 3; ga.ny_in = 4; ga.nx_in = 2; ga.nl = 3; ga.ny = 2; ga.nx = 1;
+        ga.kmap_d = maps_d; ga.jmap_d = maps_d + 3; ga.imap_d = maps_d + 5;
+        if (lec_check_maps(&ga, status) != LEC_ERR_ARG || strstr(lec_last_error(), "jmap_d[1]") == NULL) {
+            fprintf(stderr, "lec_check_maps missed a bad entry: %s\n", lec_last_error()); return 12;
+        }
+        maps[4] = 3;
+        CHECK_HIP(hipMemcpy(maps_d, maps, sizeof maps, hipMemcpyHostToDevice));
+        if (lec_check_maps(&ga, status) != LEC_OK) { fprintf(stderr, "lec_check_maps: %s\n", lec_last_error()); return 13; }
+    }
     if (lec_rowstats(&ra) != LEC_OK) { fprintf(stderr, "lec_rowstats: %s\n", lec_last_error()); return 6; }
 
     lec_reduce_args rd;

@@ -67,3 +67,33 @@ def test_positions_prefer_track_values_and_follow_the_hemisphere_rule():
     assert z["min_max_zeta_850"] == -1e-5                                                                                   # -z: vorticity at the box centre
     none = dg.positions(np.array([np.nan] * 5), np.full(8, -1, dtype=np.int32), lat, lon, lim)
     assert np.isnan(none["min_hgt_850"]) and np.isnan(none["min_hgt_850_lat"])
+
+
+def test_vorticity_tables_of_both_formulations():
+    """The coefficient tables handed to lec_track_diag: "spherical" = the separable stencils over Re cos(phi) / Re plus the curvature
+    coefficient; "metpy_no_crs" = first_derivative on great-circle spacings of pyproj's default sphere, no curvature.  Both reproduce
+    the oracle's point-by-point evaluation; they differ where they should (radius, chord vs parallel, curvature)."""
+    from oracle import track_diagnostics as td
+    rng = np.random.default_rng(5)
+    lat = np.sort(np.linspace(-55, -12, 19) + 0.2 * rng.standard_normal(19))
+    lon = np.sort(np.linspace(-80, -30, 27) + 0.2 * rng.standard_normal(27))
+    u, v = rng.standard_normal((19, 27)), rng.standard_normal((19, 27))
+
+    def apply(form):
+        xc, yc, cv = dg.vorticity_tables(lat, lon, form)
+        assert xc.shape == (19, 27, 3) and yc.shape == (19, 3) and cv.shape == (19,)
+        i0 = np.clip(np.arange(27) - 1, 0, 24)
+        j0 = np.clip(np.arange(19) - 1, 0, 16)
+        dv = sum(xc[:, :, k] * v[:, i0 + k] for k in range(3))
+        du = sum(yc[:, k, None] * u[j0 + k, :] for k in range(3))
+        return dv - du + cv[:, None] * u
+
+    assert np.allclose(apply("spherical"), td.vorticity_sphere(u, v, lat, lon), rtol=1e-11, atol=1e-18)
+    assert np.allclose(apply("metpy_no_crs"), td.vorticity_no_crs(u, v, lat, lon), rtol=1e-9, atol=1e-17)
+    assert np.all(dg.vorticity_tables(lat, lon, "metpy_no_crs")[2] == 0) and np.all(dg.vorticity_tables(lat, lon, "spherical")[2] < 0)
+    # great-circle arc of one degree of longitude at 60 S on the default sphere: a little shorter than the parallel
+    arc = dg.great_circle_arc(np.deg2rad(-60.0), 0.0, np.deg2rad(-60.0), np.deg2rad(1.0), dg.PYPROJ_SPHERE_RADIUS)
+    par = dg.PYPROJ_SPHERE_RADIUS * np.cos(np.deg2rad(60.0)) * np.deg2rad(1.0)
+    assert 0 < par - arc < 1e-4 * par
+    with pytest.raises(ValueError):
+        dg.vorticity_tables(lat, lon, "wgs84")

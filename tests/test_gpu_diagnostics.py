@@ -38,20 +38,27 @@ def test_solid_body_rotation_vorticity():
     U = 30.0
     u = (U * np.cos(np.deg2rad(lat))[:, None] * np.ones((1, lon.size)))[None]
     lim = {"min_lat": -50, "max_lat": -20, "min_lon": -70, "max_lon": -30, "central_lat": -35, "central_lon": -50}
-    val, pos = dg.device_extrema(u, np.zeros_like(u), np.full_like(u, 1500.0), lat, lon, [lim])
+    val, pos = dg.device_extrema(u, np.zeros_like(u), np.full_like(u, 1500.0), lat, lon, [lim], formulation="spherical")
     want = 2 * U * np.sin(np.deg2rad(np.array([-50.0, -20.0, -35.0]))) / RE
     assert np.allclose(val[0, [0, 1, 4]], want, rtol=3e-4)
     assert lat[pos[0, 0]] == -50.0 and lat[pos[0, 2]] == -20.0
+    # the plain Cartesian form (MetPy without a CRS) lacks the curvature term u tan(phi) / Re: solid-body rotation then shows
+    # only -du/dy = U sin(phi) / a -- HALF the vorticity.  That is what the reference's runs report if MetPy falls back as documented.
+    val2, _ = dg.device_extrema(u, np.zeros_like(u), np.full_like(u, 1500.0), lat, lon, [lim], formulation="metpy_no_crs")
+    assert np.allclose(val2[0, [0, 1, 4]], want / 2 * RE / dg.PYPROJ_SPHERE_RADIUS, rtol=3e-4)
 
 
+@pytest.mark.parametrize("form", ["spherical", "metpy_no_crs"])
 @pytest.mark.parametrize("nonuni", [False, True])
-def test_kernel_matches_the_oracle_restatement(nonuni):
+def test_kernel_matches_the_oracle_restatement(nonuni, form):
     lat, lon, u, v, h = _fields(nonuni=nonuni)
+    if nonuni and form == "metpy_no_crs":        # uneven longitudes too: the arcs along a row are then not multiples of one another
+        lon = np.sort(lon + 0.3 * np.cos(np.arange(lon.size)))
     nt = u.shape[0]
-    zr = td.vorticity_sphere(u, v, lat, lon)
+    zr = (td.vorticity_sphere if form == "spherical" else td.vorticity_no_crs)(u, v, lat, lon)
     wr = td.wind_speed(u, v)
     for lim in LIMS:
-        val, pos = dg.device_extrema(u, v, h, lat, lon, [lim] * nt)
+        val, pos = dg.device_extrema(u, v, h, lat, lon, [lim] * nt, formulation=form)
         for t in range(nt):
             for row, use_zeta in ((None, False), (pd.Series({"Lat": -30.0, "Lon": -50.0}), True),
                                   (pd.Series({"Lat": -30.0, "Lon": -50.0, "min_max_zeta_850": -9e-5, "min_hgt_850": np.nan, "max_wind_850": 40.0}), False)):
@@ -61,7 +68,7 @@ def test_kernel_matches_the_oracle_restatement(nonuni):
                     if k.endswith("_lat") or k.endswith("_lon") or k in ("min_hgt_850",):
                         assert got[k] == ref[k], (lim, t, k)
                     else:
-                        assert abs(got[k] - ref[k]) <= 1e-12 * abs(ref[k]), (lim, t, k, got[k], ref[k])
+                        assert abs(got[k] - ref[k]) <= 1e-11 * abs(ref[k]), (lim, t, k, got[k], ref[k])
 
 
 def test_nan_inside_the_box_is_skipped_values_and_positions():
@@ -71,12 +78,12 @@ def test_nan_inside_the_box_is_skipped_values_and_positions():
     for a in (u, h):
         a[0, 20, 30] = np.nan                       # NaN wind: zeta is NaN at the point and at its four stencil neighbours
     lim = LIMS[0]
-    val, pos = dg.device_extrema(u, v, h, lat, lon, [lim])
+    val, pos = dg.device_extrema(u, v, h, lat, lon, [lim], formulation="spherical")
     got = dg.positions(val[0], pos[0], lat, lon, lim)
     z, w = td.vorticity_sphere(u, v, lat, lon)[0], td.wind_speed(u, v)[0]
     ref = td.get_position(z, h[0], w, lat, lon, lim)
     for k in ("min_max_zeta_850", "min_hgt_850", "max_wind_850"):
-        assert np.isfinite(got[k]) and abs(got[k] - ref[k]) <= 1e-12 * abs(ref[k])      # values: NaN skipped on both sides
+        assert np.isfinite(got[k]) and abs(got[k] - ref[k]) <= 1e-11 * abs(ref[k])      # values: NaN skipped on both sides
         assert np.isnan([z, h[0], w][("min_max_zeta_850", "min_hgt_850", "max_wind_850").index(k)][
             np.searchsorted(lat, ref[k + "_lat"]), np.searchsorted(lon, ref[k + "_lon"])])   # the reference's position: a NaN cell
     jj, ii = np.flatnonzero((lat >= -38) & (lat <= -22)), np.flatnonzero((lon >= -58) & (lon <= -42))
@@ -111,3 +118,5 @@ def test_arguments_are_validated():
         dg.device_extrema(u, v, h, lat, lon, [LIMS[0], LIMS[0]])
     with pytest.raises(ValueError):
         dg.device_extrema(u, v, h, lat, lon, [dict(LIMS[0], min_lat=40, max_lat=50)])
+    with pytest.raises(ValueError, match="formulation"):
+        dg.device_extrema(u, v, h, lat, lon, [LIMS[0]], formulation="wgs84")

@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 run() { tag=$1; shift; echo "== $tag: $*"; timeout -k 10 240 "$@" > $O/r03_$tag.json 2> $O/r03_$tag.err || { echo "FAILED $tag"; tail -5 $O/r03_$tag.err; return 1; }; python3 - <<PY
 import json
-d = json.load(open("$O/r03_$tag.json"))
+d = json.loads([ln for ln in open("$O/r03_$tag.json") if ln.startswith("{")][-1])
 print("  value %.1f  ms/pass %.3f  n_gpus %d  backend %s" % (d["value"], d["ms_per_step"], d["n_gpus"], d["config"]["backend"]))
 for k, v in sorted(d["config"].get("segments_ms", {}).items()):
     print("    %-34s %9.3f ms" % (k, v))
