@@ -181,19 +181,21 @@ __device__ __forceinline__ void finish_row(const double (&acc)[kNA], const doubl
     constexpr int rshift = (NTHR == 64) ? kRowShift : red_rshift(NTHR);
     static_assert(NR << rshift <= NTHR, "a reduction round must fit the row's threads");
     const double cT = r.cT, cU = r.cU, cV = r.cV, cW = r.cW, cP = r.cP;
+    // rounds of NR statistics through the same LDS tile; the cross-time sums ride in the slots the last round has left
+    // (20 + 4 = 3 rounds of 8: one round less than a round of their own -- every statistic is summed on its own, so the bits are the same)
+    constexpr int NV = kNA + (XCOV ? kNX : 0);
 #pragma unroll
-    for (int r0 = 0; r0 < kNA; r0 += NR) {      // rounds of NR statistics through the same LDS tile
+    for (int r0 = 0; r0 < NV; r0 += NR) {
         double h[NR];
 #pragma unroll
-        for (int s = 0; s < NR; ++s) h[s] = (r0 + s < kNA) ? acc[(r0 + s < kNA) ? r0 + s : 0] : 0.0;
+        for (int s = 0; s < NR; ++s) {
+            const int v = r0 + s;
+            h[s] = (v < kNA) ? acc[(v < kNA) ? v : 0] : ((XCOV && v < NV) ? xacc[(XCOV && v >= kNA && v < NV) ? v - kNA : 0] : 0.0);
+        }
         const double t0 = block_sums<NR, NTHR, rshift>(h, red, tid);
-        if ((tid & ((1 << rshift) - 1)) == 0 && (tid >> rshift) < NR && r0 + (tid >> rshift) < kNA)
-            tot[r0 + (tid >> rshift)] = t0 * ((r0 + (tid >> rshift) == 5 || r0 + (tid >> rshift) == 15) ? scale * kCp : scale);   // <f>, <fa>: Q = cp f
-        row_sync<NTHR>();
-    }
-    if (XCOV) {
-        const double t0 = block_sums<kNX, NTHR, rshift>(xacc, red, tid);
-        if ((tid & ((1 << rshift) - 1)) == 0 && (tid >> rshift) < kNX) tot[kNA + (tid >> rshift)] = t0 * scale;
+        const int v = r0 + (tid >> rshift);
+        if ((tid & ((1 << rshift) - 1)) == 0 && (tid >> rshift) < NR && v < NV)
+            tot[v] = t0 * ((v == 5 || v == 15) ? scale * kCp : scale);   // <f>, <fa>: Q = cp f
         row_sync<NTHR>();
     }
     if (tid < 22) {
