@@ -92,10 +92,73 @@ struct QCoef { double tb_, tf_, tm, k0, k1, km, j0, j1, jm; };      // tb_ / tf_
 
 constexpr int kNX = 4;      // cross-time sums: <a a+>, <a+>, <a a->, <a->
 
+// element q of a vector (see sweep_elems).  EDGE = false: the element lies strictly inside its row; true: the general form (selects).
+template <int VEC, bool UNIFORM, bool EDGE, int QMODE, bool BOTH, typename OP>
+__device__ __forceinline__ void sweep_one(const int q, double (&acc)[kNA], double (&xacc)[kNX], const SweepRow& r, int e0, bool lane_in,
+                                          const OP (&fT)[VEC], const OP (&fU)[VEC], const OP (&fV)[VEC],
+                                          const OP (&fW)[VEC], const OP (&fP)[VEC], double tl_edge, double tr_edge,
+                                          const QRaw<OP, VEC>& qr, const QCoef& qc) {
+#pragma clang fp contract(off)
+    const int e = e0 + q;
+    const bool inside = !EDGE || ((e >= 0) && (e < r.nxb) && lane_in);
+    const bool first = EDGE && inside && (e == 0), last = EDGE && inside && (e == r.nxb - 1);
+    double w = 1.0;
+    if (UNIFORM) { if (EDGE) w = inside ? ((first || last) ? 0.5 : 1.0) : 0.0; }
+    else w = EDGE ? (inside ? r.wl[min(max(e, 0), r.nxb - 1)] : 0.0) : r.wl[e];
+    const double Tc = (double)fT[q];
+    const double Tv = inside ? Tc : r.cT;
+    const double Uv = inside ? (double)fU[q] : r.cU;
+    const double Vv = inside ? (double)fV[q] : r.cV;
+    const double Wv = inside ? (double)fW[q] : r.cW;
+    const double Pv = inside ? (double)fP[q] : r.cP;
+    const double a = Tv - r.cT;
+    double f = 0.0;
+    if (QMODE != 0) {
+        const double Tl = (q == 0) ? tl_edge : (double)fT[q > 0 ? q - 1 : 0];
+        const double Tr = (q == VEC - 1) ? tr_edge : (double)fT[q < VEC - 1 ? q + 1 : q];
+        double adv;                                     // u dT/dx
+        if (UNIFORM) {
+            double d = Tr - Tl;
+            if (EDGE) d = first ? 2.0 * (Tr - Tv) : (last ? 2.0 * (Tv - Tl) : d);      // one-sided at the row ends
+            adv = (Uv * r.cx) * d;
+        } else {
+            const int ec = EDGE ? min(max(e, 0), r.nxb - 1) : e;
+            adv = Uv * fma(r.gl[3 * ec + 2], Tr, fma(r.gl[3 * ec + 1], Tv, r.gl[3 * ec + 0] * Tl)) * r.inv_dx;
+        }
+        const double sP = stencil3(qc.j0, (double)qr.j0[q], qc.j1, (double)qr.j1[q], qc.jm, Tc);
+        const double sS = stencil3(qc.k0, (double)qr.k0[q], qc.k1, (double)qr.k1[q], qc.km, Tc);
+        double rest = adv;
+        if (QMODE == 1) rest = stencil3(qc.tb_, (double)qr.tb[q], qc.tf_, (double)qr.tf[q], qc.tm, Tc) + adv;
+        if (QMODE == 2) rest = (double)qr.tf[q] + adv;
+        f = fma(-Wv, sS, fma(Vv, sP, rest));
+        if (EDGE) f = inside ? f : 0.0;
+        if (QMODE == 3) {
+            // the product a * a+ is rounded before it is weighted, so the row at t and the row at t+1 (as its backward
+            // covariance) form bit-identical sums: results do not depend on where a shard or a chunk starts
+            const double af = inside ? (double)qr.tf[q] - r.cTf : 0.0;
+            const double pf = a * af;
+            if (UNIFORM && !EDGE) { xacc[0] += pf; xacc[1] += af; }
+            else { xacc[0] = fma(w, pf, xacc[0]); xacc[1] = fma(w, af, xacc[1]); }
+            if (BOTH) {
+                const double ab = inside ? (double)qr.tb[q] - r.cTb : 0.0;
+                const double pb = a * ab;
+                if (UNIFORM && !EDGE) { xacc[2] += pb; xacc[3] += ab; }
+                else { xacc[2] = fma(w, pb, xacc[2]); xacc[3] = fma(w, ab, xacc[3]); }
+            }
+        }
+    }
+    accum20<UNIFORM && !EDGE>(acc, w, a, Uv - r.cU, Vv - r.cV, Wv - r.cW, Pv - r.cP, f);
+}
+
 // One vector (VEC consecutive longitudes starting at box element e0) of every operand -> the 20 sums.
 //   EDGE = false: every element of the trip lies strictly inside the row (1 <= e <= nxb - 2): no selects,
 //                 and with uniform longitudes the weight is the constant 1 (the row epilogue multiplies by h).
-//   EDGE = true : the first / last trips: half weights at the row ends, lanes outside the row contribute 0.
+//   EDGE = true : the first / last trips: half weights at the row ends, lanes outside the row contribute 0.  Even there almost
+//                 every element is an ordinary one (a 1440-point row has 2 special points among the 512 of its two edge trips), and
+//                 the general form costs half as much again (selects on 64-bit values): so per element q the WAVE asks whether any
+//                 lane's element is a row end or outside (one v_cmp + s_cbranch) and takes the plain form when none is -- it gives
+//                 the same bits (a weight of exactly 1 and selects that pick the loaded values change nothing); lanes whose whole
+//                 vector lies past the row (the tail of the last trip) sit the element loop out instead of adding zeros.
 //   QMODE: 0 no Q;
 //          1 dT/dt = ta T(t-1) + tb T(t) + tc T(t+1) per point (moving boxes: the neighbours in time sum over other boxes);
 //          2 dT/dt read from a cube (in qr.tf): f = Q / cp complete;
@@ -111,58 +174,19 @@ __device__ __forceinline__ void sweep_elems(double (&acc)[kNA], double (&xacc)[k
                                             const OP (&fT)[VEC], const OP (&fU)[VEC], const OP (&fV)[VEC],
                                             const OP (&fW)[VEC], const OP (&fP)[VEC], double tl_edge, double tr_edge,
                                             const QRaw<OP, VEC>& qr, const QCoef& qc) {
-#pragma clang fp contract(off)
+    if (EDGE && !lane_in) return;          // the lane's vector lies wholly past the row: it would add exact zeros
 #pragma unroll
     for (int q = 0; q < VEC; ++q) {
-        const int e = e0 + q;
-        const bool inside = !EDGE || ((e >= 0) && (e < r.nxb) && lane_in);
-        const bool first = EDGE && inside && (e == 0), last = EDGE && inside && (e == r.nxb - 1);
-        double w = 1.0;
-        if (UNIFORM) { if (EDGE) w = inside ? ((first || last) ? 0.5 : 1.0) : 0.0; }
-        else w = EDGE ? (inside ? r.wl[min(max(e, 0), r.nxb - 1)] : 0.0) : r.wl[e];
-        const double Tc = (double)fT[q];
-        const double Tv = inside ? Tc : r.cT;
-        const double Uv = inside ? (double)fU[q] : r.cU;
-        const double Vv = inside ? (double)fV[q] : r.cV;
-        const double Wv = inside ? (double)fW[q] : r.cW;
-        const double Pv = inside ? (double)fP[q] : r.cP;
-        const double a = Tv - r.cT;
-        double f = 0.0;
-        if (QMODE != 0) {
-            const double Tl = (q == 0) ? tl_edge : (double)fT[q > 0 ? q - 1 : 0];
-            const double Tr = (q == VEC - 1) ? tr_edge : (double)fT[q < VEC - 1 ? q + 1 : q];
-            double adv;                                     // u dT/dx
-            if (UNIFORM) {
-                double d = Tr - Tl;
-                if (EDGE) d = first ? 2.0 * (Tr - Tv) : (last ? 2.0 * (Tv - Tl) : d);      // one-sided at the row ends
-                adv = (Uv * r.cx) * d;
-            } else {
-                const int ec = EDGE ? min(max(e, 0), r.nxb - 1) : e;
-                adv = Uv * fma(r.gl[3 * ec + 2], Tr, fma(r.gl[3 * ec + 1], Tv, r.gl[3 * ec + 0] * Tl)) * r.inv_dx;
-            }
-            const double sP = stencil3(qc.j0, (double)qr.j0[q], qc.j1, (double)qr.j1[q], qc.jm, Tc);
-            const double sS = stencil3(qc.k0, (double)qr.k0[q], qc.k1, (double)qr.k1[q], qc.km, Tc);
-            double rest = adv;
-            if (QMODE == 1) rest = stencil3(qc.tb_, (double)qr.tb[q], qc.tf_, (double)qr.tf[q], qc.tm, Tc) + adv;
-            if (QMODE == 2) rest = (double)qr.tf[q] + adv;
-            f = fma(-Wv, sS, fma(Vv, sP, rest));
-            if (EDGE) f = inside ? f : 0.0;
-            if (QMODE == 3) {
-                // the product a * a+ is rounded before it is weighted, so the row at t and the row at t+1 (as its backward
-                // covariance) form bit-identical sums: results do not depend on where a shard or a chunk starts
-                const double af = inside ? (double)qr.tf[q] - r.cTf : 0.0;
-                const double pf = a * af;
-                if (UNIFORM && !EDGE) { xacc[0] += pf; xacc[1] += af; }
-                else { xacc[0] = fma(w, pf, xacc[0]); xacc[1] = fma(w, af, xacc[1]); }
-                if (BOTH) {
-                    const double ab = inside ? (double)qr.tb[q] - r.cTb : 0.0;
-                    const double pb = a * ab;
-                    if (UNIFORM && !EDGE) { xacc[2] += pb; xacc[3] += ab; }
-                    else { xacc[2] = fma(w, pb, xacc[2]); xacc[3] = fma(w, ab, xacc[3]); }
-                }
-            }
+        if (EDGE) {
+            const int e = e0 + q;
+            const bool special = (unsigned)(e - 1) >= (unsigned)(r.nxb - 2);        // e <= 0 or e >= nxb - 1: a row end, or outside the row
+            if (__builtin_amdgcn_ballot_w64(special) != 0)
+                sweep_one<VEC, UNIFORM, true, QMODE, BOTH>(q, acc, xacc, r, e0, lane_in, fT, fU, fV, fW, fP, tl_edge, tr_edge, qr, qc);
+            else
+                sweep_one<VEC, UNIFORM, false, QMODE, BOTH>(q, acc, xacc, r, e0, lane_in, fT, fU, fV, fW, fP, tl_edge, tr_edge, qr, qc);
+        } else {
+            sweep_one<VEC, UNIFORM, false, QMODE, BOTH>(q, acc, xacc, r, e0, lane_in, fT, fU, fV, fW, fP, tl_edge, tr_edge, qr, qc);
         }
-        accum20<UNIFORM && !EDGE>(acc, w, a, Uv - r.cU, Vv - r.cV, Wv - r.cW, Pv - r.cP, f);
         // four-element vectors: finish one element before starting the next, or the scheduler interleaves all four and
         // their temporaries push the kernel past 128 VGPRs
         if (VEC > 2) __builtin_amdgcn_sched_barrier(0);

@@ -77,6 +77,16 @@ class PreparedBoxes:
     def __len__(self):
         return len(self.boxes)
 
+    def part(self, a: int, b: int) -> "PreparedBoxes":
+        """Boxes [a, b) of a series of per-time-step boxes (a chunk of the series): views of the uploaded tables, no host work and no
+        copy -- every table is indexed by box along its first axis."""
+        import dataclasses
+        if not (0 <= a < b <= len(self.boxes)):
+            raise ValueError("part: need 0 <= a < b <= number of boxes")
+        bt = dataclasses.replace(self.bt, box=self.bt.box[a:b], boxtab=self.bt.boxtab[a:b], wlon=self.bt.wlon[a:b], glon=self.bt.glon[a:b],
+                                 lattab=self.bt.lattab[a:b], boxtab2=self.bt.boxtab2[a:b], lattab2=self.bt.lattab2[a:b])
+        return PreparedBoxes(self.boxes[a:b], bt, {k: v[a:b] for k, v in self.dev.items()})
+
 
 class LECEngine:
     """One engine per (grid, device).
@@ -145,6 +155,12 @@ class LECEngine:
         self._box_cache[key] = (bt, dev)
         return bt, dev
 
+    def time_coefs_device(self, time_s) -> torch.Tensor:
+        """np.gradient's coefficients over a whole series' time axis, on the device ([n, 3]).  Rows [h0, h1) serve any cube that holds
+        the steps [h0, h1) of the series and processes only steps whose neighbours it holds (own steps + one-step halo): there the
+        coefficients of the sub-axis equal the series' (they differ only at the halo steps, which are not processed)."""
+        return self._up(tables.time_coefs(np.asarray(time_s, dtype=np.float64)))
+
     # -- the hot path ----------------------------------------------------------------------
     def compute(self, tair: torch.Tensor, u: torch.Tensor, v: torch.Tensor, omega: torch.Tensor,
                 geopt: Optional[torch.Tensor], boxes: Sequence[Sequence[int]], *,
@@ -181,9 +197,12 @@ class LECEngine:
                  time_s=None, dTdt: Optional[torch.Tensor] = None, t_begin: int = 0,
                  t_count: Optional[int] = None, with_q: bool = True, timing: Optional[list] = None,
                  rows_out: Optional[torch.Tensor] = None, tuning: Optional[dict] = None,
-                 per_step_boxes: Optional[bool] = None) -> torch.Tensor:
+                 per_step_boxes: Optional[bool] = None, tcoef: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Stage 1 (``lec_rowstats``): row records [t_count, nl, nyb_max, 32] of time steps [t_begin, t_begin + t_count).
-        ``tuning``: see ``make_tuning`` (kernel family / order / tile shape; default = the library's choice)."""
+        ``tuning``: see ``make_tuning`` (kernel family / order / tile shape; default = the library's choice).
+        ``tcoef``: the d/dt coefficients of the cube's time steps already on the device (fp64 [nt, 3], e.g. rows [h0, h1) of
+        ``time_coefs_device`` of the whole series) instead of ``time_s`` -- a chunk loop then uploads nothing per call (an upload from
+        pageable memory makes the host wait for the stream, which serialises a copy / compute pipeline)."""
         if tair.dim() != 4:
             raise ValueError("fields must be [time, level, lat, lon]")
         nt, nl, ny, nx = tair.shape
@@ -207,8 +226,12 @@ class LECEngine:
         if len(boxes) != (t_count if per_step_boxes else 1):
             raise ValueError("boxes: give one box, or one per processed time step")
 
-        tcoef = None
-        if with_q and dTdt is None:
+        if tcoef is not None:
+            if tcoef.shape != (nt, 3) or tcoef.dtype != torch.float64 or tcoef.device != tair.device or not tcoef.is_contiguous():
+                raise ValueError("tcoef must be a contiguous fp64 [nt, 3] tensor on the fields' device")
+            if nt < 2:
+                raise ValueError("dT/dt by finite differences needs at least 2 time steps")
+        elif with_q and dTdt is None:
             if time_s is None:
                 raise ValueError("with_q needs time_s (seconds) or a dTdt cube")
             time_s = np.asarray(time_s, dtype=np.float64)

@@ -136,7 +136,8 @@ class _Stager:
         # (record variables are interleaved per record): never reshape across time, that would copy the variable
         as_bytes = lambda a: a.view(a.dtype.newbyteorder("=")).view(self._carrier_np)     # reinterpret, never convert
         jobs = []
-        piece = max(1, (8 << 20) // self.itemsize)                  # ~8 MiB per copy job: memcpy releases the GIL
+        piece = max(1, (2 << 20) // self.itemsize)                  # ~2 MiB per copy job (memcpy releases the GIL): ~150 jobs per variable
+                                                                    # and chunk at the headline size, so the pool's last round is short
         for r, ft in enumerate(file_steps):
             block = self.var.data[int(ft)]
             if not block.flags["C_CONTIGUOUS"]:
@@ -256,43 +257,50 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
 
     compute = torch.cuda.current_stream(dev)
     copier = torch.cuda.Stream(device=dev)
-    copied = [torch.cuda.Event() for _ in range(slots)]        # uploads of the slot have landed
+    copied = [[torch.cuda.Event() for _ in roles] for _ in range(slots)]      # the variable's upload of the slot has landed
     consumed = [torch.cuda.Event() for _ in range(slots)]      # the slot's raw buffers have been decoded
     used = [False] * slots
     moved, host_s = 0, 0.0
-    n_chunks = (t1 - t0 + chunk_steps - 1) // chunk_steps
+    # Nothing inside the chunk loop may make the host wait for the GPU (an upload from pageable memory does: it serialised staging
+    # and copies in rounds 1-2, profiles/r03_notes.md): the d/dt coefficients of the whole time axis and the tables of every box go to
+    # the device once, here; a chunk uses rows / views of them.
+    tcoef_all = engine.time_coefs_device(time_s) if with_q else None
+    # chunk schedule: a short first chunk fills the pipeline quickly (the first upload cannot start before its staging is done)
+    first = max(1, min(chunk_steps, 1 if (t1 - t0) > chunk_steps else chunk_steps))
+    bounds = [t0, min(t0 + first, t1)]
+    while bounds[-1] < t1:
+        bounds.append(min(bounds[-1] + chunk_steps, t1))
+    n_chunks = len(bounds) - 1
     for c in range(n_chunks):
         slot = c % slots
-        c0, c1 = t0 + c * chunk_steps, min(t0 + (c + 1) * chunk_steps, t1)
+        c0, c1 = bounds[c], bounds[c + 1]
         h0, h1 = (max(c0 - 1, 0), min(c1 + 1, nt)) if with_q else (c0, c1)
         if used[slot]:
-            copied[slot].synchronize()          # the pinned buffers of this slot may be overwritten now
+            copied[slot][-1].synchronize()      # the pinned buffers of this slot may be overwritten now (uploads are in stream order)
         # only T carries the halo; the other fields start at their own first step (rows [c0 - h0, c1 - h0) of the slot)
         span_of = lambda r: (0, h1 - h0) if r == "Air Temperature" else (c0 - h0, c1 - h0)
-        t_host = time.perf_counter()
-        for r in roles:
+        for n, r in enumerate(roles):
+            # variable by variable: stage (thread pool), enqueue its upload, decode it -- the copy engine starts after a fifth of the
+            # chunk's staging, and the next variable is staged while this one is on the link
             a, b = span_of(r)
+            t_host = time.perf_counter()
             stagers[r].stage(slot, plan.tsel[h0 + a: h0 + b], a)
-        host_s += time.perf_counter() - t_host
-        with torch.cuda.stream(copier):
-            if used[slot]:
-                copier.wait_event(consumed[slot])   # the raw device buffers of this slot have been decoded
-            for r in roles:
-                a, b = span_of(r)
+            host_s += time.perf_counter() - t_host
+            with torch.cuda.stream(copier):
+                if used[slot] and n == 0:
+                    copier.wait_event(consumed[slot])   # the raw device buffers of this slot have been decoded
                 stagers[r].upload(slot, a, b)
                 moved += (b - a) * stagers[r].step_elems * stagers[r].itemsize
-            copied[slot].record(copier)
-        compute.wait_event(copied[slot])
-        with torch.cuda.device(dev):
-            for r in roles:
-                a, b = span_of(r)
+                copied[slot][n].record(copier)
+            compute.wait_event(copied[slot][n])
+            with torch.cuda.device(dev):
                 unit = 1.0 if r == geo_role else ds.field_scale(variable_list_df, r)
                 _ingest_call(lib, rvars[r], stagers[r].raw_dev[slot][a].data_ptr(), b - a, (nl_in, ny_in, nx_in, nl, ny, nx), maps, unit,
                              decode[r], common, cubes[slot][keys[r]][a].data_ptr(), compute)
-            consumed[slot].record(compute)
+        consumed[slot].record(compute)
         f = {k: t[: h1 - h0] for k, t in cubes[slot].items()}
-        engine.rowstats(f["tair"], f["u"], f["v"], f["omega"], f["geopt"], boxes[c0:c1] if per_step_boxes else boxes,
-                        time_s=time_s[h0:h1] if with_q else None, t_begin=c0 - h0, t_count=c1 - c0, with_q=with_q,
+        engine.rowstats(f["tair"], f["u"], f["v"], f["omega"], f["geopt"], own_boxes.part(c0 - t0, c1 - t0) if per_step_boxes else boxes,
+                        tcoef=tcoef_all[h0:h1] if with_q else None, t_begin=c0 - h0, t_count=c1 - c0, with_q=with_q,
                         rows_out=rows[c0 - t0:c1 - t0], per_step_boxes=per_step_boxes)
         used[slot] = True
     res = engine.reduce(rows, own_boxes, phi_scale=phi_scale, drop_any_time=not per_step_boxes, merge_dropmask=merge_dropmask, out=out)
