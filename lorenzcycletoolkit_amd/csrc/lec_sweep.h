@@ -153,12 +153,12 @@ __device__ __forceinline__ void sweep_one(const int q, double (&acc)[kNA], doubl
 // One vector (VEC consecutive longitudes starting at box element e0) of every operand -> the 20 sums.
 //   EDGE = false: every element of the trip lies strictly inside the row (1 <= e <= nxb - 2): no selects,
 //                 and with uniform longitudes the weight is the constant 1 (the row epilogue multiplies by h).
-//   EDGE = true : the first / last trips: half weights at the row ends, lanes outside the row contribute 0.  Even there almost
-//                 every element is an ordinary one (a 1440-point row has 2 special points among the 512 of its two edge trips), and
-//                 the general form costs half as much again (selects on 64-bit values): so per element q the WAVE asks whether any
-//                 lane's element is a row end or outside (one v_cmp + s_cbranch) and takes the plain form when none is -- it gives
-//                 the same bits (a weight of exactly 1 and selects that pick the loaded values change nothing); lanes whose whole
-//                 vector lies past the row (the tail of the last trip) sit the element loop out instead of adding zeros.
+//   EDGE = true : the first / last trips: half weights at the row ends, lanes outside the row contribute 0; lanes whose whole
+//                 vector lies past the row (the tail of the last trip) sit the element loop out instead of adding exact zeros
+//                 (same bits, and 20 fewer VGPRs in the fp32 all-terms instantiation).  Measured and NOT kept (LEC_EDGE_BALLOT,
+//                 profiles/r03_notes.md): per element, a wave-uniform test "is any lane's element a row end or outside" choosing
+//                 between the plain and the general form -- the same bits with 190 fewer instructions per 1440-point fp32 row, but
+//                 both forms side by side cost 9-30 VGPRs, the capped instantiations spill, and every configuration got slower.
 //   QMODE: 0 no Q;
 //          1 dT/dt = ta T(t-1) + tb T(t) + tc T(t+1) per point (moving boxes: the neighbours in time sum over other boxes);
 //          2 dT/dt read from a cube (in qr.tf): f = Q / cp complete;
@@ -180,10 +180,15 @@ __device__ __forceinline__ void sweep_elems(double (&acc)[kNA], double (&xacc)[k
         if (EDGE) {
             const int e = e0 + q;
             const bool special = (unsigned)(e - 1) >= (unsigned)(r.nxb - 2);        // e <= 0 or e >= nxb - 1: a row end, or outside the row
+#if defined(LEC_EDGE_BALLOT) && LEC_EDGE_BALLOT
             if (__builtin_amdgcn_ballot_w64(special) != 0)
                 sweep_one<VEC, UNIFORM, true, QMODE, BOTH>(q, acc, xacc, r, e0, lane_in, fT, fU, fV, fW, fP, tl_edge, tr_edge, qr, qc);
             else
                 sweep_one<VEC, UNIFORM, false, QMODE, BOTH>(q, acc, xacc, r, e0, lane_in, fT, fU, fV, fW, fP, tl_edge, tr_edge, qr, qc);
+#else
+            (void)special;
+            sweep_one<VEC, UNIFORM, true, QMODE, BOTH>(q, acc, xacc, r, e0, lane_in, fT, fU, fV, fW, fP, tl_edge, tr_edge, qr, qc);
+#endif
         } else {
             sweep_one<VEC, UNIFORM, false, QMODE, BOTH>(q, acc, xacc, r, e0, lane_in, fT, fU, fV, fW, fP, tl_edge, tr_edge, qr, qc);
         }

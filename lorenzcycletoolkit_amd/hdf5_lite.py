@@ -734,7 +734,9 @@ class H5File:
             elif fid == 2:                             # shuffle
                 es = cd[0] if cd else var.dtype.itemsize
                 n = len(raw) // es
-                raw = np.frombuffer(raw, dtype=np.uint8)[: n * es].reshape(es, n).T.tobytes()
+                out = np.empty((n, es), dtype=np.uint8)
+                np.copyto(out, np.frombuffer(raw, dtype=np.uint8)[: n * es].reshape(es, n).T)     # array assignment releases the GIL (.tobytes() does not:
+                raw = out.reshape(-1).data                                                          # the inflate threads queued for it)
             elif fid == 3:                             # fletcher32: the payload's checksum follows it (4 bytes, little-endian)
                 raw, stored = raw[:-4], int.from_bytes(raw[-4:], "little")
                 if stored not in _fletcher32(raw):
