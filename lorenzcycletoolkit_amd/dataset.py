@@ -288,11 +288,14 @@ def decode_values(raw: np.ndarray, scale, offset, fill) -> np.ndarray:
     if fill is not None:
         a = np.where(raw == fill, np.nan, raw.astype(masked)) if masked.kind == "f" else raw
     if scale is not None or offset is not None:
+        # every operation in float64, rounded to the decode dtype once per operation -- written out, so that it does not depend on
+        # the NumPy version's promotion rules (NumPy 1.x would compute `float32_array *= float64_scalar` in float32) and agrees with
+        # lec_ingest's (float)((double)v * scale), (float)((double)v + offset) bit for bit
         a = a.astype(out, copy=True)
         if scale is not None:
-            a *= np.float64(scale)
+            a = (a.astype(np.float64) * np.float64(scale)).astype(out)
         if offset is not None:
-            a += np.float64(offset)
+            a = (a.astype(np.float64) + np.float64(offset)).astype(out)
     return np.asarray(a, dtype=out)
 
 

@@ -171,8 +171,8 @@ def positions(val, pos, lat_deg, lon_deg, limits, track_row=None, use_track_zeta
     lat, lon = np.asarray(lat_deg), np.asarray(lon_deg)
     south = limits["min_lat"] < 0                              # hemisphere rule of the VALUE (lec_moving_framework.py:330-341)
     have = lambda name: track_row is not None and name in track_row.index and not np.isnan(float(track_row[name]))
-    if have("min_max_zeta_850"):
-        zval = float(track_row["min_max_zeta_850"])
+    if track_row is not None and "min_max_zeta_850" in track_row.index:
+        zval = float(track_row["min_max_zeta_850"])          # the column's value as it is, NaN included (lec_moving_framework.py:312-313)
     elif use_track_zeta and track_row is not None:
         zval = float(val[4])
     else:

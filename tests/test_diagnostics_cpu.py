@@ -63,6 +63,11 @@ def test_positions_prefer_track_values_and_follow_the_hemisphere_rule():
     row = pd.Series({"Lat": -30.0, "Lon": -50.0, "min_max_zeta_850": -9e-5, "min_hgt_850": np.nan, "max_wind_850": 40.0})
     q = dg.positions(val, pos, lat, lon, lim, row)
     assert q["min_max_zeta_850"] == -9e-5 and q["min_hgt_850"] == 1400.0 and q["max_wind_850"] == 40.0
+    # a NaN in the track file's zeta column is USED (the reference takes the column without looking, lec_moving_framework.py:312-313),
+    # while NaN in the two other columns falls back to the data (:356-360, :375-379)
+    nanrow = pd.Series({"Lat": -30.0, "Lon": -50.0, "min_max_zeta_850": np.nan, "min_hgt_850": np.nan, "max_wind_850": np.nan})
+    qn = dg.positions(val, pos, lat, lon, lim, nanrow)
+    assert np.isnan(qn["min_max_zeta_850"]) and qn["min_hgt_850"] == 1400.0 and qn["max_wind_850"] == 33.0
     z = dg.positions(val, pos, lat, lon, lim, pd.Series({"Lat": -30.0, "Lon": -50.0}), use_track_zeta=True)
     assert z["min_max_zeta_850"] == -1e-5                                                                                   # -z: vorticity at the box centre
     none = dg.positions(np.array([np.nan] * 5), np.full(8, -1, dtype=np.int32), lat, lon, lim)

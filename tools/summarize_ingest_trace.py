@@ -5,7 +5,8 @@ For the LAST streamed pass in the trace (the runs of host-to-device copies separ
 its first copy to its last lec_* kernel, how much of that span the copy engine was busy, the copy rate while busy, the largest gap
 between consecutive copies, and for how long copies and lec_* kernels ran AT THE SAME TIME (the overlap the pipeline exists for).
 
-Usage: tools/summarize_ingest_trace.py <trace dir> <out json>
+Usage: tools/summarize_ingest_trace.py <trace dir> <out json> [<bench_ingest json line file> [<passes the command ran>]]    (this rocprofv3 records
+no copy sizes: the bytes of a pass come from the bench line's bytes_moved)
 """
 import csv
 import glob
@@ -29,7 +30,7 @@ def main():
     cop = [r for r in read("*memory_copy_trace.csv", d) if "HOST_TO_DEVICE" in r.get("Direction", "") or "H2D" in r.get("Direction", "").upper()]
     ker = [r for r in read("*kernel_trace.csv", d) if "lec_" in r["Kernel_Name"]]
     c = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r.get("Size", 0) or 0)) for r in cop)
-    big = [x for x in c if x[2] >= (1 << 20)]                 # the field uploads (tables and coefficients are tiny)
+    big = [x for x in c if x[1] - x[0] >= 500_000]            # the field uploads take milliseconds (tables and coefficients: microseconds)
     passes, cur = [], [big[0]]
     for x in big[1:]:
         if x[0] - cur[-1][1] > 50_000_000:
@@ -38,6 +39,10 @@ def main():
         else:
             cur.append(x)
     passes.append(cur)
+    if len(sys.argv) > 4:                                     # the number of passes the command ran (warm-up + repeats): equal shares of the copies
+        n = int(sys.argv[4])
+        per = len(big) // n
+        passes = [big[i * per:(i + 1) * per] for i in range(n)]
     last = passes[-1]
     t0 = last[0][0]
     k = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in ker)
@@ -45,6 +50,9 @@ def main():
     t1 = max(last[-1][1], max(x[1] for x in kin))
     busy = sum(e - s for s, e, _ in last)
     nbytes = sum(b for _, _, b in last)
+    if nbytes == 0 and len(sys.argv) > 3:
+        line = [ln for ln in open(sys.argv[3]) if ln.startswith("{")][-1]
+        nbytes = json.loads(line)["bytes_moved"]
     gaps = [b[0] - a[1] for a, b in zip(last, last[1:])]
     # time during which a copy and a lec_* kernel are both running (both lists are sorted and non-overlapping within themselves)
     both, j = 0, 0
@@ -63,7 +71,7 @@ def main():
            "kernel_time_overlapped_with_copies_ms": both / 1e6, "fraction_of_kernel_time_hidden_behind_copies": both / ktime if ktime else None,
            "kernel_ms_by_name": {}}
     for s, e, n in kin:
-        key = n.split("<")[0].split("(")[0].replace("(anonymous namespace)::", "").replace("void ", "")
+        key = n.replace("(anonymous namespace)::", "").replace("void ", "").split("<")[0].split("(")[0]
         res["kernel_ms_by_name"][key] = res["kernel_ms_by_name"].get(key, 0.0) + (e - s) / 1e6
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res))
