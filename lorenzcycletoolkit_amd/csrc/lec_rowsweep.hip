@@ -196,12 +196,71 @@ __global__ void __launch_bounds__(kThreads, (sweep_min_waves<TIN, VEC, MODE>()))
             tl_edge = from_prev_lane((double)fT[VEC - 1], (double)rT[il]);
             tr_edge = from_next_lane((double)fT[0], (double)rT[ir]);
         }
+#if defined(LEC_EXPERIMENT_NOEDGE) && LEC_EXPERIMENT_NOEDGE      // measurement builds only: edge trips with the plain arithmetic (WRONG row ends)
+        if (lane_in) sweep_elems<VEC, UNIFORM, false, MODE, BOTH>(acc, xacc, r, e0, lane_in, fT, fU, fV, fW, fP, tl_edge, tr_edge, qr, qc);
+#else
         sweep_elems<VEC, UNIFORM, EDGE, MODE, BOTH>(acc, xacc, r, e0, lane_in, fT, fU, fV, fW, fP, tl_edge, tr_edge, qr, qc);
+#endif
     };
 
+#if defined(LEC_EXPERIMENT_PREFETCH) && LEC_EXPERIMENT_PREFETCH     // measurement builds only (plain arithmetic everywhere: WRONG row ends)
+    struct TripData { TIN fT[VEC], fU[VEC], fV[VEC], fW[VEC], fP[VEC]; QRaw<TIN, VEC> qr; TIN sl, sr; };
+    auto issue = [&](TripData& d, const int it) {
+        const int el = it * nthr * VEC - shift;
+        const int e0 = el + tid * VEC;
+        const unsigned eo = (unsigned)(min(e0, e0_last) + shift);
+        load_vec<TIN, VEC, MODE == 0>(rT - shift, eo, d.fT);
+        load_vec<TIN, VEC, true>(rU - shift, eo, d.fU);
+        load_vec<TIN, VEC, true>(rV - shift, eo, d.fV);
+        load_vec<TIN, VEC, true>(rW - shift, eo, d.fW);
+        load_vec<TIN, VEC, true>(rP - shift, eo, d.fP);
+        if (WITH_Q) {
+            load_vec<TIN, VEC, false>(rTjm - shift, eo, d.qr.j0);
+            load_vec<TIN, VEC, false>(rTjp - shift, eo, d.qr.j1);
+            load_vec<TIN, VEC, false>(rTkm - shift, eo, d.qr.k0);
+            load_vec<TIN, VEC, false>(rTkp - shift, eo, d.qr.k1);
+            load_vec<TIN, VEC, false>(rTtp - shift, eo, d.qr.tf);
+            d.sl = rT[min(max(el - 1, 0), nxb - 1)];
+            d.sr = rT[min(max(el + nthr * VEC, 0), nxb - 1)];
+        }
+    };
+    auto compute = [&](const TripData& d, const int it) {
+        const int e0 = it * nthr * VEC - shift + tid * VEC;
+        const double tl_edge = from_prev_lane((double)d.fT[VEC - 1], (double)d.sl);
+        const double tr_edge = from_next_lane((double)d.fT[0], (double)d.sr);
+        if (e0 <= e0_last) sweep_elems<VEC, UNIFORM, false, MODE, BOTH>(acc, xacc, r, e0, true, d.fT, d.fU, d.fV, d.fW, d.fP, tl_edge, tr_edge, d.qr, qc);
+    };
+    const int ntrips = p.ntrips;
+    {
+        // the number of loads in flight must be the same on every path into a block, or the compiler's s_waitcnt has to assume the
+        // fewest (a conditional issue() made every wait a vmcnt(0) and the pipeline serial): issue() is unconditional inside the
+        // loop, the last trips are peeled
+        TripData A, B;
+        issue(A, 0);
+        issue(B, min(1, ntrips - 1));
+        int it = 0;
+#pragma unroll 1
+        for (; it + 3 < ntrips; it += 2) {
+            compute(A, it);
+            issue(A, it + 2);
+            compute(B, it + 1);
+            issue(B, it + 3);
+        }
+        compute(A, it);
+        if (it + 2 < ntrips) {
+            issue(A, it + 2);
+            compute(B, it + 1);
+            compute(A, it + 2);
+        } else if (it + 1 < ntrips) {
+            compute(B, it + 1);
+        }
+    }
+    if (false)
+#else
     // a real loop (not unrolled): the live state stays at the 20 accumulators plus one vector's worth of
     // operands, which is what lets 4 waves/SIMD fit.  Trips [1, mid_end) lie strictly inside the row.
     const int ntrips = ONE_TRIP ? 1 : p.ntrips;      // short rows (moving boxes): one trip, no loop
+#endif
     trip(std::true_type{}, 0);
     if (!ONE_TRIP) {
         const int mid_end = min((nxb - 1 + shift) / (nthr * VEC), ntrips);
