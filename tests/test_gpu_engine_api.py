@@ -76,7 +76,8 @@ def test_device_resident_time_coefficients_equal_the_per_call_upload():
         g = [x[h0:h1].contiguous() for x in f]
         part = eng.rowstats(*g, [box], tcoef=tc[h0:h1], t_begin=a - h0, t_count=b - a)
         also = eng.rowstats(*g, [box], time_s=dom.time_s[h0:h1], t_begin=a - h0, t_count=b - a)
-        assert torch.equal(part, whole[a:b]) and torch.equal(also, part), (h0, h1, a, b)
+        # slots 28..31 of a record are stage-1 scratch (the first processed step of a launch keeps its backward covariance pieces there)
+        assert torch.equal(part[..., :28], whole[a:b][..., :28]) and torch.equal(also, part), (h0, h1, a, b)
     with pytest.raises(ValueError):
         eng.rowstats(*f, [box], tcoef=tc[:5])
     with pytest.raises(ValueError):
