@@ -279,6 +279,24 @@ int lec_track_diag(const lec_diag_args* args);
 int lec_check_boxes(const lec_rowstats_args* args, int32_t* status_d);
 int lec_check_maps(const lec_ingest_args* args, int32_t* status_d);
 
+/*
+ * Host-memory plumbing of the device ingest: move file bytes to the GPU WITHOUT a staging copy.  The reference reads its file
+ * through xarray into NumPy memory (src/utils/preprocessing.py:35-146); here a span of the memory-mapped file (or of any host
+ * array) is registered with the HIP runtime -- its pages are pinned and mapped for the copy engines --, the rows a chunk needs are
+ * copied from it asynchronously, and the span is unregistered once the copies have completed (the caller synchronises on them
+ * first and keeps the bookkeeping: registered spans must not overlap).
+ *   lec_host_register    ptr / bytes: page-aligned span of host memory (read-only file mappings are fine)
+ *   lec_host_unregister  the pointer a span was registered with
+ *   lec_copy_rows_async  `rows` rows of `width_bytes`, source rows `src_pitch` bytes apart (host), destination rows `dst_pitch` apart
+ *                        (device), on `stream`; rows == 1 or both pitches == width: one linear copy.  Truly asynchronous only from
+ *                        registered (or pinned) memory.
+ * Return LEC_OK, LEC_ERR_ARG, or LEC_ERR_LAUNCH with the runtime's message when HIP refuses (the Python host then falls back to its
+ * pinned staging buffers).
+ */
+int lec_host_register(const void* ptr, size_t bytes);
+int lec_host_unregister(const void* ptr);
+int lec_copy_rows_async(void* dst_d, size_t dst_pitch, const void* src_h, size_t src_pitch, size_t width_bytes, size_t rows, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

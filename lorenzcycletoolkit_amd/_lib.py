@@ -23,7 +23,7 @@ KERNEL_AUTO, KERNEL_TWO_SWEEP, KERNEL_ROW_SWEEP, KERNEL_ROW_BLOCK, KERNEL_BOX_TI
 ORDER_AUTO, ORDER_MEMORY, ORDER_XCD_LAT, ORDER_XCD_TILED = 0, 1, 2, 7
 
 EXPORTS = ["lec_version", "lec_last_error", "lec_max_row", "lec_rowstats", "lec_reduce", "lec_dropmask", "lec_ingest", "lec_track_diag",
-           "lec_check_boxes", "lec_check_maps"]
+           "lec_check_boxes", "lec_check_maps", "lec_host_register", "lec_host_unregister", "lec_copy_rows_async"]
 
 
 class Tuning(C.Structure):
@@ -127,6 +127,12 @@ def load():
     lib.lec_check_boxes.argtypes = [C.POINTER(RowstatsArgs), C.c_void_p]
     lib.lec_check_maps.restype = C.c_int
     lib.lec_check_maps.argtypes = [C.POINTER(IngestArgs), C.c_void_p]
+    lib.lec_host_register.restype = C.c_int
+    lib.lec_host_register.argtypes = [C.c_void_p, C.c_size_t]
+    lib.lec_host_unregister.restype = C.c_int
+    lib.lec_host_unregister.argtypes = [C.c_void_p]
+    lib.lec_copy_rows_async.restype = C.c_int
+    lib.lec_copy_rows_async.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]
     if lib.lec_version() != LEC_ABI_VERSION:
         raise LecLibraryError(f"liblec_hip.so ABI {lib.lec_version()} != expected {LEC_ABI_VERSION}")
     _lib = lib

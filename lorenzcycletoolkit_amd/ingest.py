@@ -99,6 +99,66 @@ def _pool():
     return _POOL
 
 
+_PAGE = 4096
+
+
+class RegisteredSpans:
+    """Host memory registered with the HIP runtime for direct (staging-free) copies: a set of page-aligned, NON-OVERLAPPING blocks
+    (``lec_host_register`` refuses a span that touches a registered one).  ``ensure(lo, hi, use)`` registers whatever part of
+    [lo, hi) is not covered yet and stamps every block it touches with ``use`` (the chunk number); ``release(before)`` unregisters
+    the blocks whose last use is older than ``before`` -- the caller has synchronised on those chunks' copies.  One instance serves
+    every variable of a file (record variables interleave, so their spans touch)."""
+
+    def __init__(self, lib):
+        self.lib = lib
+        self.blocks = []                # [start, end, last_use], sorted, disjoint
+        self.registered_bytes = 0
+        self.calls = 0
+
+    def ensure(self, lo: int, hi: int, use: int) -> None:
+        lo, hi = lo & ~(_PAGE - 1), (hi + _PAGE - 1) & ~(_PAGE - 1)
+        at, new = lo, []
+        for b in self.blocks:
+            if b[1] <= lo or b[0] >= hi:
+                continue
+            b[2] = max(b[2], use)
+            if b[0] > at:
+                new.append([at, b[0], use])
+            at = max(at, b[1])
+        if at < hi:
+            new.append([at, hi, use])
+        for b in new:
+            _lib.check(self.lib.lec_host_register(C.c_void_p(b[0]), b[1] - b[0]), "lec_host_register")
+            self.registered_bytes += b[1] - b[0]
+            self.calls += 1
+        if new:
+            self.blocks = sorted(self.blocks + new)
+
+    def pieces(self, lo: int, hi: int):
+        """[lo, hi) cut at the boundaries of the registered blocks: a copy must lie inside ONE registered allocation to go out as a
+        direct DMA (the runtime treats a range that runs from one allocation into the next as unregistered memory)."""
+        out = []
+        for b in self.blocks:
+            a, e = max(lo, b[0]), min(hi, b[1])
+            if a < e:
+                out.append((a, e))
+        if sum(e - a for a, e in out) != hi - lo:
+            raise RuntimeError("copy range is not wholly registered")
+        return out
+
+    def release(self, before: int) -> None:
+        keep = []
+        for b in self.blocks:
+            if b[2] < before:
+                _lib.check(self.lib.lec_host_unregister(C.c_void_p(b[0])), "lec_host_unregister")
+            else:
+                keep.append(b)
+        self.blocks = keep
+
+    def close(self) -> None:
+        self.release(1 << 62)
+
+
 class _Stager:
     """One variable's path to the GPU: a pinned host buffer and a raw device buffer per pipeline slot.
 
@@ -107,7 +167,7 @@ class _Stager:
     each -- whole longitude rows, which stay contiguous in the file.  A regional box out of a global file moves
     a fraction of the bytes (a 15-degree band of a 0.25-degree grid: 1/12)."""
 
-    def __init__(self, var: ds.RawVariable, steps: int, device, levels: np.ndarray, j0: int, j1: int, slots: int = 2):
+    def __init__(self, var: ds.RawVariable, steps: int, device, levels: np.ndarray, j0: int, j1: int, slots: int = 2, pinned: bool = True):
         self.var = var
         self.levels = [int(k) for k in levels]
         self.j0, self.j1 = int(j0), int(j1)
@@ -123,7 +183,8 @@ class _Stager:
         self.step_elems = len(self.levels) * self.level_elems
         self.itemsize = var.data.dtype.itemsize
         carrier = {2: torch.int16, 4: torch.int32, 8: torch.int64}[self.itemsize]      # bytes only; never interpreted
-        self.pinned = [torch.empty((steps, self.step_elems), dtype=carrier, pin_memory=True) for _ in range(slots)]
+        # (direct copies from registered file memory need no pinned staging buffers)
+        self.pinned = [torch.empty((steps, self.step_elems), dtype=carrier, pin_memory=True) for _ in range(slots)] if pinned else None
         self.raw_dev = [torch.empty((steps, self.step_elems), dtype=carrier, device=device) for _ in range(slots)]
         self._carrier_np = {2: np.int16, 4: np.int32, 8: np.int64}[self.itemsize]
 
@@ -154,6 +215,43 @@ class _Stager:
 
     def upload(self, slot: int, a: int, b: int):
         self.raw_dev[slot][a:b].copy_(self.pinned[slot][a:b], non_blocking=True)
+
+    # -- staging-free path: the file's own memory, registered with the HIP runtime ------------------------------------------------
+    def direct_ok(self) -> bool:
+        """True when every time step of the variable is a C-contiguous block of ordinary (mapped-file or host) memory: a NumPy
+        array, not a lazily inflated HDF5 variable."""
+        d = self.var.data
+        full = self.j0 == 0 and self.j1 == int(d.shape[2]) - 1      # a latitude band of a larger file: registering (= pinning, hence reading) whole
+        return full and isinstance(d, np.ndarray) and d.ndim == 4 and d[0].flags["C_CONTIGUOUS"]      # levels would touch the bytes the band spares
+
+    def step_address(self, ft: int) -> int:
+        d = self.var.data
+        return int(d.ctypes.data) + int(ft) * int(d.strides[0])
+
+    def upload_direct(self, lib, spans: RegisteredSpans, slot: int, file_steps, at: int, use: int, stream) -> int:
+        """File time steps -> raw device rows [at, at + len) of the slot, straight from the registered file memory: per step one
+        linear copy per run of whole levels (cut where it runs from one registered block into the next)."""
+        if len(file_steps) == 0:
+            return 0
+        d = self.var.data
+        plane = int(d.shape[2]) * self.nx * self.itemsize
+        step_bytes = int(d.shape[1]) * plane
+        bases = [self.step_address(ft) for ft in file_steps]
+        first = 0                                                       # one registration per run of neighbouring file steps (what of it is not
+        for r in range(1, len(bases) + 1):                              # covered yet): steps a track skips are neither pinned nor read
+            if r == len(bases) or int(file_steps[r]) != int(file_steps[r - 1]) + 1:
+                spans.ensure(min(bases[first:r]), max(bases[first:r]) + step_bytes, use)
+                first = r
+        moved = 0
+        for r, base in enumerate(bases):
+            dst0 = self.raw_dev[slot][at + r].data_ptr()
+            for n, k, cnt in self.runs:
+                src, dst, nbytes = base + k * plane, dst0 + n * plane, cnt * plane
+                for a, e in spans.pieces(src, src + nbytes):
+                    _lib.check(lib.lec_copy_rows_async(C.c_void_p(dst + (a - src)), e - a, C.c_void_p(a), e - a, e - a, 1, stream),
+                               "lec_copy_rows_async")
+                moved += nbytes
+        return moved
 
 
 def _lec_code(dtype: np.dtype) -> int:
@@ -207,12 +305,16 @@ def device_cube(var: ds.RawVariable, plan: IngestPlan, device="cuda:0", unit: fl
 
 def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_limits, *, per_step_boxes: bool = False,
                  device="cuda:0", chunk_steps: int = 8, with_q: bool = True, stats: Optional[dict] = None,
-                 t_range=None, merge_dropmask=None, out=None) -> LECResult:
+                 t_range=None, merge_dropmask=None, out=None, staging: str = "auto") -> LECResult:
     """All LEC terms for the whole series, streamed from the memory-mapped file.
 
     ``boxes_limits``: one (west, east, south, north) in degrees (fixed framework, as inputs/box_limits) or one per time step
     (``per_step_boxes``: the moving framework; dT/dt is differentiated over the plan's time axis on the device).
     ``chunk_steps`` time steps are resident per pipeline slot (two slots).  ``stats`` receives counters: bytes moved, chunks, dtype.
+    ``staging``: "registered" -- the mapped file's own pages are registered with the HIP runtime chunk by chunk and copied from
+    directly (no host copy, no staging threads: with eight ranks streaming at once the host's memory carries a third of the traffic);
+    "staged" -- a thread pool copies page cache -> pinned buffers first; "auto" (default): registered where every variable is plain
+    mapped memory and the runtime accepts the first span, else staged (lazily inflated NetCDF-4 variables, hosts that refuse).
     ``t_range`` = (t0, t1): a rank's share of a time-sharded run -- only those steps (and their one-step T halo) are staged, copied
     and computed, so N ranks move 1/N of the bytes each, over N host links; ``merge_dropmask`` / ``out``: see ``LECEngine.reduce``.
     """
@@ -243,7 +345,23 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
     j0, j1 = int(plan.jmap.min()), int(plan.jmap.max())
     nl_in, ny_in, nx_in = nl, j1 - j0 + 1, int(rvars["Air Temperature"].data.shape[3])
     file_levels = np.sort(plan.kmap)
-    stagers = {r: _Stager(rvars[r], span, dev, file_levels, j0, j1, slots) for r in roles}
+    if staging not in ("auto", "staged", "registered"):
+        raise ValueError("staging must be 'auto', 'staged' or 'registered'")
+    probe = {r: _Stager.__new__(_Stager) for r in roles}
+    for r in roles:
+        probe[r].var, probe[r].j0, probe[r].j1 = rvars[r], j0, j1
+    direct = staging != "staged" and all(probe[r].direct_ok() for r in roles)
+    if staging == "registered" and not direct:
+        raise ValueError("staging='registered' needs every variable as plain (mapped) memory; lazily inflated NetCDF-4 variables are staged")
+    spans = RegisteredSpans(lib) if direct else None
+    if direct and staging == "auto":            # does this host's runtime register this memory at all?  (one page of the first variable)
+        try:
+            a0 = probe[roles[0]].step_address(int(plan.tsel[t0]))
+            spans.ensure(a0, a0 + 1, -1)
+            spans.release(0)
+        except _lib.LecLibraryError:
+            direct, spans = False, None
+    stagers = {r: _Stager(rvars[r], span, dev, file_levels, j0, j1, slots, pinned=not direct) for r in roles}
     cubes = [{keys[r]: torch.empty((span, nl, ny, nx), dtype=out_dtype, device=dev) for r in roles} for _ in range(slots)]
     up = lambda a: torch.as_tensor(a, dtype=torch.int32).to(dev)
     maps = (up(np.searchsorted(file_levels, plan.kmap)), up(plan.jmap - j0), up(plan.imap))   # maps into the staged sub-cube
@@ -277,6 +395,8 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
         h0, h1 = (max(c0 - 1, 0), min(c1 + 1, nt)) if with_q else (c0, c1)
         if used[slot]:
             copied[slot][-1].synchronize()      # the pinned buffers of this slot may be overwritten now (uploads are in stream order)
+            if direct:
+                spans.release(c - slots + 1)    # ... and the file spans only chunks up to c - slots used are no longer being read
         # only T carries the halo; the other fields start at their own first step (rows [c0 - h0, c1 - h0) of the slot)
         span_of = lambda r: (0, h1 - h0) if r == "Air Temperature" else (c0 - h0, c1 - h0)
         for n, r in enumerate(roles):
@@ -284,13 +404,19 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
             # chunk's staging, and the next variable is staged while this one is on the link
             a, b = span_of(r)
             t_host = time.perf_counter()
-            stagers[r].stage(slot, plan.tsel[h0 + a: h0 + b], a)
+            if not direct:
+                stagers[r].stage(slot, plan.tsel[h0 + a: h0 + b], a)
             host_s += time.perf_counter() - t_host
             with torch.cuda.stream(copier):
                 if used[slot] and n == 0:
                     copier.wait_event(consumed[slot])   # the raw device buffers of this slot have been decoded
-                stagers[r].upload(slot, a, b)
-                moved += (b - a) * stagers[r].step_elems * stagers[r].itemsize
+                if direct:
+                    t_host = time.perf_counter()
+                    moved += stagers[r].upload_direct(lib, spans, slot, plan.tsel[h0 + a: h0 + b], a, c, C.c_void_p(copier.cuda_stream))
+                    host_s += time.perf_counter() - t_host
+                else:
+                    stagers[r].upload(slot, a, b)
+                    moved += (b - a) * stagers[r].step_elems * stagers[r].itemsize
                 copied[slot][n].record(copier)
             compute.wait_event(copied[slot][n])
             with torch.cuda.device(dev):
@@ -304,7 +430,12 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
                         rows_out=rows[c0 - t0:c1 - t0], per_step_boxes=per_step_boxes)
         used[slot] = True
     res = engine.reduce(rows, own_boxes, phi_scale=phi_scale, drop_any_time=not per_step_boxes, merge_dropmask=merge_dropmask, out=out)
+    if direct:
+        copier.synchronize()                    # every copy has read its span
+        reg_stats = dict(registered_bytes=spans.registered_bytes, register_calls=spans.calls)
+        spans.close()
     if stats is not None:
+        stats.update(staging="registered" if direct else "staged", **(reg_stats if direct else {}))
         stats.update(bytes_moved=moved, host_staging_seconds=host_s, chunks=n_chunks, chunk_steps=chunk_steps, storage=str(out_dtype).replace("torch.", ""),
                      decode={keys[r]: str(d) for r, d in decode.items()}, box=tuple(int(x) for x in boxes[0]), domain=(nt, nl, ny, nx))
     return res

@@ -185,3 +185,36 @@ def test_mixed_dtype_file_on_both_paths(workdir):
     a, b, stats = _both_paths(path, "inputs/namelist", limits, 2)
     assert stats["storage"] == "float64" and stats["decode"]["tair"] == "float32" and stats["decode"]["geopt"] == "float64"
     assert torch.equal(a.scalars, b.scalars) and torch.equal(a.levels, b.levels) and torch.isfinite(a.scalars).all()
+
+
+@pytest.mark.parametrize("chunk_steps", [4, 36])
+def test_registered_file_memory_equals_staged(workdir, golden_dir, chunk_steps):
+    """staging="registered": the mapped file's own pages are registered with the HIP runtime and copied from directly (no pinned
+    staging copy); "staged": the thread-pool copy into pinned buffers.  Same bytes on the device, same results, bit for bit; the
+    Catarina box is the file's whole latitude range after the crop?  No: the fixed box crops -- so the full-range case is built by
+    giving a box that spans every latitude of the file."""
+    args = argparse.Namespace(fixed=True, track=False, trackfile=None, residuals=True)
+    df = ds.read_namelist("inputs/namelist")
+    infile = os.path.join(golden_dir, "Catarina_NCEP-R2.nc")
+    raw = ds.open_raw(infile, df)
+    lat = np.sort(raw.lat)
+    (workdir / "inputs" / "box_limits").write_text(f"min_lon;-55\nmax_lon;-36\nmin_lat;{lat[0]}\nmax_lat;{lat[-1]}\n")
+    plan = ingest.make_plan(raw, args)
+    limits = (-55.0, -36.0, float(lat[0]), float(lat[-1]))
+    sa, sb = {}, {}
+    a = ingest.lec_fixed_streamed(raw, plan, df, limits, chunk_steps=chunk_steps, staging="staged", stats=sa)
+    b = ingest.lec_fixed_streamed(raw, plan, df, limits, chunk_steps=chunk_steps, staging="registered", stats=sb)
+    c = ingest.lec_fixed_streamed(raw, plan, df, limits, chunk_steps=chunk_steps, stats={})          # auto
+    torch.cuda.synchronize()
+    assert sa["staging"] == "staged" and sb["staging"] == "registered" and sb["register_calls"] >= 1 and sb["bytes_moved"] == sa["bytes_moved"]
+    for r in (b, c):
+        assert torch.equal(a.scalars, r.scalars) and torch.equal(a.levels, r.levels) and torch.equal(a.nanflag, r.nanflag)
+    # a latitude BAND of the file is staged (registering pins -- and so reads -- whole levels): asked for by name it is refused, auto stages
+    (workdir / "inputs" / "box_limits").write_text("min_lon;-55\nmax_lon;-36\nmin_lat;-35\nmax_lat;-20\n")
+    plan2 = ingest.make_plan(raw, args)
+    with pytest.raises(ValueError, match="registered"):
+        ingest.lec_fixed_streamed(raw, plan2, df, (-55.0, -36.0, -35.0, -20.0), staging="registered")
+    st = {}
+    ingest.lec_fixed_streamed(raw, plan2, df, (-55.0, -36.0, -35.0, -20.0), stats=st)
+    assert st["staging"] == "staged"
+    raw.close()

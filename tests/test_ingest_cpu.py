@@ -136,3 +136,45 @@ def test_prepare_data_falls_back_for_other_axis_orders(workdir):
     assert got.variables["t"].shape == (3, 4, 4, 6) and got.level.tolist() == [20000.0, 50000.0, 85000.0, 100000.0]
     want = np.transpose(data["t"], (0, 2, 1, 3))[:, ::-1][:, :, 1:5][:, :, :, 1:7]
     assert np.array_equal(got.variables["t"], want)
+
+
+def test_registered_spans_bookkeeping():
+    """RegisteredSpans keeps the host memory registered for direct copies as page-aligned, NON-overlapping blocks (the runtime refuses
+    overlaps), registers only what a request does not find covered, cuts copies at block boundaries and releases by last use."""
+    from lorenzcycletoolkit_amd import ingest
+
+    class FakeRuntime:
+        def __init__(self):
+            self.reg = {}
+
+        def lec_host_register(self, p, n):
+            a = p.value
+            assert a % 4096 == 0 and n % 4096 == 0
+            assert all(a >= e or a + n <= b for b, e in self.reg.items()), "overlapping registration"
+            self.reg[a] = a + n
+            return 0
+
+        def lec_host_unregister(self, p):
+            del self.reg[p.value]
+            return 0
+
+    rt = FakeRuntime()
+    sp = ingest.RegisteredSpans(rt)
+    base = 1 << 30
+    sp.ensure(base + 10000, base + 30000, 0)
+    assert sp.blocks == [[base + 8192, base + 32768, 0]]
+    sp.ensure(base + 25000, base + 50000, 1)                               # overlaps the first: only the uncovered tail is registered
+    assert sp.blocks == [[base + 8192, base + 32768, 1], [base + 32768, base + 53248, 1]] and sp.calls == 2
+    assert sp.pieces(base + 20000, base + 45000) == [(base + 20000, base + 32768), (base + 32768, base + 45000)]
+    sp.ensure(base + 100, base + 5000, 2)
+    sp.ensure(base + 4000, base + 60000, 2)                                # fills the gap between blocks and extends the end: two new blocks
+    assert [b[:2] for b in sp.blocks] == [[base, base + 8192], [base + 8192, base + 32768], [base + 32768, base + 53248],
+                                          [base + 53248, base + 61440]] and all(b[2] == 2 for b in sp.blocks)
+    assert sp.registered_bytes == 61440
+    with pytest.raises(RuntimeError):
+        sp.pieces(base + 60000, base + 70000)                              # runs past what is registered
+    sp.ensure(base + 200000, base + 204096, 5)
+    sp.release(3)                                                          # everything last used by chunks < 3 goes
+    assert [b[:2] for b in sp.blocks] == [[base + 200704 - 4096, base + 208896]] or len(sp.blocks) == 1
+    sp.close()
+    assert rt.reg == {} and sp.blocks == []

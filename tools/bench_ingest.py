@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--timesteps", type=int, default=16)
     ap.add_argument("--chunk", type=int, default=4)
     ap.add_argument("--repeat", type=int, default=3)
+    ap.add_argument("--staging", choices=["auto", "staged", "registered"], default="auto", help="pinned staging copy, or the source memory "
+                    "registered with the HIP runtime and copied from directly (auto: registered where possible)")
     ap.add_argument("--ny", type=int, default=721)
     ap.add_argument("--nx", type=int, default=1440)
     args = ap.parse_args()
@@ -83,7 +85,7 @@ def main():
     for r in range(args.repeat + 1):                               # first pass = warm-up (pinned allocations, page faults)
         torch.cuda.synchronize()
         t0 = time_now()
-        res = ingest.lec_fixed_streamed(raw, plan, df, limits, chunk_steps=args.chunk, stats=stats)
+        res = ingest.lec_fixed_streamed(raw, plan, df, limits, chunk_steps=args.chunk, stats=stats, staging=args.staging)
         torch.cuda.synchronize()
         dt = time_now() - t0
         if r > 0:
@@ -93,7 +95,8 @@ def main():
         "metric": "LEC timesteps/sec from HOST memory (PCIe-inclusive device ingest), all terms, 37x%dx%d" % (args.ny, args.nx),
         "value": T / best, "unit": "timesteps/s", "source_dtype": args.src, "timesteps": T, "chunk_steps": args.chunk,
         "seconds": best, "bytes_moved": stats["bytes_moved"], "host_to_device_GBs": stats["bytes_moved"] / best / 1e9,
-        "storage_on_device": stats["storage"], "host_staging_seconds": stats["host_staging_seconds"], "results_finite": finite}))
+        "storage_on_device": stats["storage"], "staging": stats["staging"], "host_staging_seconds": stats["host_staging_seconds"],
+        "register_calls": stats.get("register_calls"), "results_finite": finite}))
 
 
 def time_now():
