@@ -209,12 +209,15 @@ def test_registered_file_memory_equals_staged(workdir, golden_dir, chunk_steps):
     assert sa["staging"] == "staged" and sb["staging"] == "registered" and sb["register_calls"] >= 1 and sb["bytes_moved"] == sa["bytes_moved"]
     for r in (b, c):
         assert torch.equal(a.scalars, r.scalars) and torch.equal(a.levels, r.levels) and torch.equal(a.nanflag, r.nanflag)
-    # a latitude BAND of the file is staged (registering pins -- and so reads -- whole levels): asked for by name it is refused, auto stages
-    (workdir / "inputs" / "box_limits").write_text("min_lon;-55\nmax_lon;-36\nmin_lat;-35\nmax_lat;-20\n")
+    raw.close()
+    # a latitude BAND of a larger file is staged (registering pins -- and so reads -- whole levels): asked for by name it is refused, auto stages
+    raw = ds.open_raw(os.path.join(golden_dir, "testdata_NCEP-R2.nc"), df)
+    (workdir / "inputs" / "box_limits").write_text("min_lon;-60\nmax_lon;-30\nmin_lat;-42.5\nmax_lat;-17.5\n")
     plan2 = ingest.make_plan(raw, args)
+    assert plan2.lat.size < raw.lat.size
     with pytest.raises(ValueError, match="registered"):
-        ingest.lec_fixed_streamed(raw, plan2, df, (-55.0, -36.0, -35.0, -20.0), staging="registered")
+        ingest.lec_fixed_streamed(raw, plan2, df, (-60.0, -30.0, -42.5, -17.5), staging="registered")
     st = {}
-    ingest.lec_fixed_streamed(raw, plan2, df, (-55.0, -36.0, -35.0, -20.0), stats=st)
+    ingest.lec_fixed_streamed(raw, plan2, df, (-60.0, -30.0, -42.5, -17.5), stats=st)
     assert st["staging"] == "staged"
     raw.close()
