@@ -197,6 +197,17 @@ class SeriesGatherer:
             if self.receives:
                 self._hrecv = [torch.empty((self.world, self.width, self.ncol), **hostkw) for _ in range(self.slots)]
 
+    def _switch_to_all_gather(self) -> None:
+        kw = dict(dtype=self._send[0].dtype, device=self.device)
+        self.to_all = True
+        had = self.receives
+        if not had:
+            self._recv = [torch.empty((self.world, self.width, self.ncol), **kw) for _ in range(self.slots)]
+            if self.staged:
+                self._hrecv = [torch.empty((self.world, self.width, self.ncol), dtype=kw["dtype"], device="cpu", pin_memory=True) for _ in range(self.slots)]
+        self._hands_out = had                      # the ranks that were to receive still do; the others drop what arrives
+        self.receives = True
+
     # -- buffers ------------------------------------------------------------------------------------------------------------
     def send(self, slot: int = 0) -> torch.Tensor:
         """The slot's send buffer, this rank's own rows.  Waits (on the stream, not the host) for the collective that last read it."""
@@ -240,7 +251,16 @@ class SeriesGatherer:
         else:
             glist = list(dstbuf.unbind(0)) if self.rank == self.dst else None
             dst_global = dist.get_global_rank(self.group, self.dst) if self.group is not None else self.dst
-            self._work[slot] = dist.gather(src, glist, dst=dst_global, group=self.group, async_op=True)
+            try:
+                self._work[slot] = dist.gather(src, glist, dst=dst_global, group=self.group, async_op=True)
+            except (NotImplementedError, RuntimeError) as e:
+                # a backend without gather (every rank gets the same exception at the same call, before anything is enqueued):
+                # from here on every rank receives the series through an all_gather; only `dst` hands it out
+                if "gather" not in str(e).lower() and not isinstance(e, NotImplementedError):
+                    raise
+                self._switch_to_all_gather()
+                self.start(slot)
+                return
         if self.profile is not None:
             self._work[slot].wait()
             self._work[slot] = None
@@ -256,7 +276,7 @@ class SeriesGatherer:
         t = time.perf_counter() if self.profile is not None else 0.0
         self.wait(slot)
         t = self._tick("collective", t)
-        if not self.receives:
+        if not self.receives or not getattr(self, "_hands_out", True):
             return None
         buf = self._recv[slot]
         if self.staged:

@@ -77,6 +77,24 @@ def _worker(rank, world, port, n_steps, out_dir):
             np.save(os.path.join(out_dir, "passes.npy"), np.stack([x.numpy() for x in got]))
         else:
             assert all(x is None for x in got)
+        # a backend without gather: the gatherer switches to an all_gather on the first call, rank 0 still gets the series, the others None
+        real_gather = dist.gather
+
+        def no_gather(*a, **k):
+            raise NotImplementedError("gather is not implemented by this backend")
+        dist.gather = no_gather
+        try:
+            g2 = SeriesGatherer(n_steps, 3, "cpu", dst=0, slots=1)
+            g2.send(0)[:] = local
+            g2.start(0)
+            s2 = g2.finish(0)
+            assert g2.to_all
+            if rank == 0:
+                np.save(os.path.join(out_dir, "fallback.npy"), s2.numpy())
+            else:
+                assert s2 is None
+        finally:
+            dist.gather = real_gather
     finally:
         dist.destroy_process_group()
 
@@ -94,6 +112,7 @@ def test_gather_timeseries_gloo(tmp_path, world, n_steps):
     for r in range(world):
         assert np.array_equal(np.load(tmp_path / f"full_{r}.npy"), want)
         assert np.array_equal(np.load(tmp_path / f"mask_{r}.npy"), want_mask)
+    assert np.array_equal(np.load(tmp_path / "fallback.npy"), want)
     passes = np.load(tmp_path / "passes.npy")
     assert passes.shape == (3, n_steps, 4)
     for p in range(3):
