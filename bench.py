@@ -320,6 +320,7 @@ def run_rank(args):
             f["geopt"] = None
         return h0, h1, f
 
+    tc_all = eng.time_coefs_device(time_s) if with_q else None      # d/dt coefficients of the whole axis on the device: no upload per call
     held = generate(*chunks[0]) if resident else None
     # Everything a pass writes is allocated ONCE, here: the row records, the NaN counters, and (SeriesGatherer) the send / receive
     # buffers of the gather in two pipeline slots.  lec_reduce writes its packed [T_local, 16 + 21 nl] records straight into the
@@ -374,7 +375,7 @@ def run_rank(args):
         if resident:
             h0, h1, f = held
             timing = [] if record else None
-            eng.rowstats(f["tair"], f["u"], f["v"], f["omega"], f["geopt"], all_boxes, time_s=time_s[h0:h1] if with_q else None,
+            eng.rowstats(f["tair"], f["u"], f["v"], f["omega"], f["geopt"], all_boxes, tcoef=tc_all[h0:h1] if with_q else None,
                          t_begin=t0 - h0, t_count=T_local, timing=timing, rows_out=rows, **stage1)
             if record:
                 kernel_ms.extend(timing)
@@ -387,7 +388,7 @@ def run_rank(args):
                 gen_s[0] += time.perf_counter() - g0
                 timing = [] if record else None
                 tic = time.perf_counter()
-                eng.rowstats(f["tair"], f["u"], f["v"], f["omega"], f["geopt"], chunk_boxes[(a, b)], time_s=time_s[h0:h1] if with_q else None,
+                eng.rowstats(f["tair"], f["u"], f["v"], f["omega"], f["geopt"], chunk_boxes[(a, b)], tcoef=tc_all[h0:h1] if with_q else None,
                              t_begin=a - h0, t_count=b - a, timing=timing, rows_out=rows[a - t0:b - t0], **stage1)
                 torch.cuda.synchronize()
                 timed += time.perf_counter() - tic

@@ -23,3 +23,5 @@ run g2f  python3 $R/bench.py --gpus 2 --timesteps 8 --cpu-baseline none --steps 
 LEC_DIST_BACKEND=nccl run n1m4096 python3 $R/bench.py --force-dist --moving --timesteps-global 4096 --cpu-baseline none --steps 10 --warmup 2 &&
 LEC_DIST_BACKEND=nccl run n1m512 python3 $R/bench.py --force-dist --moving --timesteps-global 512 --cpu-baseline none --steps 20 --warmup 3 &&
 LEC_DIST_BACKEND=nccl run n1f  python3 $R/bench.py --force-dist --timesteps 16 --cpu-baseline none --steps 5 --warmup 2
+LEC_DIST_BACKEND=gloo run g2chunk python3 $R/bench.py --gpus 2 --timesteps-global 12 --chunk 3 --ny 61 --nx 128 --cpu-baseline none --steps 2 --warmup 1
+LEC_DIST_BACKEND=gloo run g3mchunk python3 $R/bench.py --gpus 3 --moving --timesteps-global 50 --chunk 7 --cpu-baseline none --steps 2 --warmup 1
