@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box: (1) the round-2 bench (tools/probes/old_r02, instrumented) on the configuration of gpurun_out/g4m.json;
+# GPU box: (1) the round-2 bench (git archive 2ae2ab4 into tools/probes/old_r02, built there, one_pass instrumented: see profiles/r03_notes.md section 1) on the configuration of gpurun_out/g4m.json;
 # (2) the ingest copy pipeline's timeline in its variants.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
