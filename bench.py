@@ -196,7 +196,8 @@ def cpu_baseline_and_parity(kind, eng, held, lat, lon, level, time_s, device):
         dt, ref_s, ref_l = _oracle_run(host, lat, lon, level, ts, limits)
         reps.append(dt)
     worst, worst_term = 0.0, ""
-    for name in ("Az", "Ae", "Kz", "Ke", "Cz", "Ca", "Ck", "Ce", "BAz", "BAe", "BKz", "BKe", "Gz", "Ge"):     # lec_fixed drops BPhiZ / BPhiE
+    names = ("Az", "Ae", "Kz", "Ke", "Cz", "Ca", "Ck", "Ce", "BAz", "BAe", "BKz", "BKe", "BΦZ", "BΦE", "Gz", "Ge")      # all 16 (the results
+    for name in names:                                                                                                  # CSV of lec_fixed drops the two BPhi)
         e = _scale_err(got_s[name], ref_s[name])
         if e > worst:
             worst, worst_term = e, name
@@ -209,7 +210,7 @@ def cpu_baseline_and_parity(kind, eng, held, lat, lon, level, time_s, device):
         if e > lworst:
             lworst, lworst_term = e, name
     parity = {"worst_rel_to_scale": worst, "term": worst_term, "levels_worst_rel_to_scale": lworst, "levels_term": lworst_term,
-              "steps": nt, "terms_compared": 14, "level_tables_compared": len(ref_l),
+              "steps": nt, "terms_compared": len(names), "level_tables_compared": len(ref_l),
               "box": f"lon [{limits[0]}, {limits[1]}] lat [{limits[2]}, {limits[3]}] ({box[3] - box[2] + 1} x {box[1] - box[0] + 1} points)",
               "data": "the first %d time steps of the resident synthetic cube the GPU was timed on, copied to the host" % nt,
               "checker": "oracle/lec_oracle.py (NumPy fp64 restatement of the reference's un-factored formulas)", "tolerance": 1e-9,

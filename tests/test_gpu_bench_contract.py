@@ -45,7 +45,7 @@ def test_bench_json_contract():
     # the CPU leg is also the line's parity check: the oracle evaluated steps of the cube the GPU was timed on
     pr = d["parity"]
     assert pr["ok"] is True and pr["worst_rel_to_scale"] <= 1e-9 and pr["levels_worst_rel_to_scale"] <= 1e-9
-    assert pr["steps"] == 2 and pr["terms_compared"] == 14 and pr["level_tables_compared"] == 21 and "59 x 128" in pr["box"]     # polar rows left out
+    assert pr["steps"] == 2 and pr["terms_compared"] == 16 and pr["level_tables_compared"] == 21 and "59 x 128" in pr["box"]     # polar rows left out
     # where a pass's time goes
     sg = d["config"]["segments_ms"]
     for k in ("stage1", "stage2", "gather", "pass_total_synchronised", "pass_timed_unsynchronised", "stage1_kernels_hip_events", "fixed_cost_per_pass"):
