@@ -215,17 +215,28 @@ __global__ void __launch_bounds__(kThreads, (sweep_min_waves<TIN, VEC, MODE>()))
         load_vec<TIN, VEC, true>(rW - shift, eo, d.fW);
         load_vec<TIN, VEC, true>(rP - shift, eo, d.fP);
         if (WITH_Q) {
+#if LEC_EXPERIMENT_PREFETCH == 1
             load_vec<TIN, VEC, false>(rTjm - shift, eo, d.qr.j0);
             load_vec<TIN, VEC, false>(rTjp - shift, eo, d.qr.j1);
             load_vec<TIN, VEC, false>(rTkm - shift, eo, d.qr.k0);
             load_vec<TIN, VEC, false>(rTkp - shift, eo, d.qr.k1);
+#endif
             load_vec<TIN, VEC, false>(rTtp - shift, eo, d.qr.tf);
             d.sl = rT[min(max(el - 1, 0), nxb - 1)];
             d.sr = rT[min(max(el + nthr * VEC, 0), nxb - 1)];
         }
     };
-    auto compute = [&](const TripData& d, const int it) {
+    auto compute = [&](TripData& d, const int it) {
         const int e0 = it * nthr * VEC - shift + tid * VEC;
+#if LEC_EXPERIMENT_PREFETCH == 2      // only the streamed operands run ahead; the four stencil rows (L2 hits) are fetched when the trip is computed
+        if (WITH_Q) {
+            const unsigned eo = (unsigned)(min(e0, e0_last) + shift);
+            load_vec<TIN, VEC, false>(rTjm - shift, eo, d.qr.j0);
+            load_vec<TIN, VEC, false>(rTjp - shift, eo, d.qr.j1);
+            load_vec<TIN, VEC, false>(rTkm - shift, eo, d.qr.k0);
+            load_vec<TIN, VEC, false>(rTkp - shift, eo, d.qr.k1);
+        }
+#endif
         const double tl_edge = from_prev_lane((double)d.fT[VEC - 1], (double)d.sl);
         const double tr_edge = from_next_lane((double)d.fT[0], (double)d.sr);
         if (e0 <= e0_last) sweep_elems<VEC, UNIFORM, false, MODE, BOTH>(acc, xacc, r, e0, true, d.fT, d.fU, d.fV, d.fW, d.fP, tl_edge, tr_edge, d.qr, qc);
@@ -255,12 +266,11 @@ __global__ void __launch_bounds__(kThreads, (sweep_min_waves<TIN, VEC, MODE>()))
             compute(B, it + 1);
         }
     }
-    if (false)
+    (void)trip;
 #else
     // a real loop (not unrolled): the live state stays at the 20 accumulators plus one vector's worth of
     // operands, which is what lets 4 waves/SIMD fit.  Trips [1, mid_end) lie strictly inside the row.
     const int ntrips = ONE_TRIP ? 1 : p.ntrips;      // short rows (moving boxes): one trip, no loop
-#endif
     trip(std::true_type{}, 0);
     if (!ONE_TRIP) {
         const int mid_end = min((nxb - 1 + shift) / (nthr * VEC), ntrips);
@@ -269,6 +279,7 @@ __global__ void __launch_bounds__(kThreads, (sweep_min_waves<TIN, VEC, MODE>()))
 #pragma unroll 1
         for (int it = max(mid_end, 1); it < ntrips; ++it) trip(std::true_type{}, it);
     }
+#endif
 
     finish_row<NTHR, kRound, MODE == 3>(acc, xacc, red, tot, tid, UNIFORM ? h_rad * inv_xlen : inv_xlen, r, out);
     // T, u, v at the west / east box columns (boundary terms): wave-uniform scalar loads
