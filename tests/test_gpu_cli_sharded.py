@@ -122,8 +122,12 @@ def test_under_the_torch_launcher(workdir, golden_dir):
     results = workdir / "LEC_Results" / "Catarina_NCEP-R2_fixed"
     _run([infile, "-r", "-f", "-o", "one"])
     one = open(results / "one.csv", "rb").read()
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
     launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                "--master-port", "29731"]
+                "--master-port", str(port)]
     _run([infile, "-r", "-f", "-o", "two"], launcher=launcher)
     assert open(results / "two.csv", "rb").read() == one
 
