@@ -1,0 +1,130 @@
+#!/usr/bin/env python3
+"""Randomised parity soak on the GPU box (not collected by pytest: run by hand, `python tests/soak_gpu.py --cases 300 --seed 1`).
+
+Every case draws a grid, a storage dtype, uniform or stretched longitudes, fixed or per-step boxes anywhere in the grid (edges and
+one-vector-wide boxes included), an even or uneven time axis and, now and then, NaN patches; then
+  * every kernel family that can run the case must agree record by record (row_sweep vs two_sweep vs row_block / box_tile),
+  * the terms must agree with the oracle (1e-9 of scale) -- the oracle is test infrastructure, hence this file lives under tests/,
+  * shards of the series must reproduce the whole bit for bit.
+Prints one line per failure and a summary; exit code 1 if anything failed."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from lorenzcycletoolkit_amd.engine import LECEngine  # noqa: E402
+from oracle import lec_oracle as o  # noqa: E402
+from tests.helpers import SCALARS, as_f64, scale_err, synthetic_domain  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).to(DEV)
+
+
+def rows_close(a, b, tol=2e-11):
+    ra, rb = a.rows[..., :28], b.rows[..., :28]
+    den = rb.abs().amax(dim=(0, 1, 2)).clamp_min(1e-300)
+    bad = torch.isnan(ra) != torch.isnan(rb)
+    if bool(bad.any()):
+        return float("inf")
+    d = torch.where(torch.isnan(rb), torch.zeros_like(rb), (ra - rb).abs())
+    return float((d.amax(dim=(0, 1, 2)) / den).max())
+
+
+def one_case(rng, case, with_oracle):
+    nt = int(rng.integers(2, 7))
+    nl = int(rng.choice([2, 3, 5, 8, 13, 22, 37]))
+    ny = int(rng.integers(4, 70))
+    nx = int(rng.choice([8, 16, 31, 64, 65, 96, 127, 128, 129, 200, 256, 257, 300]))
+    dtype = np.float32 if rng.random() < 0.4 else np.float64
+    nonuni = bool(rng.random() < 0.25)
+    moving = bool(rng.random() < 0.45)
+    dom = synthetic_domain(nt, nl, ny, nx, seed=int(rng.integers(1 << 30)), dtype=dtype, nonuniform_lon=nonuni,
+                           dt_s=float(rng.choice([3600.0, 21600.0])))
+    if rng.random() < 0.4:
+        dom.time_s = np.cumsum(rng.integers(1, 4, nt) * 3600.0)
+    nan_case = bool(rng.random() < 0.15) and not moving
+    if nan_case:
+        k = int(rng.integers(0, nl))
+        j0, i0 = int(rng.integers(0, ny - 1)), int(rng.integers(0, nx - 2))
+        dom.omega[int(rng.integers(0, nt)), k, j0:j0 + 2, i0:i0 + 3] = np.nan
+
+    def box():
+        wx, wy = int(rng.integers(2, nx + 1)), int(rng.integers(2, ny + 1))
+        if rng.random() < 0.3:
+            wx = min(nx, int(rng.choice([2, 3, 4, 5, 8, 63, 64, 65, 128])))
+        iw, js = int(rng.integers(0, nx - wx + 1)), int(rng.integers(0, ny - wy + 1))
+        if rng.random() < 0.3:
+            iw = 0 if rng.random() < 0.5 else nx - wx
+        return (iw, iw + wx - 1, js, js + wy - 1)
+
+    boxes = [box() for _ in range(nt)] if moving else [box()]
+    eng = LECEngine(dom.lat, dom.lon, dom.level, device=DEV)
+    f = [dev(a) for a in (dom.tair, dom.u, dom.v, dom.omega, dom.geopt)]
+    kw = dict(time_s=dom.time_s, keep_rows=True, per_step_boxes=moving)
+    what = f"case {case}: nt={nt} nl={nl} {ny}x{nx} {np.dtype(dtype).name} nonuni={nonuni} moving={moving} nan={nan_case} boxes={boxes}"
+    fails = []
+    auto = eng.compute(*f, boxes, **kw)
+    fams = ["row_sweep", "two_sweep"] + (["box_tile"] if moving else ["row_block", "box_tile"])
+    for fam in fams:
+        try:
+            r = eng.compute(*f, boxes, tuning={"kernel": fam}, **kw)
+        except Exception as e:      # two_sweep has a row-length limit only far above these sizes: anything raised is a failure
+            fails.append(f"{what}: {fam} raised {e!r}")
+            continue
+        err = rows_close(r, auto)
+        if not err <= 2e-11:
+            fails.append(f"{what}: {fam} differs from the default family by {err:.3e}")
+    # shards of the series: bit-identical
+    if nt >= 3:
+        a, b = 1, nt - 1
+        part = eng.compute(*f, boxes[a:b] if moving else boxes, time_s=dom.time_s, t_begin=a, t_count=b - a, keep_rows=True,
+                           per_step_boxes=moving, drop_any_time=(False if (nan_case or moving) else None))
+        whole = auto if not nan_case else eng.compute(*f, boxes, drop_any_time=False, **kw)
+        nyb = part.rows.shape[2]
+        if not (torch.equal(part.rows[..., :28], whole.rows[a:b, :, :nyb, :28]) and torch.equal(part.scalars, whole.scalars[a:b])):
+            fails.append(f"{what}: shard [{a}, {b}) is not bit-identical to the whole")
+    if with_oracle and all(b[1] - b[0] >= 2 and b[3] - b[2] >= 2 for b in boxes):      # (2-point-wide boxes: eddy terms vanish to rounding)
+        d64 = as_f64(dom)
+        lim = [(dom.lon[b[0]], dom.lon[b[1]], dom.lat[b[2]], dom.lat[b[3]]) for b in boxes]
+        with np.errstate(all="ignore"):
+            ref_s, _ = o.lec_moving(d64, lim) if moving else o.lec_fixed(d64, *lim[0])
+        got = auto.scalars_dict()
+        for name in SCALARS:
+            if name in ref_s:
+                e = scale_err(got[name], ref_s[name])
+                if not e <= 1e-9:
+                    fails.append(f"{what}: {name} off the oracle by {e:.3e}")
+    torch.cuda.synchronize()
+    return fails
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=200)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--oracle-every", type=int, default=2, help="compare every n-th case with the oracle too (it is the slow part)")
+    args = ap.parse_args()
+    rng = np.random.default_rng(args.seed)
+    t0 = time.time()
+    fails = []
+    for c in range(args.cases):
+        fails += one_case(rng, c, with_oracle=(c % args.oracle_every == 0))
+        if (c + 1) % 25 == 0:
+            print(f"{c + 1} cases, {len(fails)} failures, {time.time() - t0:.0f} s", flush=True)
+    for ln in fails:
+        print("FAIL", ln)
+    print(f"soak: {args.cases} cases, seed {args.seed}: {len(fails)} failures")
+    sys.exit(1 if fails else 0)
+
+
+if __name__ == "__main__":
+    main()
