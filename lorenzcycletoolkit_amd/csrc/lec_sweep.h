@@ -135,15 +135,19 @@ __device__ __forceinline__ void sweep_one(const int q, double (&acc)[kNA], doubl
         if (QMODE == 3) {
             // the product a * a+ is rounded before it is weighted, so the row at t and the row at t+1 (as its backward
             // covariance) form bit-identical sums: results do not depend on where a shard or a chunk starts
+            // ... and the weighted sum of the neighbour row's deviations is formed exactly like the row's own <a> (accum20: the product
+            // w a rounded, then added), because lec_qtime_kernel uses the one in place of the other: <a+> of row t is <a> of row t + 1.
+            // (A fused multiply-add here differs from it in the last bit for weights that are not powers of two -- stretched
+            // longitudes -- and made shards of such a series differ from the whole by an ulp; tests/soak_gpu.py found it.)
             const double af = inside ? (double)qr.tf[q] - r.cTf : 0.0;
             const double pf = a * af;
             if (UNIFORM && !EDGE) { xacc[0] += pf; xacc[1] += af; }
-            else { xacc[0] = fma(w, pf, xacc[0]); xacc[1] = fma(w, af, xacc[1]); }
+            else { xacc[0] = fma(w, pf, xacc[0]); const double waf = w * af; xacc[1] += waf; }
             if (BOTH) {
                 const double ab = inside ? (double)qr.tb[q] - r.cTb : 0.0;
                 const double pb = a * ab;
                 if (UNIFORM && !EDGE) { xacc[2] += pb; xacc[3] += ab; }
-                else { xacc[2] = fma(w, pb, xacc[2]); xacc[3] = fma(w, ab, xacc[3]); }
+                else { xacc[2] = fma(w, pb, xacc[2]); const double wab = w * ab; xacc[3] += wab; }
             }
         }
     }

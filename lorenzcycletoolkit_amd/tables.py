@@ -99,7 +99,11 @@ def build_box_tables(lat_deg: np.ndarray, lon_deg: np.ndarray, boxes: Sequence[S
         raise ValueError("nyb_min exceeds the grid")
     t = BoxTables(box=box, boxtab=np.zeros((nb, 4)), wlon=np.zeros((nb, nxm)), glon=np.zeros((nb, nxm, 3)),
                   lattab=np.zeros((nb, nym, 4)), boxtab2=np.zeros((nb, 4)), lattab2=np.zeros((nb, nym, 8)),
-                  nxb_max=nxm, nyb_max=nym, lon_uniform=True)
+                  nxb_max=nxm, nyb_max=nym, lon_uniform=is_uniform(lon))
+    # (lon_uniform selects the kernels' fast path and is decided on the grid's whole longitude axis, not on the boxes at hand: a
+    # chunk or shard of a moving series may hold only boxes that happen to lie in an evenly spaced part of a stretched grid -- any
+    # two-point-wide box does -- and must still use the formulation the whole series uses, or it differs from it by an ulp;
+    # tests/soak_gpu.py found exactly that.)
     inv_dy = 1.0 / (np.deg2rad(1.0) * RE)      # dy = deg2rad(d lat/d lat) Re, thermodynamics.py:102
     cache = {}
     for b in range(nb):
@@ -115,8 +119,6 @@ def build_box_tables(lat_deg: np.ndarray, lon_deg: np.ndarray, boxes: Sequence[S
         rlon, rlat = np.deg2rad(lo), np.deg2rad(la)
         xlen = rlon[-1] - rlon[0]                                  # box_data.py:128
         ylen = np.sin(rlat[-1]) - np.sin(rlat[0])                  # box_data.py:129-131
-        uni = is_uniform(lo)
-        t.lon_uniform = t.lon_uniform and uni
         n = lo.size
         t.boxtab[b] = (1.0 / xlen, xlen / (n - 1), (n - 1) / (lo[-1] - lo[0]), 0.0)
         t.wlon[b, :n] = trapz_weights(rlon)
