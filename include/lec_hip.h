@@ -55,7 +55,7 @@ extern "C" {
 #define LEC_NLEVFUN 28 /* functions of level that _handle_nans repairs (10 terms + 3 x 6 boundary pieces) */
 #define LEC_NLEVTAB 21 /* Az Ae Kz Ke Ge Gz Cz Cz_1 Cz_2 Ca Ca_1 Ca_2 Ce Ce_1 Ce_2 Ck Ck_1..Ck_5 */
 
-enum lec_dtype { LEC_F64 = 0, LEC_F32 = 1, LEC_I16 = 2 /* lec_ingest source only */ };
+enum lec_dtype { LEC_F64 = 0, LEC_F32 = 1, LEC_I16 = 2, LEC_I32 = 3, LEC_I8 = 4 /* the integers: lec_ingest source only */ };
 
 /* Stage-1 kernel families (lec_tuning.kernel).  Every family writes the same row records; AUTO is what is
  * measured and shipped, the others exist for cross-checks and A/B measurements.  The library reads NO
@@ -205,7 +205,7 @@ typedef struct lec_reduce_args {
  */
 typedef struct lec_ingest_args {
     const void* src_d;          /* device copy of the raw variable bytes for nt time steps */
-    int32_t src_dtype;          /* LEC_I16, LEC_F32 or LEC_F64 */
+    int32_t src_dtype;          /* LEC_I8, LEC_I16, LEC_I32, LEC_F32 or LEC_F64 (int32 values are exact in fp64 only: decode_dtype LEC_F64) */
     int32_t swap_bytes;         /* 1: source is in the opposite byte order (classic NetCDF is big-endian) */
     int32_t nt, nl_in, ny_in, nx_in;
     int32_t nl, ny, nx;         /* output extents */

@@ -16,7 +16,7 @@ LEC_NLEVRAW = 40
 LEC_NSCALAR = 16
 LEC_NLEVTAB = 21
 LEC_NLEVFUN = 28
-LEC_F64, LEC_F32, LEC_I16 = 0, 1, 2
+LEC_F64, LEC_F32, LEC_I16, LEC_I32, LEC_I8 = 0, 1, 2, 3, 4
 
 # enum lec_kernel / enum lec_order (include/lec_hip.h)
 KERNEL_AUTO, KERNEL_TWO_SWEEP, KERNEL_ROW_SWEEP, KERNEL_ROW_BLOCK, KERNEL_BOX_TILE = 0, 1, 2, 3, 4

@@ -27,6 +27,12 @@ __device__ __forceinline__ int16_t load_elem(const int16_t* p, bool swap) {
     if (swap) b = (uint16_t)((b >> 8) | (b << 8));
     return (int16_t)b;
 }
+__device__ __forceinline__ int8_t load_elem(const int8_t* p, bool) { return *p; }
+__device__ __forceinline__ int32_t load_elem(const int32_t* p, bool swap) {
+    uint32_t b = *(const uint32_t*)p;
+    if (swap) b = __builtin_bswap32(b);
+    return (int32_t)b;
+}
 __device__ __forceinline__ float load_elem(const float* p, bool swap) {
     uint32_t b = *(const uint32_t*)p;
     if (swap) b = __builtin_bswap32(b);
@@ -80,7 +86,7 @@ void launch(const IngestParams& p, int out_dtype, long long rows, hipStream_t st
 extern "C" int lec_ingest(const lec_ingest_args* a) {
     if (!a) return lec_set_error(LEC_ERR_ARG, "lec_ingest: null args");
     if (!a->src_d || !a->out_d || !a->kmap_d || !a->jmap_d || !a->imap_d) return lec_set_error(LEC_ERR_ARG, "lec_ingest: null pointer argument");
-    if (a->src_dtype != LEC_I16 && a->src_dtype != LEC_F32 && a->src_dtype != LEC_F64) return lec_set_error(LEC_ERR_ARG, "lec_ingest: src_dtype must be LEC_I16, LEC_F32 or LEC_F64");
+    if (a->src_dtype < LEC_F64 || a->src_dtype > LEC_I8) return lec_set_error(LEC_ERR_ARG, "lec_ingest: src_dtype must be LEC_I8, LEC_I16, LEC_I32, LEC_F32 or LEC_F64");
     if (a->out_dtype != LEC_F64 && a->out_dtype != LEC_F32) return lec_set_error(LEC_ERR_ARG, "lec_ingest: out_dtype must be LEC_F64 or LEC_F32");
     if (a->nt < 1 || a->nl_in < 1 || a->ny_in < 1 || a->nx_in < 1 || a->nl < 1 || a->ny < 1 || a->nx < 1 ||
         a->nl > a->nl_in || a->ny > a->ny_in || a->nx > a->nx_in)
@@ -92,11 +98,14 @@ extern "C" int lec_ingest(const lec_ingest_args* a) {
     p.nt = a->nt; p.nl_in = a->nl_in; p.ny_in = a->ny_in; p.nx_in = a->nx_in; p.nl = a->nl; p.ny = a->ny; p.nx = a->nx;
     p.kmap = a->kmap_d; p.jmap = a->jmap_d; p.imap = a->imap_d;
     if (a->decode_dtype != LEC_F64 && a->decode_dtype != LEC_F32) return lec_set_error(LEC_ERR_ARG, "lec_ingest: decode_dtype must be LEC_F64 or LEC_F32");
-    if (a->decode_dtype == LEC_F32 && a->src_dtype == LEC_F64) return lec_set_error(LEC_ERR_ARG, "lec_ingest: float64 data do not decode to float32");
+    if (a->decode_dtype == LEC_F32 && (a->src_dtype == LEC_F64 || a->src_dtype == LEC_I32))
+        return lec_set_error(LEC_ERR_ARG, "lec_ingest: float64 and int32 data do not decode to float32");
     p.swap = a->swap_bytes; p.has_packing = a->has_packing; p.has_fill = a->has_fill; p.decode_f32 = a->decode_dtype == LEC_F32;
     p.scale = a->scale_factor; p.offset = a->add_offset; p.fill = a->fill_value; p.unit = a->unit_scale;
     hipStream_t st = (hipStream_t)a->stream;
     if (a->src_dtype == LEC_I16) launch<int16_t>(p, a->out_dtype, rows, st);
+    else if (a->src_dtype == LEC_I32) launch<int32_t>(p, a->out_dtype, rows, st);
+    else if (a->src_dtype == LEC_I8) launch<int8_t>(p, a->out_dtype, rows, st);
     else if (a->src_dtype == LEC_F32) launch<float>(p, a->out_dtype, rows, st);
     else launch<double>(p, a->out_dtype, rows, st);
     const hipError_t e = hipGetLastError();

@@ -353,9 +353,9 @@ def open_raw(path: str, variable_list_df: pd.DataFrame) -> RawDataset:
         if tuple(v.dimensions) != want:
             nc.close()
             raise ValueError(f"{names[role]} has dimensions {v.dimensions}; the device ingest needs {want} order")
-        if v.data.dtype.kind not in "if" or v.data.dtype.itemsize not in (2, 4, 8) or (v.data.dtype.kind == "i" and v.data.dtype.itemsize != 2):
+        if v.data.dtype.kind not in "if" or (v.data.dtype.kind, v.data.dtype.itemsize) not in (("i", 1), ("i", 2), ("i", 4), ("f", 4), ("f", 8)):
             nc.close()
-            raise ValueError(f"{names[role]}: the device ingest reads int16, float32 and float64 variables, not {v.data.dtype}")
+            raise ValueError(f"{names[role]}: the device ingest reads int8, int16, int32, float32 and float64 variables, not {v.data.dtype}")
         scale, offset, fill = _packing(v)
         variables[names[role]] = RawVariable(v.data, scale, offset, fill)
     return RawDataset(variables, lat, lon, lev, time, names, level_units, geo_role, nc)

@@ -75,13 +75,13 @@ def prepare_streamed(args, varlist: str = "inputs/namelist", app_logger=None, ch
 
 
 def _src_code(dtype: np.dtype) -> int:
-    if dtype.kind == "i" and dtype.itemsize == 2:
-        return _lib.LEC_I16
+    if dtype.kind == "i" and dtype.itemsize in (1, 2, 4):
+        return {1: _lib.LEC_I8, 2: _lib.LEC_I16, 4: _lib.LEC_I32}[dtype.itemsize]
     if dtype.kind == "f" and dtype.itemsize == 4:
         return _lib.LEC_F32
     if dtype.kind == "f" and dtype.itemsize == 8:
         return _lib.LEC_F64
-    raise ValueError(f"the device ingest reads int16, float32 and float64 variables, not {dtype}")
+    raise ValueError(f"the device ingest reads int8, int16, int32, float32 and float64 variables, not {dtype}")
 
 
 def _swapped(dtype: np.dtype) -> bool:
@@ -182,11 +182,11 @@ class _Stager:
         self.level_elems = (self.j1 - self.j0 + 1) * self.nx
         self.step_elems = len(self.levels) * self.level_elems
         self.itemsize = var.data.dtype.itemsize
-        carrier = {2: torch.int16, 4: torch.int32, 8: torch.int64}[self.itemsize]      # bytes only; never interpreted
+        carrier = {1: torch.int8, 2: torch.int16, 4: torch.int32, 8: torch.int64}[self.itemsize]      # bytes only; never interpreted
         # (direct copies from registered file memory need no pinned staging buffers)
         self.pinned = [torch.empty((steps, self.step_elems), dtype=carrier, pin_memory=True) for _ in range(slots)] if pinned else None
         self.raw_dev = [torch.empty((steps, self.step_elems), dtype=carrier, device=device) for _ in range(slots)]
-        self._carrier_np = {2: np.int16, 4: np.int32, 8: np.int64}[self.itemsize]
+        self._carrier_np = {1: np.int8, 2: np.int16, 4: np.int32, 8: np.int64}[self.itemsize]
 
     def stage(self, slot: int, file_steps: np.ndarray, at: int):
         """File time steps -> pinned rows [at, at + len): the only host touch of the data (page cache -> pinned)."""

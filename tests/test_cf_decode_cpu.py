@@ -85,3 +85,17 @@ def test_host_preparation_equals_the_oracle_on_an_era5_style_file(tmp_path, monk
         assert x.dtype == want and y.dtype == want, (role, x.dtype, y.dtype)
         assert np.array_equal(x, y, equal_nan=True), role
     assert np.isnan(ref.v).any() == fill
+
+
+def test_random_file_layouts_host_preparation_equals_the_oracle(tmp_path, monkeypatch):
+    """60 cases of tests/soak_ingest.py (random storage types int8 / int16 / int32 / float32 / float64, packing and fill attributes in
+    float32 or float64, axis orders and units, boxes): dataset.prepare_data against the oracle's decode, dtype for dtype, bit for bit."""
+    from tests import soak_ingest as soak
+    os.makedirs(tmp_path / "inputs")
+    (tmp_path / "inputs" / "namelist").write_text(soak.NAMELIST)
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.default_rng(11)
+    fails = []
+    for case in range(60):
+        fails += soak.one_case(rng, case, str(tmp_path), gpu=False)
+    assert not fails, fails[:3]

@@ -221,3 +221,16 @@ def test_registered_file_memory_equals_staged(workdir, golden_dir, chunk_steps):
     ingest.lec_fixed_streamed(raw, plan2, df, (-60.0, -30.0, -42.5, -17.5), stats=st)
     assert st["staging"] == "staged"
     raw.close()
+
+
+def test_random_file_layouts_device_decode_equals_the_oracle(workdir):
+    """60 cases of tests/soak_ingest.py: lec_ingest (int8 / int16 / int32 / float32 / float64 sources, every combination of packing
+    and fill attributes, rolled longitudes, reversed latitudes and levels) against the oracle's decode + process_data +
+    slice_domain, dtype for dtype, bit for bit -- and the host preparation with it."""
+    from tests import soak_ingest as soak
+    (workdir / "inputs" / "namelist").write_text(soak.NAMELIST)
+    rng = np.random.default_rng(12)
+    fails = []
+    for case in range(60):
+        fails += soak.one_case(rng, case, str(workdir), gpu=True)
+    assert not fails, fails[:3]
