@@ -12,7 +12,8 @@ gridded data:
 * attributes in the object header or in dense storage.
 
 Not supported (raises Hdf5Error): sub-groups, compound / enum data, other filters (szip, lzf, zstd ...), external or
-virtual storage, v2 B-trees deeper than two levels.  Format reference: "HDF5 File Format Specification
+virtual storage, v2 B-trees deeper than two levels.  tools/soak_hdf5.py checks the reader against h5py on random files (build
+container only).  Format reference: "HDF5 File Format Specification
 Version 3.0" (The HDF Group).
 """
 from __future__ import annotations
@@ -596,7 +597,8 @@ class H5File:
             if lay["addr"] != (1 << (8 * self.O)) - 1:
                 walk(lay["addr"])
         elif lay["index"] == "single":
-            table[(0,) * rank] = (lay["addr"], lay["fsize"] if lay["fsize"] is not None else nbytes, lay["fmask"])
+            if lay["addr"] != (1 << (8 * self.O)) - 1:
+                table[(0,) * rank] = (lay["addr"], lay["fsize"] if lay["fsize"] is not None else nbytes, lay["fmask"])
         elif lay["index"] == "btree2":                     # several unlimited dimensions: records carry the scaled chunk offsets
             a = lay["addr"] + self.base
             rtype = self._m[a + 5]
@@ -623,7 +625,7 @@ class H5File:
             counts = [-(-s // c) for s, c in zip(var.shape, chunk)]
             coords = list(np.ndindex(*counts))
             if lay["index"] == "implicit":
-                for i, c in enumerate(coords):
+                for i, c in enumerate(coords if lay["addr"] != (1 << (8 * self.O)) - 1 else ()):
                     table[tuple(ci * ch for ci, ch in zip(c, chunk))] = (lay["addr"] + i * nbytes, nbytes, 0)
             else:                                      # fixed array
                 a = lay["addr"] + self.base
@@ -636,15 +638,32 @@ class H5File:
                 if m[db: db + 4] != b"FADB":
                     raise Hdf5Error("bad fixed array data block")
                 p = db + 6 + self.O
-                if nent > (1 << pbits):
-                    raise Hdf5Error("paged fixed-array chunk index not supported")
+                undef = (1 << (8 * self.O)) - 1
+                page_n = 1 << pbits
+                if nent > page_n:
+                    # paged data block: a bitmap of the initialised pages (most significant bit first) and the block's checksum,
+                    # then the pages, each followed by its own checksum; pages that were never initialised hold no chunks
+                    npages = -(-nent // page_n)
+                    bitmap = bytes(m[p: p + (npages + 7) // 8])
+                    p += (npages + 7) // 8 + 4
+                    starts = []
+                    for pg in range(npages):
+                        n_here = min(page_n, nent - pg * page_n)
+                        live = bool(bitmap[pg // 8] & (0x80 >> (pg % 8)))
+                        starts.extend([(p + e * esize) if live else None for e in range(n_here)])
+                        p += n_here * esize + 4
+                else:
+                    starts = [p + e * esize for e in range(nent)]
                 for i, c in enumerate(coords[:nent]):
+                    q = starts[i]
+                    if q is None or self._addr(q) == undef:            # a chunk that was never written reads as the fill value
+                        continue
                     off = tuple(ci * ch for ci, ch in zip(c, chunk))
                     if client == 0:
-                        table[off] = (self._addr(p), nbytes, 0); p += esize
+                        table[off] = (self._addr(q), nbytes, 0)
                     else:
                         csz = esize - self.O - 4
-                        table[off] = (self._addr(p), self._u(p + self.O, csz), self._u(p + self.O + csz, 4)); p += esize
+                        table[off] = (self._addr(q), self._u(q + self.O, csz), self._u(q + self.O + csz, 4))
         var._cache["table"] = table
         return table
 
@@ -766,8 +785,8 @@ class H5File:
         else:
             out = np.zeros((1,) + shape[1:], dtype=var.dtype)
             lo0, hi0 = t, t + 1
-        fill = var._cache.get("fill", var.attrs.get("_FillValue"))
-        if fill is not None and not isinstance(fill, (list, str)):
+        fill = var._cache.get("fill")        # the dataset's HDF5 fill value (netCDF-C sets it to _FillValue); none defined: zeros, like the library
+        if fill is not None:
             out[...] = fill
         if "by_t" not in var._cache:                           # chunks grouped by their first-axis offset: a time-step read looks at its own only
             by_t = {}

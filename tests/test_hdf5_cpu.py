@@ -154,3 +154,20 @@ def test_fletcher32_checksums_are_verified(tmp_path):
         h.variables["t"].read()
     h.close()
     assert good.size > 0
+
+
+def test_chunks_that_were_never_written_read_as_the_hdf5_fill_value():
+    """sparse_latest.h5 (tools/make_hdf5_fixtures.py write_sparse): undefined entries of a fixed-array chunk index, a paged
+    fixed array whose second page was never initialised, a chunked dataset without any storage -- each reads as the dataset's HDF5
+    fill value (zeros when none is defined), never as its ``_FillValue`` attribute, whole and index by index; what h5py returns."""
+    gen = _generator()
+    _a, want_a, _b, want_b, want_c = gen["sparse_arrays"]()
+    f = hdf5_lite.H5File(os.path.join(FIX, "sparse_latest.h5"))
+    for name, want in (("a", want_a), ("b", want_b), ("c", want_c)):
+        v = f.variables[name]
+        got = v.read()
+        assert got.dtype == want.dtype and np.array_equal(got, want), name
+        for t in (0, want.shape[0] // 2, want.shape[0] - 1):
+            assert np.array_equal(v[t], want[t]), (name, t)
+    assert f.variables["a"].attrs["_FillValue"] == -32767
+    f.close()

@@ -84,8 +84,36 @@ def write(path, libver, track_order, packed, chunks, vlen_units, many_attrs, nt=
                 h.create_dataset("pad_%d" % i, data=np.arange(3, dtype=np.int32))
 
 
+def sparse_arrays():
+    """What write_sparse() writes and what a reader must return for it (pure function: the test regenerates it)."""
+    rng = np.random.default_rng(11)
+    a = rng.integers(-30000, 30000, (6, 4, 10, 12)).astype(np.int16)          # written only in [0:4, 0:3, 0:7, 0:9]
+    want_a = np.full(a.shape, -99, dtype=np.int16); want_a[:4, :3, :7, :9] = a[:4, :3, :7, :9]
+    b = rng.integers(0, 60000, (1500, 2, 3)).astype(np.uint16)                 # 1500 one-step chunks, the second half never written
+    want_b = np.zeros(b.shape, dtype=np.uint16); want_b[:750] = b[:750]
+    c = rng.standard_normal((5, 8)).astype(np.float32)                         # a chunked variable nobody ever wrote to
+    return a, want_a, b, want_b, np.zeros_like(c)
+
+
+def write_sparse(path):
+    """Chunks that were never written read as the dataset's HDF5 fill value (zeros if none is defined) -- NOT as its _FillValue
+    attribute: fixed-array chunk indexes with undefined entries, a paged one (1500 chunks > 1024 per page) whose second page was
+    never initialised, and a single-chunk dataset without storage.  (The round-3 soak against h5py, tools/soak_hdf5.py, found all
+    three unread; netCDF-C writes every chunk of a variable it defines, h5py / h5netcdf writers need not.)"""
+    a, _wa, b, _wb, c = sparse_arrays()
+    with h5py.File(path, "w", libver="latest") as h:
+        d = h.create_dataset("a", a.shape, dtype=np.int16, chunks=(2, 2, 4, 5), compression="gzip", shuffle=True, fillvalue=np.int16(-99))
+        d[:4, :3, :7, :9] = a[:4, :3, :7, :9]
+        d.attrs["_FillValue"] = np.int16(-32767)          # the CF attribute says one thing, the HDF5 fill value another: the latter fills
+        d = h.create_dataset("b", b.shape, dtype=np.uint16, chunks=(1, 2, 3))
+        d[:750] = b[:750]
+        d.attrs["_FillValue"] = np.uint16(65535)
+        h.create_dataset("c", c.shape, dtype=np.float32, chunks=c.shape)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    write_sparse(os.path.join(OUT, "sparse_latest.h5"))
     write(os.path.join(OUT, "packed_chunked_earliest.nc"), "earliest", False, True, True, False, False)
     write(os.path.join(OUT, "packed_chunked_tracked.nc"), ("earliest", "v110"), True, True, True, True, True)
     write(os.path.join(OUT, "float_contiguous_latest.nc"), "latest", True, False, False, True, True)
