@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define LEC_ABI_VERSION 6
+#define LEC_ABI_VERSION 7
 
 /* number of fp64 values per (time, level, lat) row record written by lec_rowstats */
 #define LEC_NSTAT 32
@@ -296,6 +296,51 @@ int lec_check_maps(const lec_ingest_args* args, int32_t* status_d);
 int lec_host_register(const void* ptr, size_t bytes);
 int lec_host_unregister(const void* ptr);
 int lec_copy_rows_async(void* dst_d, size_t dst_pitch, const void* src_h, size_t src_pitch, size_t width_bytes, size_t rows, void* stream);
+
+/*
+ * Deflated NetCDF-4 input on the device.  The reference reads such files through netCDF4 / HDF5, which inflate every chunk on one
+ * host thread (src/utils/preprocessing.py:35-146 -> xr.open_dataset); here the compressed chunks cross the link as they lie in
+ * the file and the GPU inflates them, one wave per chunk:
+ *   lec_inflate        n_streams independent zlib streams (RFC 1950 / 1951: stored, fixed and dynamic blocks) -> their
+ *                      inflated bytes.  desc_d[s] = {byte offset of the stream in src_d (a multiple of 16), its size, byte offset of
+ *                      its output in dst_d (a multiple of 16), the output's exact size}.  src_bytes is the size of the src_d
+ *                      allocation (the kernel reads whole dwords: it may touch up to 512 bytes after a stream's end, never beyond
+ *                      src_bytes).  status_d[s] = {code, deflate block, output position, input bit position}; code 0 = ok, anything
+ *                      else names what was wrong with the stream (lec_inflate_status_text) -- the adler32 trailer is NOT verified.
+ *                      Asynchronous like every other entry point: the caller reads status_d after synchronising.
+ *   lec_chunk_scatter  the payloads of n_chunks HDF5 chunks (each ct x ck x cj x ci elements of elem_size bytes, all of one
+ *                      variable; shuffled = 1: the HDF5 shuffle filter's byte planes, undone here) -> a contiguous array
+ *                      [nt][nl][ny][nx] of raw elements, which lec_ingest then decodes.  chunk_d[c] = {byte offset of the payload
+ *                      in src_d, the chunk's origin in FILE coordinates t, k, j, i}; file step t lands in output step
+ *                      tmap_d[t - t_base], file level k in output level kmap_d[k] (either < 0: not wanted), file row j in output
+ *                      row j - j0, column i in column i; whatever falls outside the output (edge chunks are padded) is skipped.
+ */
+typedef struct lec_inflate_args {
+    const void* src_d;
+    int64_t src_bytes;
+    const int64_t* desc_d;      /* [n_streams][4] */
+    int32_t n_streams, reserved0;
+    void* dst_d;
+    int32_t* status_d;          /* [n_streams][4] */
+    void* stream;
+} lec_inflate_args;
+
+typedef struct lec_chunk_scatter_args {
+    const void* src_d;
+    const int64_t* chunk_d;     /* [n_chunks][5] */
+    int32_t n_chunks, elem_size, shuffled, reserved0;
+    int32_t ct, ck, cj, ci;
+    int32_t t_base, n_tmap, n_kmap, j0;
+    const int32_t* tmap_d;      /* [n_tmap] */
+    const int32_t* kmap_d;      /* [n_kmap] */
+    int32_t nt, nl, ny, nx;
+    void* out_d;
+    void* stream;
+} lec_chunk_scatter_args;
+
+int lec_inflate(const lec_inflate_args* args);
+const char* lec_inflate_status_text(int code);
+int lec_chunk_scatter(const lec_chunk_scatter_args* args);
 
 #ifdef __cplusplus
 }

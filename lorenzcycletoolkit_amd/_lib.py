@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # LEC_LIB: alternative build of the same ABI (kernel experiments only)
 LIB_PATH = os.environ.get("LEC_LIB") or os.path.join(_HERE, "liblec_hip.so")
 
-LEC_ABI_VERSION = 6
+LEC_ABI_VERSION = 7
 LEC_NSTAT = 32
 LEC_NLEVRAW = 40
 LEC_NSCALAR = 16
@@ -23,7 +23,8 @@ KERNEL_AUTO, KERNEL_TWO_SWEEP, KERNEL_ROW_SWEEP, KERNEL_ROW_BLOCK, KERNEL_BOX_TI
 ORDER_AUTO, ORDER_MEMORY, ORDER_XCD_LAT, ORDER_XCD_TILED = 0, 1, 2, 7
 
 EXPORTS = ["lec_version", "lec_last_error", "lec_max_row", "lec_rowstats", "lec_reduce", "lec_dropmask", "lec_ingest", "lec_track_diag",
-           "lec_check_boxes", "lec_check_maps", "lec_host_register", "lec_host_unregister", "lec_copy_rows_async"]
+           "lec_check_boxes", "lec_check_maps", "lec_host_register", "lec_host_unregister", "lec_copy_rows_async",
+           "lec_inflate", "lec_inflate_status_text", "lec_chunk_scatter"]
 
 
 class Tuning(C.Structure):
@@ -91,6 +92,23 @@ class DiagArgs(C.Structure):
                 ("val_d", C.c_void_p), ("pos_d", C.c_void_p), ("stream", C.c_void_p)]
 
 
+class InflateArgs(C.Structure):
+    """struct lec_inflate_args (include/lec_hip.h)."""
+    _fields_ = [("src_d", C.c_void_p), ("src_bytes", C.c_int64), ("desc_d", C.c_void_p), ("n_streams", C.c_int32), ("reserved0", C.c_int32),
+                ("dst_d", C.c_void_p), ("status_d", C.c_void_p), ("stream", C.c_void_p)]
+
+
+class ChunkScatterArgs(C.Structure):
+    """struct lec_chunk_scatter_args (include/lec_hip.h)."""
+    _fields_ = [("src_d", C.c_void_p), ("chunk_d", C.c_void_p),
+                ("n_chunks", C.c_int32), ("elem_size", C.c_int32), ("shuffled", C.c_int32), ("reserved0", C.c_int32),
+                ("ct", C.c_int32), ("ck", C.c_int32), ("cj", C.c_int32), ("ci", C.c_int32),
+                ("t_base", C.c_int32), ("n_tmap", C.c_int32), ("n_kmap", C.c_int32), ("j0", C.c_int32),
+                ("tmap_d", C.c_void_p), ("kmap_d", C.c_void_p),
+                ("nt", C.c_int32), ("nl", C.c_int32), ("ny", C.c_int32), ("nx", C.c_int32),
+                ("out_d", C.c_void_p), ("stream", C.c_void_p)]
+
+
 _lib = None
 
 
@@ -133,6 +151,12 @@ def load():
     lib.lec_host_unregister.argtypes = [C.c_void_p]
     lib.lec_copy_rows_async.restype = C.c_int
     lib.lec_copy_rows_async.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]
+    lib.lec_inflate.restype = C.c_int
+    lib.lec_inflate.argtypes = [C.POINTER(InflateArgs)]
+    lib.lec_inflate_status_text.restype = C.c_char_p
+    lib.lec_inflate_status_text.argtypes = [C.c_int]
+    lib.lec_chunk_scatter.restype = C.c_int
+    lib.lec_chunk_scatter.argtypes = [C.POINTER(ChunkScatterArgs)]
     if lib.lec_version() != LEC_ABI_VERSION:
         raise LecLibraryError(f"liblec_hip.so ABI {lib.lec_version()} != expected {LEC_ABI_VERSION}")
     _lib = lib

@@ -1,0 +1,536 @@
+// lec_inflate.hip -- zlib / deflate streams inflated on the GPU, and the chunks of a NetCDF-4 variable put in place
+// (include/lec_hip.h: lec_inflate, lec_chunk_scatter).
+//
+// Why: a deflated NetCDF-4 file (what the CDS delivers for ERA5) is bound by the HOST's inflate -- 3.75 GB/s of decoded data with
+// 16 threads against a 57 GB/s link (profiles/r03_notes.md) -- and the reference's netCDF4 / HDF5 stack inflates in one thread.
+// Here the link carries the compressed chunks as they lie in the file and the GPU inflates them: thousands of independent
+// streams per batch of time steps (one per HDF5 chunk), ONE WAVE PER STREAM.
+//
+// A deflate stream is serial: the position of a code is known only when the code before it is decoded.  A wave breaks that
+// chain by speculation: lane l decodes the token (literal, or length + distance with their extra bits, or end-of-block) that WOULD
+// start at bit (base + l) -- 64 candidate positions, one table lookup each in LDS --, then a short scalar walk follows the true
+// chain through the lanes (position 0, then 0 + bits(0), ...), typically 6-9 tokens per round, assigns output offsets, and the
+// wave writes: literals at once, matches one after the other with all 64 lanes copying.  Codes longer than the lookup width
+// (rare symbols) are resolved only when the walk actually lands on them (canonical decode, count / sorted-symbol arrays).
+//
+// Output goes through a 16 KiB ring in LDS (the recent history LZ77 matches mostly refer to) and is flushed to HBM in 16-byte
+// pieces; a match that reaches further back than the ring reads the flushed bytes from HBM (a fence orders the wave's own earlier
+// stores, taken lazily -- only when such a match occurs).  23 KiB of LDS per wave: 6 waves per CU, ~1500 streams in flight.
+//
+// Every loop is bounded by the stream's bit length / the output size; malformed input ends with a status code, never a hang.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/lec_hip.h"
+#include "lec_internal.h"
+
+namespace {
+
+constexpr int kLitBits = 11;        // lookup width of the literal / length code (codes up to 15 bits: the rest resolves on demand)
+constexpr int kDistBits = 10;
+constexpr int kRing = 16384;        // LDS history ring (bytes, power of two)
+constexpr int kCap = 4096;          // most output bytes one round of tokens may produce
+constexpr int kFlushAt = 2048;      // pending bytes that trigger a flush of the ring to HBM
+
+enum { T_LIT = 0, T_MATCH = 1, T_EOB = 2, T_SLOW = 3, T_BAD = 4 };
+
+// the order in which a dynamic block header lists the lengths of the code-length code (RFC 1951, 3.2.7)
+__constant__ uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+struct __attribute__((aligned(16))) InflateLds {
+    uint8_t ring[kRing];
+    uint16_t lit[1 << kLitBits];    // (symbol << 4) | code length; 0: not in the table (longer code, or no such code)
+    uint16_t dist[1 << kDistBits];
+    uint16_t lsym[288];             // symbols sorted by (code length, symbol): canonical decode of the long codes
+    uint16_t dsym[32];
+    uint32_t lcnt[16], dcnt[16];    // number of codes of each length
+    uint16_t clt[128];              // the code-length code of a dynamic block header (<= 7 bits)
+    uint8_t lens[320];              // code lengths as read from the header: 288 literal/length + 32 distance
+};
+
+__device__ __forceinline__ uint32_t rl(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
+__device__ __forceinline__ uint32_t wl(uint32_t value, uint32_t lane, uint32_t old) {      // `old` with lane `lane` set to the uniform `value`
+    return (uint32_t)__lane_id() == lane ? value : old;
+}
+__device__ __forceinline__ void wave_sync() { __syncthreads(); }      // one wave per workgroup: orders its LDS traffic for the compiler
+
+// The compressed stream seen through two 64-dword blocks held in registers (lane l: dword blk * 64 + l and the one 64 further):
+// any dword the decoder needs is one v_readlane away, and the next block loads while the current one is consumed.
+struct BitIn {
+    const uint32_t* in32;
+    uint32_t nwords;                // dwords that may be read (the buffer's padding included)
+    uint32_t blk;
+    uint32_t a, b;
+    int lane;
+    __device__ __forceinline__ uint32_t load(uint32_t block) const {
+        const uint32_t i = block * 64u + (uint32_t)lane;
+        return i < nwords ? in32[i] : 0u;
+    }
+    __device__ __forceinline__ void reset(uint32_t bitpos) { blk = (bitpos >> 5) >> 6; a = load(blk); b = load(blk + 1); }
+    // afterwards dwords [bitpos / 32, bitpos / 32 + 64) are held
+    __device__ __forceinline__ void seek(uint32_t bitpos) {
+        const uint32_t d = bitpos >> 5;
+        if (d >= blk * 64u + 64u) {
+            if (d < blk * 64u + 128u) { a = b; ++blk; b = load(blk + 1); }
+            else reset(bitpos);
+        } else if (d < blk * 64u) reset(bitpos);
+    }
+    __device__ __forceinline__ uint32_t dword(uint32_t d) const {      // d wave-uniform, within the held range
+        const uint32_t rel = d - blk * 64u;
+        return rel < 64u ? rl(a, rel) : rl(b, rel - 64u);
+    }
+    __device__ __forceinline__ uint32_t peek(uint32_t bitpos) const {  // 32 bits at a wave-uniform position
+        const uint32_t d = bitpos >> 5, s = bitpos & 31u;
+        const uint64_t w = ((uint64_t)dword(d + 1) << 32) | dword(d);
+        return (uint32_t)(w >> s);
+    }
+};
+
+__device__ __forceinline__ void length_of(uint32_t c, uint32_t& base, uint32_t& extra) {      // c = symbol - 257, 0..28
+    if (c < 8u) { base = 3u + c; extra = 0u; }
+    else if (c == 28u) { base = 258u; extra = 0u; }
+    else { extra = (c >> 2) - 1u; base = 3u + ((4u + (c & 3u)) << extra); }
+}
+__device__ __forceinline__ void distance_of(uint32_t d, uint32_t& base, uint32_t& extra) {    // d = 0..29
+    if (d < 4u) { base = 1u + d; extra = 0u; }
+    else { extra = (d >> 1) - 1u; base = 1u + ((2u + (d & 1u)) << extra); }
+}
+
+// canonical decode of one code from the low bits of `w` (first stream bit = most significant code bit); -1: no such code
+__device__ __forceinline__ int canon(uint64_t w, const uint32_t* cnt, const uint16_t* sorted, uint32_t& len_out) {
+    int code = 0, first = 0, index = 0;
+    for (int len = 1; len <= 15; ++len) {
+        code |= (int)(w & 1u); w >>= 1;
+        const int count = (int)cnt[len];
+        if (code - count < first) { len_out = (uint32_t)len; return (int)sorted[index + (code - first)]; }
+        index += count; first += count; first <<= 1; code <<= 1;
+    }
+    return -1;
+}
+
+// Lookup table + canonical arrays from `n` code lengths in LDS.  0: ok (incomplete codes are allowed: their gaps decode as
+// "no such code"); 1: over-subscribed.
+__device__ int build_code(const uint8_t* lens, int n, uint16_t* table, int bits, uint16_t* sorted, uint32_t* cnt, int lane) {
+    int mylen[5];
+#pragma unroll
+    for (int g = 0; g < 5; ++g) { const int s = g * 64 + lane; mylen[g] = s < n ? (int)lens[s] : 0; }
+    for (int i = lane; i < (1 << bits); i += 64) table[i] = 0;
+    if (lane < 16) cnt[lane] = 0;
+    wave_sync();
+    uint32_t code = 0, index = 0;
+    int left = 1;
+    const uint64_t below = (1ull << lane) - 1ull;
+    for (int len = 1; len <= 15; ++len) {
+        uint64_t m[5];
+        uint32_t c = 0;
+#pragma unroll
+        for (int g = 0; g < 5; ++g) { m[g] = __ballot(mylen[g] == len); c += (uint32_t)__popcll(m[g]); }
+        left = (left << 1) - (int)c;
+        if (left < 0) return 1;
+        if (c == 0) { code <<= 1; continue; }
+        if (lane == 0) cnt[len] = c;
+        uint32_t run = 0;
+#pragma unroll
+        for (int g = 0; g < 5; ++g) {
+            if (mylen[g] == len) {
+                const uint32_t r = run + (uint32_t)__popcll(m[g] & below);
+                const uint32_t sym = (uint32_t)(g * 64 + lane);
+                sorted[index + r] = (uint16_t)sym;
+                if (len <= bits) {
+                    const uint32_t rev = __brev(code + r) >> (32 - len);
+                    const uint16_t e = (uint16_t)((sym << 4) | (uint32_t)len);
+                    for (uint32_t at = rev; at < (1u << bits); at += (1u << len)) table[at] = e;
+                }
+            }
+            run += (uint32_t)__popcll(m[g]);
+        }
+        code = (code + c) << 1;
+        index += c;
+    }
+    wave_sync();
+    return 0;
+}
+
+struct InflateParams {
+    const uint8_t* src; long long src_bytes;
+    const long long* desc; int n;
+    uint8_t* dst; int* status;
+};
+
+enum {
+    ST_OK = 0, ST_HEADER = 1, ST_BLOCK_TYPE = 2, ST_STORED = 3, ST_CODE_LENGTHS = 4, ST_OVERSUBSCRIBED = 5, ST_BAD_CODE = 6,
+    ST_DISTANCE = 7, ST_INPUT_END = 8, ST_OUTPUT_FULL = 9, ST_SIZE = 10, ST_STALLED = 11
+};
+
+__global__ void __launch_bounds__(64) lec_inflate_kernel(const InflateParams P) {
+    __shared__ InflateLds L;
+    const int lane = (int)threadIdx.x;
+    const int s = (int)blockIdx.x;
+    const long long src_off = P.desc[4 * s + 0], src_len = P.desc[4 * s + 1], dst_off = P.desc[4 * s + 2], dst_len = P.desc[4 * s + 3];
+    uint8_t* const out = P.dst + dst_off;
+    const uint8_t* const inb = P.src + src_off;
+    BitIn in;
+    in.in32 = (const uint32_t*)inb; in.lane = lane;
+    in.nwords = (uint32_t)((P.src_bytes - src_off) >> 2);
+    const uint32_t src_bits = (uint32_t)src_len * 8u;
+    const uint32_t out_len = (uint32_t)dst_len;
+
+    uint32_t bitpos = 16;           // after the zlib header
+    uint32_t opos = 0, flushed = 0, fenced = 0;
+    int status = ST_OK, block = 0;
+    in.reset(0);
+    {
+        const uint32_t h = in.peek(0);
+        const uint32_t cmf = h & 0xffu, flg = (h >> 8) & 0xffu;
+        if (src_len < 6 || (cmf & 0x0fu) != 8u || (cmf >> 4) > 7u || ((cmf << 8) | flg) % 31u != 0u || (flg & 0x20u)) status = ST_HEADER;
+    }
+
+    // ring -> HBM, whole 16-byte pieces (all of it when `all`)
+    auto flush = [&](bool all) {
+        const uint32_t end16 = opos & ~15u;
+        for (uint32_t q = flushed + 16u * (uint32_t)lane; q < end16; q += 16u * 64u)
+            *(uint4*)(out + q) = *(const uint4*)&L.ring[q & (kRing - 1)];
+        if (end16 > flushed) flushed = end16;
+        if (all) {
+            for (uint32_t q = flushed + (uint32_t)lane; q < opos; q += 64u) out[q] = L.ring[q & (kRing - 1)];
+            flushed = opos;
+        }
+    };
+
+    bool last = false;
+    while (status == ST_OK && !last) {
+        // ------------------------------------------------------------------ block header (wave-uniform)
+        in.seek(bitpos);
+        if (bitpos + 3u > src_bits) { status = ST_INPUT_END; break; }
+        uint32_t hdr = in.peek(bitpos);
+        last = (hdr & 1u) != 0u;
+        const uint32_t btype = (hdr >> 1) & 3u;
+        bitpos += 3;
+        ++block;
+        if (btype == 3u) { status = ST_BLOCK_TYPE; break; }
+        if (btype == 0u) {
+            // stored: to the next byte, LEN, ~LEN, the bytes
+            bitpos = (bitpos + 7u) & ~7u;
+            in.seek(bitpos);
+            if (bitpos + 32u > src_bits) { status = ST_INPUT_END; break; }
+            const uint32_t ll = in.peek(bitpos);
+            uint32_t len = ll & 0xffffu;
+            if (len != ((~ll >> 16) & 0xffffu)) { status = ST_STORED; break; }
+            bitpos += 32;
+            uint32_t at = bitpos >> 3;
+            if ((uint64_t)at + len > (uint64_t)src_len) { status = ST_INPUT_END; break; }
+            if (len > out_len - opos) { status = ST_OUTPUT_FULL; break; }
+            while (len) {
+                const uint32_t n = len < (uint32_t)kCap ? len : (uint32_t)kCap;
+                for (uint32_t k = (uint32_t)lane; k < n; k += 64u) L.ring[(opos + k) & (kRing - 1)] = inb[at + k];
+                wave_sync();
+                opos += n; at += n; len -= n;
+                if (opos - flushed >= (uint32_t)kFlushAt) flush(false);
+            }
+            bitpos = at * 8u;
+            continue;
+        }
+        // ------------------------------------------------------------------ the two codes of this block
+        int nlit = 288, ndist = 32;
+        if (btype == 1u) {
+            for (int i = lane; i < 320; i += 64) L.lens[i] = (uint8_t)(i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : i < 288 ? 8 : 5);
+        } else {
+            in.seek(bitpos);
+            if (bitpos + 14u > src_bits) { status = ST_INPUT_END; break; }
+            hdr = in.peek(bitpos);
+            nlit = (int)(hdr & 31u) + 257; ndist = (int)((hdr >> 5) & 31u) + 1;
+            const int ncl = (int)((hdr >> 10) & 15u) + 4;
+            bitpos += 14;
+            if (nlit > 286 || ndist > 30) { status = ST_CODE_LENGTHS; break; }
+            // code-length code: ncl x 3 bits in the order 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
+            if (lane < 19) L.lens[lane] = 0;
+            wave_sync();
+            for (int i = 0; i < ncl; ++i) {
+                in.seek(bitpos);
+                const uint32_t v = in.peek(bitpos) & 7u;
+                bitpos += 3;
+                if (lane == 0) L.lens[kClOrder[i]] = (uint8_t)v;
+            }
+            if (bitpos > src_bits) { status = ST_INPUT_END; break; }
+            wave_sync();
+            if (build_code(L.lens, 19, L.clt, 7, L.dsym, L.dcnt, lane)) { status = ST_OVERSUBSCRIBED; break; }
+            // the nlit + ndist code lengths, run-length coded with that code
+            int have = 0, prev = 0;
+            const int want = nlit + ndist;
+            bool bad = false;
+            while (have < want) {
+                in.seek(bitpos);
+                const uint32_t w = in.peek(bitpos);
+                const uint32_t e = L.clt[w & 127u];
+                if (e == 0u) { bad = true; break; }
+                const uint32_t cl = e & 15u, sym = e >> 4;
+                bitpos += cl;
+                int rep = 1, val = (int)sym;
+                if (sym == 16u) { if (have == 0) { bad = true; break; } rep = 3 + (int)((w >> cl) & 3u); bitpos += 2; val = prev; }
+                else if (sym == 17u) { rep = 3 + (int)((w >> cl) & 7u); bitpos += 3; val = 0; }
+                else if (sym == 18u) { rep = 11 + (int)((w >> cl) & 127u); bitpos += 7; val = 0; }
+                if (have + rep > want || bitpos > src_bits) { bad = true; break; }
+                // literal/length lengths at lens[0..nlit), distance lengths at lens[288..288 + ndist)
+                for (int r = lane; r < rep; r += 64) { const int i = have + r; L.lens[i < nlit ? i : 288 + (i - nlit)] = (uint8_t)val; }
+                have += rep; prev = val;
+            }
+            if (bad) { status = ST_CODE_LENGTHS; break; }
+            wave_sync();
+            for (int i = nlit + lane; i < 288; i += 64) L.lens[i] = 0;
+            for (int i = 288 + ndist + lane; i < 320; i += 64) L.lens[i] = 0;
+            wave_sync();
+            if (L.lens[256] == 0) { status = ST_CODE_LENGTHS; break; }      // no end-of-block code
+        }
+        wave_sync();
+        if (build_code(L.lens, 288, L.lit, kLitBits, L.lsym, L.lcnt, lane) || build_code(L.lens + 288, 32, L.dist, kDistBits, L.dsym, L.dcnt, lane)) {
+            status = ST_OVERSUBSCRIBED; break;
+        }
+
+        // ------------------------------------------------------------------ the block's tokens, up to 64 candidate positions a round
+        bool eob = false;
+        uint32_t rounds = 0;
+        while (!eob) {
+            if (++rounds > src_bits + 8u) { status = ST_STALLED; break; }
+            in.seek(bitpos);
+            // 64 bits of the stream from bit (bitpos + lane)
+            uint64_t win;
+            {
+                const uint32_t d0 = bitpos >> 5;
+                const uint32_t u0 = in.dword(d0), u1 = in.dword(d0 + 1), u2 = in.dword(d0 + 2), u3 = in.dword(d0 + 3), u4 = in.dword(d0 + 4);
+                const uint32_t o = (bitpos & 31u) + (uint32_t)lane, wi = o >> 5, sh = o & 31u;
+                const uint32_t x0 = wi == 0u ? u0 : wi == 1u ? u1 : u2;
+                const uint32_t x1 = wi == 0u ? u1 : wi == 1u ? u2 : u3;
+                const uint32_t x2 = wi == 0u ? u2 : wi == 1u ? u3 : u4;
+                win = (((uint64_t)x1 << 32) | x0) >> sh;
+                if (sh) win |= (uint64_t)x2 << (64u - sh);
+            }
+            // the token that would start here
+            uint32_t type, used, value = 0, dist = 0;        // value: the literal byte, or the match length
+            {
+                const uint32_t e = L.lit[(uint32_t)win & ((1u << kLitBits) - 1u)];
+                used = e & 15u;
+                const uint32_t sym = e >> 4;
+                if (e == 0u) type = T_SLOW;
+                else if (sym < 256u) { type = T_LIT; value = sym; }
+                else if (sym == 256u) type = T_EOB;
+                else if (sym > 285u) type = T_BAD;
+                else {
+                    uint32_t base, extra;
+                    length_of(sym - 257u, base, extra);
+                    value = base + ((uint32_t)(win >> used) & ((1u << extra) - 1u));
+                    used += extra;
+                    const uint32_t de = L.dist[(uint32_t)(win >> used) & ((1u << kDistBits) - 1u)];
+                    if (de == 0u) type = T_SLOW;
+                    else if ((de >> 4) > 29u) type = T_BAD;
+                    else {
+                        used += de & 15u;
+                        distance_of(de >> 4, base, extra);
+                        dist = base + ((uint32_t)(win >> used) & ((1u << extra) - 1u));
+                        used += extra;
+                        type = T_MATCH;
+                    }
+                }
+            }
+            // follow the true chain through the lanes; offsets of the tokens' output
+            uint32_t pos = 0, produced = 0, ooff = 0;
+            uint64_t chain = 0;
+            const uint32_t win_lo = (uint32_t)win, win_hi = (uint32_t)(win >> 32);
+            while (pos < 64u) {
+                uint32_t ty = rl(type, pos);
+                if (ty == T_SLOW) {
+                    // a code longer than the lookup width (or none at all): decode this one position canonically
+                    uint64_t w = ((uint64_t)rl(win_hi, pos) << 32) | rl(win_lo, pos);
+                    uint32_t n = 0, tot;
+                    const int sym = canon(w, L.lcnt, L.lsym, n);
+                    uint32_t nty = T_BAD, nval = 0, ndis = 0;
+                    tot = n;
+                    if (sym >= 0 && sym < 256) { nty = T_LIT; nval = (uint32_t)sym; }
+                    else if (sym == 256) nty = T_EOB;
+                    else if (sym > 256 && sym <= 285) {
+                        uint32_t base, extra;
+                        length_of((uint32_t)sym - 257u, base, extra);
+                        nval = base + ((uint32_t)(w >> tot) & ((1u << extra) - 1u));
+                        tot += extra;
+                        uint32_t dn = 0;
+                        const int ds = canon(w >> tot, L.dcnt, L.dsym, dn);
+                        if (ds >= 0 && ds <= 29) {
+                            tot += dn;
+                            distance_of((uint32_t)ds, base, extra);
+                            ndis = base + ((uint32_t)(w >> tot) & ((1u << extra) - 1u));
+                            tot += extra;
+                            nty = T_MATCH;
+                        }
+                    }
+                    type = wl(nty, pos, type); used = wl(tot, pos, used); value = wl(nval, pos, value); dist = wl(ndis, pos, dist);
+                    ty = nty;
+                }
+                if (ty == T_BAD) { status = ST_BAD_CODE; break; }
+                const uint32_t n_out = ty == T_LIT ? 1u : ty == T_MATCH ? rl(value, pos) : 0u;
+                if (produced + n_out > (uint32_t)kCap) break;                  // the next round starts at this token
+                const uint32_t nbits = rl(used, pos);
+                if (bitpos + pos + nbits > src_bits) { status = ST_INPUT_END; break; }
+                ooff = wl(produced, pos, ooff);
+                chain |= 1ull << pos;
+                produced += n_out;
+                pos += nbits;
+                if (ty == T_EOB) { eob = true; break; }
+            }
+            if (status != ST_OK) break;
+            if (produced > out_len - opos) { status = ST_OUTPUT_FULL; break; }
+            const bool mine = (chain >> lane) & 1ull;
+            // literals
+            if (mine && type == T_LIT) L.ring[(opos + ooff) & (kRing - 1)] = (uint8_t)value;
+            // matches, in stream order, 64 bytes at a time
+            uint64_t mm = chain & __ballot(type == T_MATCH);
+            const int safe_lo = (int)opos + kCap - kRing;                      // positions from here on are in the ring for the whole round
+            while (mm) {
+                const uint32_t i = (uint32_t)__builtin_ctzll(mm);
+                mm &= mm - 1ull;
+                const uint32_t len = rl(value, i), d = rl(dist, i), p = opos + rl(ooff, i);
+                if (d > p) { status = ST_DISTANCE; break; }
+                const int from = (int)(p - d);
+                if (from < safe_lo && (uint32_t)from + (len < d ? len : d) > fenced) {
+                    // the source was flushed by this wave's own earlier stores: make them visible to its loads
+                    __threadfence();
+                    fenced = flushed;
+                }
+                const float rd = __frcp_rn((float)d);
+                for (uint32_t k = (uint32_t)lane; k < len; k += 64u) {
+                    uint32_t kk = k;
+                    if (d < len) {                                              // overlapping: the pattern of d bytes repeats
+                        const uint32_t q = (uint32_t)((float)k * rd);
+                        int r = (int)k - (int)(q * d);
+                        if (r < 0) r += (int)d; else if (r >= (int)d) r -= (int)d;
+                        kk = (uint32_t)r;
+                    }
+                    const int sp = from + (int)kk;
+                    const uint8_t byte = sp >= safe_lo ? L.ring[(uint32_t)sp & (kRing - 1)] : out[sp];
+                    L.ring[(p + k) & (kRing - 1)] = byte;
+                }
+                wave_sync();
+            }
+            if (status != ST_OK) break;
+            wave_sync();
+            opos += produced;
+            bitpos += pos;
+            if (opos - flushed >= (uint32_t)kFlushAt) flush(false);
+        }
+    }
+    if (status == ST_OK) {
+        flush(true);
+        if (opos != out_len) status = ST_SIZE;
+    }
+    if (lane == 0) {
+        P.status[4 * s + 0] = status; P.status[4 * s + 1] = block; P.status[4 * s + 2] = (int)opos; P.status[4 * s + 3] = (int)bitpos;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// chunks -> the contiguous raw sub-cube lec_ingest reads (un-shuffle, chunk tiling, edge chunks, level / time selection)
+// ---------------------------------------------------------------------------------------------------------------------
+struct ScatterParams {
+    const uint8_t* src; const long long* chunk; int n_chunks, es, shuffled;
+    int ct, ck, cj, ci;
+    int t_base, n_tmap; const int* tmap; int n_kmap; const int* kmap; int j0;
+    int nt, nl, ny, nx;
+    uint8_t* out;
+};
+
+template <int ES>
+__global__ void __launch_bounds__(256) lec_chunk_scatter_kernel(const ScatterParams p) {
+    const int rows = p.ct * p.ck * p.cj;
+    const int c = (int)(blockIdx.x / (unsigned)rows), row = (int)(blockIdx.x % (unsigned)rows);
+    const int cj_ = row % p.cj, ck_ = (row / p.cj) % p.ck, ct_ = row / (p.cj * p.ck);
+    const long long* ch = p.chunk + 5ll * c;
+    const int ft = (int)ch[1] + ct_, fk = (int)ch[2] + ck_, fj = (int)ch[3] + cj_, fi0 = (int)ch[4];
+    const int tt = ft - p.t_base;
+    if (tt < 0 || tt >= p.n_tmap || fk < 0 || fk >= p.n_kmap) return;
+    const int ot = p.tmap[tt], ok = p.kmap[fk], oj = fj - p.j0;
+    if (ot < 0 || ot >= p.nt || ok < 0 || ok >= p.nl || oj < 0 || oj >= p.ny) return;
+    const long long n_elem = (long long)rows * p.ci;
+    const uint8_t* base = p.src + ch[0];
+    const long long e0 = (long long)row * p.ci;
+    uint8_t* orow = p.out + ((((long long)ot * p.nl + ok) * p.ny + oj) * p.nx) * ES;
+    for (int i = (int)threadIdx.x; i < p.ci; i += (int)blockDim.x) {
+        const int oi = fi0 + i;
+        if (oi < 0 || oi >= p.nx) continue;                 // edge chunks are padded to the full chunk shape
+        uint8_t b[ES];
+        if (p.shuffled) {
+#pragma unroll
+            for (int q = 0; q < ES; ++q) b[q] = base[q * n_elem + e0 + i];
+        } else {
+#pragma unroll
+            for (int q = 0; q < ES; ++q) b[q] = base[(e0 + i) * ES + q];
+        }
+        if constexpr (ES == 1) orow[oi] = b[0];
+        else if constexpr (ES == 2) *(uint16_t*)(orow + 2ll * oi) = (uint16_t)(b[0] | (b[1] << 8));
+        else if constexpr (ES == 4) *(uint32_t*)(orow + 4ll * oi) = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24);
+        else {
+            uint64_t v = 0;
+#pragma unroll
+            for (int q = 0; q < ES; ++q) v |= (uint64_t)b[q] << (8 * q);
+            *(uint64_t*)(orow + 8ll * oi) = v;
+        }
+    }
+}
+
+const char* status_text(int code) {
+    switch (code) {
+        case ST_HEADER: return "not a zlib stream (header)";
+        case ST_BLOCK_TYPE: return "reserved deflate block type";
+        case ST_STORED: return "stored block: length check failed";
+        case ST_CODE_LENGTHS: return "dynamic block: bad code lengths";
+        case ST_OVERSUBSCRIBED: return "over-subscribed Huffman code";
+        case ST_BAD_CODE: return "invalid code in the stream";
+        case ST_DISTANCE: return "match distance reaches before the start of the output";
+        case ST_INPUT_END: return "compressed data end before the stream does";
+        case ST_OUTPUT_FULL: return "stream holds more data than the chunk's size";
+        case ST_SIZE: return "stream holds less data than the chunk's size";
+        case ST_STALLED: return "decoder made no progress";
+        default: return "unknown";
+    }
+}
+
+}  // namespace
+
+extern "C" int lec_inflate(const lec_inflate_args* a) {
+    if (!a) return lec_set_error(LEC_ERR_ARG, "lec_inflate: null args");
+    if (!a->src_d || !a->desc_d || !a->dst_d || !a->status_d) return lec_set_error(LEC_ERR_ARG, "lec_inflate: null pointer argument");
+    if (a->n_streams < 1 || a->src_bytes < 8) return lec_set_error(LEC_ERR_ARG, "lec_inflate: n_streams >= 1 and src_bytes >= 8 needed");
+    if (((uintptr_t)a->src_d & 15u) || ((uintptr_t)a->dst_d & 15u)) return lec_set_error(LEC_ERR_ARG, "lec_inflate: src_d and dst_d must be 16-byte aligned");
+    InflateParams p;
+    p.src = (const uint8_t*)a->src_d; p.src_bytes = a->src_bytes; p.desc = (const long long*)a->desc_d; p.n = a->n_streams;
+    p.dst = (uint8_t*)a->dst_d; p.status = a->status_d;
+    hipLaunchKernelGGL(lec_inflate_kernel, dim3((unsigned)a->n_streams), dim3(64), 0, (hipStream_t)a->stream, p);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return lec_set_error(LEC_ERR_LAUNCH, hipGetErrorString(e));
+    return LEC_OK;
+}
+
+extern "C" const char* lec_inflate_status_text(int code) { return code == 0 ? "ok" : status_text(code); }
+
+extern "C" int lec_chunk_scatter(const lec_chunk_scatter_args* a) {
+    if (!a) return lec_set_error(LEC_ERR_ARG, "lec_chunk_scatter: null args");
+    if (!a->src_d || !a->chunk_d || !a->tmap_d || !a->kmap_d || !a->out_d) return lec_set_error(LEC_ERR_ARG, "lec_chunk_scatter: null pointer argument");
+    if (a->n_chunks < 1 || a->ct < 1 || a->ck < 1 || a->cj < 1 || a->ci < 1 || a->nt < 1 || a->nl < 1 || a->ny < 1 || a->nx < 1 || a->n_tmap < 1 || a->n_kmap < 1)
+        return lec_set_error(LEC_ERR_ARG, "lec_chunk_scatter: extents must be >= 1");
+    if (a->elem_size != 1 && a->elem_size != 2 && a->elem_size != 4 && a->elem_size != 8) return lec_set_error(LEC_ERR_ARG, "lec_chunk_scatter: elem_size must be 1, 2, 4 or 8");
+    const long long rows = (long long)a->ct * a->ck * a->cj;
+    const long long blocks = rows * a->n_chunks;
+    if (blocks > 0x7fffffffLL) return lec_set_error(LEC_ERR_UNSUPPORTED, "lec_chunk_scatter: more than 2^31-1 chunk rows in one call");
+    ScatterParams p;
+    p.src = (const uint8_t*)a->src_d; p.chunk = (const long long*)a->chunk_d; p.n_chunks = a->n_chunks; p.es = a->elem_size; p.shuffled = a->shuffled;
+    p.ct = a->ct; p.ck = a->ck; p.cj = a->cj; p.ci = a->ci;
+    p.t_base = a->t_base; p.n_tmap = a->n_tmap; p.tmap = a->tmap_d; p.n_kmap = a->n_kmap; p.kmap = a->kmap_d; p.j0 = a->j0;
+    p.nt = a->nt; p.nl = a->nl; p.ny = a->ny; p.nx = a->nx; p.out = (uint8_t*)a->out_d;
+    hipStream_t st = (hipStream_t)a->stream;
+    const dim3 grid((unsigned)blocks), blk(256);
+    if (a->elem_size == 1) hipLaunchKernelGGL(lec_chunk_scatter_kernel<1>, grid, blk, 0, st, p);
+    else if (a->elem_size == 2) hipLaunchKernelGGL(lec_chunk_scatter_kernel<2>, grid, blk, 0, st, p);
+    else if (a->elem_size == 4) hipLaunchKernelGGL(lec_chunk_scatter_kernel<4>, grid, blk, 0, st, p);
+    else hipLaunchKernelGGL(lec_chunk_scatter_kernel<8>, grid, blk, 0, st, p);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return lec_set_error(LEC_ERR_LAUNCH, hipGetErrorString(e));
+    return LEC_OK;
+}
