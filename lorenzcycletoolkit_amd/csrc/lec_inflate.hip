@@ -25,13 +25,24 @@
 #include "../../include/lec_hip.h"
 #include "lec_internal.h"
 
+// measurement knobs (defaults = what ships)
+#ifndef LEC_INFLATE_LITBITS
+#define LEC_INFLATE_LITBITS 10
+#endif
+#ifndef LEC_INFLATE_DISTBITS
+#define LEC_INFLATE_DISTBITS 9
+#endif
+#ifndef LEC_INFLATE_RING
+#define LEC_INFLATE_RING 8192
+#endif
+
 namespace {
 
-constexpr int kLitBits = 11;        // lookup width of the literal / length code (codes up to 15 bits: the rest resolves on demand)
-constexpr int kDistBits = 10;
-constexpr int kRing = 16384;        // LDS history ring (bytes, power of two)
-constexpr int kCap = 4096;          // most output bytes one round of tokens may produce
-constexpr int kFlushAt = 2048;      // pending bytes that trigger a flush of the ring to HBM
+constexpr int kLitBits = LEC_INFLATE_LITBITS;        // lookup width of the literal / length code (codes up to 15 bits: the rest resolves on demand)
+constexpr int kDistBits = LEC_INFLATE_DISTBITS;
+constexpr int kRing = LEC_INFLATE_RING;        // LDS history ring (bytes, power of two)
+constexpr int kCap = kRing / 4;         // most output bytes one round of tokens may produce
+constexpr int kFlushAt = kRing / 8;      // pending bytes that trigger a flush of the ring to HBM
 
 enum { T_LIT = 0, T_MATCH = 1, T_EOB = 2, T_SLOW = 3, T_BAD = 4 };
 
@@ -53,7 +64,12 @@ __device__ __forceinline__ uint32_t rl(uint32_t v, uint32_t lane) { return (uint
 __device__ __forceinline__ uint32_t wl(uint32_t value, uint32_t lane, uint32_t old) {      // `old` with lane `lane` set to the uniform `value`
     return (uint32_t)__lane_id() == lane ? value : old;
 }
-__device__ __forceinline__ void wave_sync() { __syncthreads(); }      // one wave per workgroup: orders its LDS traffic for the compiler
+// One wave per workgroup: its LDS operations execute in program order, so only the COMPILER has to be kept from moving them
+// across this point (an s_barrier would also wait for the prefetched input block, every round).
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 
 // The compressed stream seen through two 64-dword blocks held in registers (lane l: dword blk * 64 + l and the one 64 further):
 // any dword the decoder needs is one v_readlane away, and the next block loads while the current one is consumed.
@@ -176,6 +192,16 @@ __global__ void __launch_bounds__(64) lec_inflate_kernel(const InflateParams P) 
     const uint32_t src_bits = (uint32_t)src_len * 8u;
     const uint32_t out_len = (uint32_t)dst_len;
 
+    if (src_len < 0) {
+        // the chunk was stored as it is (HDF5 skips an optional filter that does not pay): a plain copy
+        const long long n = -src_len;
+        if (n == dst_len) {
+            for (long long q = 16ll * lane; q + 16 <= n; q += 16 * 64) *(uint4*)(out + q) = *(const uint4*)(inb + q);
+            for (long long q = (n & ~15ll) + lane; q < n; q += 64) out[q] = inb[q];
+        }
+        if (lane == 0) { P.status[4 * s + 0] = n == dst_len ? ST_OK : ST_SIZE; P.status[4 * s + 1] = 0; P.status[4 * s + 2] = (int)n; P.status[4 * s + 3] = 0; }
+        return;
+    }
     uint32_t bitpos = 16;           // after the zlib header
     uint32_t opos = 0, flushed = 0, fenced = 0;
     int status = ST_OK, block = 0;
@@ -332,14 +358,27 @@ __global__ void __launch_bounds__(64) lec_inflate_kernel(const InflateParams P) 
                     }
                 }
             }
-            // follow the true chain through the lanes; offsets of the tokens' output
-            uint32_t pos = 0, produced = 0, ooff = 0;
-            uint64_t chain = 0;
+            // Follow the true chain through the lanes.  One word per lane carries what the walk needs of a token: bits used (6) |
+            // type (3) | output bytes (9); a literal -- the common case -- is recognised by one compare and costs one readlane.
+            auto pack = [](uint32_t ty, uint32_t nbits, uint32_t val) { return nbits | (ty << 6) | ((ty == T_LIT ? 1u : ty == T_MATCH ? val : 0u) << 9); };
+            uint32_t info = pack(type, used, value);
+            uint32_t pos = 0, extra_out = 0;            // extra_out: output bytes of the chain's matches beyond one each
+            uint64_t chain = 0;                         // lanes whose token is on the chain and writes output
             const uint32_t win_lo = (uint32_t)win, win_hi = (uint32_t)(win >> 32);
-            while (pos < 64u) {
-                uint32_t ty = rl(type, pos);
+            for (;;) {
+                // a run of literals: the scalar unit is shared by the whole CU, so this inner loop is kept to a handful of
+                // scalar instructions and touches no vector register
+                uint32_t inf = 0;
+                while (pos < 64u) {
+                    inf = rl(info, pos);
+                    if ((inf >> 6) != 8u) break;                                  // not (type 0, one byte)
+                    chain |= 1ull << pos;
+                    pos += inf & 63u;
+                }
+                if (pos >= 64u) break;
+                const uint32_t ty = (inf >> 6) & 7u;
                 if (ty == T_SLOW) {
-                    // a code longer than the lookup width (or none at all): decode this one position canonically
+                    // a code longer than the lookup width (or none at all): decode this one position canonically, then look again
                     uint64_t w = ((uint64_t)rl(win_hi, pos) << 32) | rl(win_lo, pos);
                     uint32_t n = 0, tot;
                     const int sym = canon(w, L.lcnt, L.lsym, n);
@@ -362,28 +401,37 @@ __global__ void __launch_bounds__(64) lec_inflate_kernel(const InflateParams P) 
                             nty = T_MATCH;
                         }
                     }
-                    type = wl(nty, pos, type); used = wl(tot, pos, used); value = wl(nval, pos, value); dist = wl(ndis, pos, dist);
-                    ty = nty;
+                    type = wl(nty, pos, type); value = wl(nval, pos, value); dist = wl(ndis, pos, dist);
+                    info = wl(pack(nty, tot & 63u, nval), pos, info);
+                    continue;
                 }
                 if (ty == T_BAD) { status = ST_BAD_CODE; break; }
-                const uint32_t n_out = ty == T_LIT ? 1u : ty == T_MATCH ? rl(value, pos) : 0u;
-                if (produced + n_out > (uint32_t)kCap) break;                  // the next round starts at this token
-                const uint32_t nbits = rl(used, pos);
-                if (bitpos + pos + nbits > src_bits) { status = ST_INPUT_END; break; }
-                ooff = wl(produced, pos, ooff);
+                if (ty == T_EOB) { pos += inf & 63u; eob = true; break; }
+                const uint32_t n_out = inf >> 9;                                  // a match
+                if ((uint32_t)__popcll(chain) + extra_out + n_out > (uint32_t)kCap) break;       // the next round starts at this token
                 chain |= 1ull << pos;
-                produced += n_out;
-                pos += nbits;
-                if (ty == T_EOB) { eob = true; break; }
+                extra_out += n_out - 1u;
+                pos += inf & 63u;
             }
             if (status != ST_OK) break;
+            if (bitpos + pos > src_bits) { status = ST_INPUT_END; break; }
+            const uint32_t produced = (uint32_t)__popcll(chain) + extra_out;
             if (produced > out_len - opos) { status = ST_OUTPUT_FULL; break; }
             const bool mine = (chain >> lane) & 1ull;
+            uint64_t mm = chain & __ballot(type == T_MATCH);
+            // where each token's output starts: one byte per chain token below it, plus what the matches below it add
+            uint32_t ooff = (uint32_t)__popcll(chain & ((1ull << lane) - 1ull));
+            for (uint64_t m2 = mm; m2;) {
+                const uint32_t i = (uint32_t)__builtin_ctzll(m2);
+                m2 &= m2 - 1ull;
+                const uint32_t add = rl(value, i) - 1u;
+                if ((uint32_t)lane > i) ooff += add;
+            }
             // literals
             if (mine && type == T_LIT) L.ring[(opos + ooff) & (kRing - 1)] = (uint8_t)value;
             // matches, in stream order, 64 bytes at a time
-            uint64_t mm = chain & __ballot(type == T_MATCH);
-            const int safe_lo = (int)opos + kCap - kRing;                      // positions from here on are in the ring for the whole round
+            const int safe_lo = (int)opos + kCap + 64 - kRing;                 // positions from here on are in the ring for the whole round (a round
+                                                                                // writes at most kCap bytes up to its last match, then < 64 literals)
             while (mm) {
                 const uint32_t i = (uint32_t)__builtin_ctzll(mm);
                 mm &= mm - 1ull;

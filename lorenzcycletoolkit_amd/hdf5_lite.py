@@ -76,6 +76,32 @@ class H5Variable:
         return self._file._read_dataset(self, t)
 
 
+    def chunk_streams(self):
+        """What a device-side inflate needs, or None when this variable is not a fully written, deflated, chunked dataset:
+        ``{"chunk": chunk shape, "shuffle": bool, "table": {chunk origin (elements) -> (offset in the mapped file, stored bytes,
+        deflate skipped for this chunk)}, "map": the file's memory map}``.  The stored bytes of a chunk are its zlib stream (a
+        fletcher32 checksum at the end is left out; it is not verified on that path)."""
+        lay = self._layout
+        ids = [fid for fid, _cd in self._filters]
+        if lay.get("class") != "chunked" or 1 not in ids or any(f not in (1, 2, 3) for f in ids):
+            return None
+        if sorted(ids, key=lambda f: {2: 0, 1: 1, 3: 2}[f]) != ids or len(set(ids)) != len(ids):
+            return None                                    # the usual pipeline order only: shuffle, deflate, fletcher32
+        if 2 in ids and self._filters[ids.index(2)][1] and self._filters[ids.index(2)][1][0] != self.dtype.itemsize:
+            return None
+        table = self._file._chunks(self)
+        counts = [-(-s // c) for s, c in zip(self.shape, lay["chunk"])]
+        if len(table) != int(np.prod(counts)):
+            return None                                    # chunks that were never written read as the fill value: host path
+        out = {}
+        for offs, (addr, size, mask) in table.items():
+            skip = [bool(mask & (1 << i)) for i in range(len(ids))]
+            if (2 in ids and skip[ids.index(2)]) or (3 in ids and skip[ids.index(3)]):
+                return None
+            out[offs] = (addr + self._file.base, size - (4 if 3 in ids else 0), skip[ids.index(1)])
+        return {"chunk": tuple(lay["chunk"]), "shuffle": 2 in ids, "table": out, "map": self._file._m}
+
+
 class H5File:
     def __init__(self, path: str):
         self.path = path

@@ -254,6 +254,169 @@ class _Stager:
         return moved
 
 
+class _ChunkStager:
+    """The path of a DEFLATED NetCDF-4 variable to the GPU: the compressed chunks cross the link as they lie in the file and
+    ``lec_inflate`` (one wave per chunk) + ``lec_chunk_scatter`` (un-shuffle, chunk tiling) rebuild the raw sub-cube on the device --
+    the same [steps][staged levels][band rows][nx] layout a ``_Stager`` uploads, so everything downstream is unchanged.  The host
+    only copies compressed bytes (page cache -> pinned); the reference's netCDF4 / HDF5 stack inflates them on one thread.
+
+    ``stage`` / ``upload`` have ``_Stager``'s signatures; the status words of every launch are fetched asynchronously and checked by
+    ``check`` (before a slot is reused and at the end of the run): a corrupt chunk raises ``hdf5_lite.Hdf5Error`` naming it."""
+
+    def __init__(self, var: ds.RawVariable, info: dict, steps: int, device, levels: np.ndarray, j0: int, j1: int, slots: int = 2):
+        self.var, self.info = var, info
+        self.levels = [int(k) for k in levels]
+        self.j0, self.j1 = int(j0), int(j1)
+        shape = tuple(int(x) for x in var.data.shape)
+        self.shape = shape
+        self.nx = shape[3]
+        self.itemsize = var.data.dtype.itemsize
+        self.level_elems = (self.j1 - self.j0 + 1) * self.nx
+        self.step_elems = len(self.levels) * self.level_elems
+        self.chunk = tuple(int(c) for c in info["chunk"])
+        ct, ck, cj, ci = self.chunk
+        self.chunk_bytes = ct * ck * cj * ci * self.itemsize
+        self.slot16 = (self.chunk_bytes + 15) & ~15
+        # the chunk columns every step needs: levels x latitude band x all longitudes
+        kk = sorted({k // ck for k in self.levels})
+        jj = range(self.j0 // cj, self.j1 // cj + 1)
+        ii = range(-(-shape[3] // ci))
+        self.space = [(k * ck, j * cj, i * ci) for k in kk for j in jj for i in ii]
+        table = info["table"]
+        per_tc = {}                                            # stored bytes per time-chunk (16-byte slots): sizes the buffers
+        for tc in range(-(-shape[0] // ct)):
+            per_tc[tc] = sum((table[(tc * ct,) + o][1] + 15) & ~15 for o in self.space)
+        n_tc = min(len(per_tc), steps)                         # every staged step lies in one time-chunk
+        worst = sum(sorted(per_tc.values(), reverse=True)[:n_tc]) + 1024
+        self.max_chunks = n_tc * len(self.space)
+        dev = torch.device(device)
+        self.device = dev
+        carrier = {1: torch.int8, 2: torch.int16, 4: torch.int32, 8: torch.int64}[self.itemsize]
+        self.raw_dev = [torch.empty((steps, self.step_elems), dtype=carrier, device=dev) for _ in range(slots)]
+        self.comp_pin = [torch.empty(worst, dtype=torch.uint8, pin_memory=True) for _ in range(slots)]
+        self.comp_dev = [torch.empty(worst, dtype=torch.uint8, device=dev) for _ in range(slots)]
+        self.inflated = [torch.empty(self.max_chunks * self.slot16 + 16, dtype=torch.uint8, device=dev) for _ in range(slots)]
+        # per chunk: the lec_inflate descriptor (4 int64) and the lec_chunk_scatter record (5 int64), one upload
+        self.meta_pin = [torch.zeros(self.max_chunks * 9, dtype=torch.int64, pin_memory=True) for _ in range(slots)]
+        self.meta_dev = [torch.zeros(self.max_chunks * 9, dtype=torch.int64, device=dev) for _ in range(slots)]
+        self.status_dev = [torch.zeros((self.max_chunks, 4), dtype=torch.int32, device=dev) for _ in range(slots)]
+        self.status_pin = [torch.zeros((self.max_chunks, 4), dtype=torch.int32, pin_memory=True) for _ in range(slots)]
+        self.tmap_pin = [torch.zeros(steps * max(ct, 1) + 2 * ct + 8, dtype=torch.int32, pin_memory=True) for _ in range(slots)]
+        self.tmap_dev = [torch.zeros_like(t, device=dev) for t in self.tmap_pin]
+        kmap = np.full(shape[1], -1, dtype=np.int32)
+        kmap[self.levels] = np.arange(len(self.levels), dtype=np.int32)
+        self.kmap_dev = torch.as_tensor(kmap).to(dev)
+        self.pending = [None] * slots                          # (n chunks, their origins) of the launch whose status is in flight
+        self.staged = [None] * slots
+        self.fetched = [torch.cuda.Event() for _ in range(slots)]
+        self.compressed_bytes = 0
+        self.view = np.frombuffer(info["map"], dtype=np.uint8)
+
+    def direct_ok(self) -> bool:
+        return False
+
+    def stage(self, slot: int, file_steps: np.ndarray, at: int):
+        """The compressed chunks that hold ``file_steps`` -> the slot's pinned buffer (thread pool), descriptors beside them."""
+        self.check(slot)
+        if len(file_steps) == 0:
+            self.staged[slot] = None
+            return
+        ct = self.chunk[0]
+        table = self.info["table"]
+        steps = [int(t) for t in file_steps]
+        tcs = sorted({t // ct for t in steps})
+        origins = [(tc * ct,) + o for tc in tcs for o in self.space]
+        n = len(origins)
+        if n > self.max_chunks:
+            raise RuntimeError("more chunks than the staging buffers were sized for")
+        meta = self.meta_pin[slot].numpy()
+        desc, recs = meta[: 4 * n].reshape(n, 4), meta[4 * n: 9 * n].reshape(n, 5)
+        comp = self.comp_pin[slot].numpy()
+        view = self.view
+        jobs, at_byte = [], 0
+        for c, org in enumerate(origins):
+            addr, size, plain = table[org]
+            if at_byte + size + 1024 > comp.size:
+                raise RuntimeError("compressed chunks exceed the staging buffer")
+            desc[c] = (at_byte, -size if plain else size, c * self.slot16, self.chunk_bytes)
+            recs[c] = (c * self.slot16,) + org
+            jobs.append((comp[at_byte: at_byte + size], view[addr: addr + size]))
+            at_byte += (size + 15) & ~15
+        if len(jobs) == 1:
+            np.copyto(*jobs[0])
+        else:
+            list(_pool().map(lambda j: np.copyto(*j), jobs))
+        t_base = tcs[0] * ct
+        tmap = self.tmap_pin[slot].numpy()
+        n_tmap = (tcs[-1] + 1) * ct - t_base
+        tmap[:n_tmap] = -1
+        for r, t in enumerate(steps):
+            tmap[t - t_base] = at + r
+        self.staged[slot] = (n, at_byte, t_base, n_tmap, origins)
+        self.compressed_bytes += at_byte
+
+    def upload(self, slot: int, a: int, b: int):
+        """Enqueued on the current stream: compressed bytes + descriptors to the device, inflate, scatter into rows [a, b)."""
+        st = self.staged[slot]
+        if st is None:
+            return
+        n, nbytes, t_base, n_tmap, origins = st
+        lib = _lib.load()
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        used = nbytes + 1024
+        self.comp_dev[slot][:used].copy_(self.comp_pin[slot][:used], non_blocking=True)
+        self.meta_dev[slot][: 9 * n].copy_(self.meta_pin[slot][: 9 * n], non_blocking=True)
+        self.tmap_dev[slot][:n_tmap].copy_(self.tmap_pin[slot][:n_tmap], non_blocking=True)
+        desc, recs = self.meta_dev[slot][: 4 * n], self.meta_dev[slot][4 * n: 9 * n]
+        with torch.cuda.device(self.device):
+            ia = _lib.InflateArgs(src_d=self.comp_dev[slot].data_ptr(), src_bytes=used, desc_d=desc.data_ptr(), n_streams=n,
+                                  dst_d=self.inflated[slot].data_ptr(), status_d=self.status_dev[slot].data_ptr(), stream=stream)
+            _lib.check(lib.lec_inflate(C.byref(ia)), "lec_inflate")
+            ct, ck, cj, ci = self.chunk
+            sa = _lib.ChunkScatterArgs(src_d=self.inflated[slot].data_ptr(), chunk_d=recs.data_ptr(), n_chunks=n, elem_size=self.itemsize,
+                                       shuffled=int(self.info["shuffle"]), ct=ct, ck=ck, cj=cj, ci=ci, t_base=t_base, n_tmap=n_tmap,
+                                       n_kmap=self.shape[1], j0=self.j0, tmap_d=self.tmap_dev[slot].data_ptr(), kmap_d=self.kmap_dev.data_ptr(),
+                                       nt=int(self.raw_dev[slot].shape[0]), nl=len(self.levels), ny=self.j1 - self.j0 + 1, nx=self.nx,
+                                       out_d=self.raw_dev[slot].data_ptr(), stream=stream)
+            _lib.check(lib.lec_chunk_scatter(C.byref(sa)), "lec_chunk_scatter")
+        self.status_pin[slot][:n].copy_(self.status_dev[slot][:n], non_blocking=True)
+        self.fetched[slot].record(torch.cuda.current_stream(self.device))
+        self.pending[slot] = (n, origins)
+
+    def check(self, slot: int):
+        """Waits for the slot's last launch and raises if a chunk did not inflate."""
+        p = self.pending[slot]
+        if p is None:
+            return
+        self.pending[slot] = None
+        self.fetched[slot].synchronize()
+        n, origins = p
+        st = self.status_pin[slot][:n, 0].numpy()
+        bad = np.flatnonzero(st != 0)
+        if bad.size:
+            from .hdf5_lite import Hdf5Error
+            c = int(bad[0])
+            what = _lib.load().lec_inflate_status_text(int(st[c])).decode()
+            raise Hdf5Error(f"deflated chunk at {origins[c]} (time, level, lat, lon) did not inflate on the device: {what} ({bad.size} of {n} chunks)")
+
+    def finish(self):
+        for slot in range(len(self.pending)):
+            self.check(slot)
+
+
+def _make_stager(var: ds.RawVariable, steps: int, device, levels, j0: int, j1: int, slots: int, pinned: bool, inflate: str):
+    """``inflate``: "device" -- deflated NetCDF-4 variables are inflated on the GPU (error if the variable is not one);
+    "host" -- the pure-Python reader's thread pool inflates them; "auto" (default): device where the variable allows it."""
+    if inflate not in ("auto", "host", "device"):
+        raise ValueError("inflate must be 'auto', 'host' or 'device'")
+    info = var.data.chunk_streams() if (inflate != "host" and hasattr(var.data, "chunk_streams")) else None
+    if info is not None:
+        return _ChunkStager(var, info, steps, device, levels, j0, j1, slots)
+    if inflate == "device":
+        raise ValueError("inflate='device' needs a fully written, deflated (optionally shuffled / checksummed) chunked NetCDF-4 variable")
+    return _Stager(var, steps, device, levels, j0, j1, slots, pinned=pinned)
+
+
 def _lec_code(dtype: np.dtype) -> int:
     return _lib.LEC_F64 if np.dtype(dtype) == np.float64 else _lib.LEC_F32
 
@@ -280,7 +443,7 @@ def _ingest_call(lib, v: ds.RawVariable, src_ptr: int, nt: int, geom, maps, unit
     _lib.check(lib.lec_ingest(C.byref(ga)), "lec_ingest")
 
 
-def device_cube(var: ds.RawVariable, plan: IngestPlan, device="cuda:0", unit: float = 1.0, out_dtype=None) -> torch.Tensor:
+def device_cube(var: ds.RawVariable, plan: IngestPlan, device="cuda:0", unit: float = 1.0, out_dtype=None, inflate: str = "auto") -> torch.Tensor:
     """One variable of the analysis domain, [time, level, lat, lon] on the device, through the same staging + ``lec_ingest``
     path the streamed frameworks use (all time steps at once: for tests and small domains)."""
     lib = _lib.load()
@@ -290,9 +453,10 @@ def device_cube(var: ds.RawVariable, plan: IngestPlan, device="cuda:0", unit: fl
     out_dtype = np.dtype(decode if out_dtype is None else out_dtype)
     j0, j1 = int(plan.jmap.min()), int(plan.jmap.max())
     file_levels = np.sort(plan.kmap)
-    st = _Stager(var, nt, dev, file_levels, j0, j1, slots=1)
+    st = _make_stager(var, nt, dev, file_levels, j0, j1, 1, True, inflate)
     st.stage(0, plan.tsel, 0)
-    st.upload(0, 0, nt)
+    with torch.cuda.device(dev):
+        st.upload(0, 0, nt)
     up = lambda a: torch.as_tensor(a, dtype=torch.int32).to(dev)
     maps = (up(np.searchsorted(file_levels, plan.kmap)), up(plan.jmap - j0), up(plan.imap))
     out = torch.empty((nt, nl, ny, nx), dtype=torch.float64 if out_dtype == np.float64 else torch.float32, device=dev)
@@ -300,12 +464,14 @@ def device_cube(var: ds.RawVariable, plan: IngestPlan, device="cuda:0", unit: fl
         _ingest_call(lib, var, st.raw_dev[0].data_ptr(), nt, (nl, j1 - j0 + 1, int(var.data.shape[3]), nl, ny, nx), maps, unit,
                      decode, out_dtype, out.data_ptr(), torch.cuda.current_stream(dev))
     torch.cuda.synchronize(dev)
+    if hasattr(st, "finish"):
+        st.finish()
     return out
 
 
 def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_limits, *, per_step_boxes: bool = False,
                  device="cuda:0", chunk_steps: int = 8, with_q: bool = True, stats: Optional[dict] = None,
-                 t_range=None, merge_dropmask=None, out=None, staging: str = "auto") -> LECResult:
+                 t_range=None, merge_dropmask=None, out=None, staging: str = "auto", inflate: str = "auto") -> LECResult:
     """All LEC terms for the whole series, streamed from the memory-mapped file.
 
     ``boxes_limits``: one (west, east, south, north) in degrees (fixed framework, as inputs/box_limits) or one per time step
@@ -315,6 +481,8 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
     directly (no host copy, no staging threads: with eight ranks streaming at once the host's memory carries a third of the traffic);
     "staged" -- a thread pool copies page cache -> pinned buffers first; "auto" (default): registered where every variable is plain
     mapped memory and the runtime accepts the first span, else staged (lazily inflated NetCDF-4 variables, hosts that refuse).
+    ``inflate``: where deflated NetCDF-4 chunks are inflated -- "device" (``lec_inflate``: the link carries the compressed bytes),
+    "host" (the reader's thread pool), "auto" = device wherever the variable allows it (``_make_stager``).
     ``t_range`` = (t0, t1): a rank's share of a time-sharded run -- only those steps (and their one-step T halo) are staged, copied
     and computed, so N ranks move 1/N of the bytes each, over N host links; ``merge_dropmask`` / ``out``: see ``LECEngine.reduce``.
     """
@@ -361,7 +529,7 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
             spans.release(0)
         except _lib.LecLibraryError:
             direct, spans = False, None
-    stagers = {r: _Stager(rvars[r], span, dev, file_levels, j0, j1, slots, pinned=not direct) for r in roles}
+    stagers = {r: _make_stager(rvars[r], span, dev, file_levels, j0, j1, slots, not direct, inflate) for r in roles}
     cubes = [{keys[r]: torch.empty((span, nl, ny, nx), dtype=out_dtype, device=dev) for r in roles} for _ in range(slots)]
     up = lambda a: torch.as_tensor(a, dtype=torch.int32).to(dev)
     maps = (up(np.searchsorted(file_levels, plan.kmap)), up(plan.jmap - j0), up(plan.imap))   # maps into the staged sub-cube
@@ -416,7 +584,8 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
                     host_s += time.perf_counter() - t_host
                 else:
                     stagers[r].upload(slot, a, b)
-                    moved += (b - a) * stagers[r].step_elems * stagers[r].itemsize
+                    if not isinstance(stagers[r], _ChunkStager):
+                        moved += (b - a) * stagers[r].step_elems * stagers[r].itemsize
                 copied[slot][n].record(copier)
             compute.wait_event(copied[slot][n])
             with torch.cuda.device(dev):
@@ -430,12 +599,17 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
                         rows_out=rows[c0 - t0:c1 - t0], per_step_boxes=per_step_boxes)
         used[slot] = True
     res = engine.reduce(rows, own_boxes, phi_scale=phi_scale, drop_any_time=not per_step_boxes, merge_dropmask=merge_dropmask, out=out)
+    on_device = [r for r in roles if isinstance(stagers[r], _ChunkStager)]
+    for r in on_device:
+        stagers[r].finish()                     # every chunk inflated (raises otherwise)
+        moved += stagers[r].compressed_bytes
     if direct:
         copier.synchronize()                    # every copy has read its span
         reg_stats = dict(registered_bytes=spans.registered_bytes, register_calls=spans.calls)
         spans.close()
     if stats is not None:
         stats.update(staging="registered" if direct else "staged", **(reg_stats if direct else {}))
+        stats.update(inflate="device" if on_device else ("host" if any(hasattr(v.data, "chunk_streams") for v in rvars.values()) else "none"))
         stats.update(bytes_moved=moved, host_staging_seconds=host_s, chunks=n_chunks, chunk_steps=chunk_steps, storage=str(out_dtype).replace("torch.", ""),
                      decode={keys[r]: str(d) for r, d in decode.items()}, box=tuple(int(x) for x in boxes[0]), domain=(nt, nl, ny, nx))
     return res

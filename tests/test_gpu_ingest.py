@@ -79,7 +79,8 @@ def test_packed_int16_file_streamed_equals_resident(workdir, chunk_steps):
 @pytest.mark.parametrize("name,storage", [("packed_chunked_tracked.nc", "float32"), ("float_chunked_latest.nc", "float32"),
                                           ("packed_chunked_earliest.nc", "float32")])
 def test_netcdf4_file_streamed_equals_resident(workdir, name, storage):
-    """NetCDF-4 / HDF5 input (hdf5_lite): chunks are inflated on the host per time step, then take the same device path."""
+    """NetCDF-4 / HDF5 input (hdf5_lite): deflated chunks are inflated on the device (lec_inflate; the contiguous-free float file too),
+    then take the same device path -- the resident run inflates on the host."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     path = os.path.join(root, "tests", "golden", "hdf5", name)
     (workdir / "inputs" / "namelist").write_text(
@@ -89,10 +90,76 @@ def test_netcdf4_file_streamed_equals_resident(workdir, name, storage):
     limits = (-60.0, 30.0, -40.0, 30.0)
     (workdir / "inputs" / "box_limits").write_text("min_lon;-60\nmax_lon;30\nmin_lat;-40\nmax_lat;30\n")
     a, b, stats = _both_paths(path, "inputs/namelist", limits, 2)
-    assert stats["storage"] == storage and stats["chunks"] == 3
+    assert stats["storage"] == storage and stats["chunks"] == 3 and stats["inflate"] == "device"
     assert torch.equal(a.scalars, b.scalars)
     assert np.array_equal(a.levels.cpu().numpy(), b.levels.cpu().numpy(), equal_nan=True)
     assert torch.isfinite(a.scalars[:, :4]).all()
+
+
+HDF5_DEFLATED = ["packed_chunked_earliest.nc", "packed_chunked_tracked.nc", "float_chunked_latest.nc", "packed_unlimited_v18.nc",
+                 "packed_unlimited_latest.nc"]
+
+
+@pytest.mark.parametrize("name", HDF5_DEFLATED)
+def test_device_inflate_equals_host_inflate(workdir, name):
+    """Every deflated fixture (v1 B-tree / fixed-array / extensible-array chunk indexes, shuffle, fletcher32 trailers, int16 and
+    float32, chunks of 2 levels x half the longitudes): the raw cube rebuilt by lec_inflate + lec_chunk_scatter and decoded by
+    lec_ingest equals the one the host reader inflates, for the whole domain and for a band of it (whole chunks cross the link
+    compressed; the band is cut out on the device)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "tests", "golden", "hdf5", name)
+    (workdir / "inputs" / "namelist").write_text(ERA5_NAMELIST)
+    args = argparse.Namespace(fixed=True, track=False, trackfile=None)
+    df = ds.read_namelist("inputs/namelist")
+    for limits in ((-60.0, 30.0, -40.0, 30.0), (-170.0, 170.0, -60.0, 60.0)):
+        (workdir / "inputs" / "box_limits").write_text("min_lon;%r\nmax_lon;%r\nmin_lat;%r\nmax_lat;%r\n" % limits)
+        raw = ds.open_raw(path, df)
+        plan = ingest.make_plan(raw, args)
+        for var in ("t", "u", "v", "w", "z"):
+            v = raw.variables[var]
+            assert v.data.chunk_streams() is not None
+            dev = ingest.device_cube(v, plan, inflate="device")
+            host = ingest.device_cube(v, plan, inflate="host")
+            assert dev.dtype == host.dtype and torch.equal(torch.nan_to_num(dev, nan=-1e30), torch.nan_to_num(host, nan=-1e30)), (var, limits)
+        st_d, st_h = {}, {}
+        a = ingest.lec_streamed(raw, plan, df, [limits], chunk_steps=2, stats=st_d, inflate="device")
+        b = ingest.lec_streamed(raw, plan, df, [limits], chunk_steps=2, stats=st_h, inflate="host")
+        assert torch.equal(a.scalars, b.scalars) and np.array_equal(a.levels.cpu().numpy(), b.levels.cpu().numpy(), equal_nan=True)
+        assert st_d["inflate"] == "device" and st_h["inflate"] == "host" and st_d["bytes_moved"] > 0
+        raw.close()
+
+
+def test_corrupt_deflated_chunk_is_reported(workdir, tmp_path):
+    """A flipped byte inside a compressed chunk: the device inflate ends with a status (never a hang) and the host raises Hdf5Error
+    naming the chunk -- or, if the damaged stream still decodes to the right size, the data differ and nothing crashes."""
+    from lorenzcycletoolkit_amd.hdf5_lite import Hdf5Error
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    blob = bytearray(open(os.path.join(root, "tests", "golden", "hdf5", "packed_chunked_earliest.nc"), "rb").read())
+    (workdir / "inputs" / "namelist").write_text(ERA5_NAMELIST)
+    (workdir / "inputs" / "box_limits").write_text("min_lon;-60\nmax_lon;30\nmin_lat;-40\nmax_lat;30\n")
+    df = ds.read_namelist("inputs/namelist")
+    clean = str(tmp_path / "clean.nc")
+    open(clean, "wb").write(blob)
+    raw = ds.open_raw(clean, df)
+    info = raw.variables["t"].data.chunk_streams()
+    addr, size, _plain = info["table"][(1, 0, 0, 0)]
+    raw.close()
+    outcomes = set()
+    for k, at in enumerate((2, 5, size // 2, size - 6)):        # block header, code lengths, the tokens, the end
+        bad = bytearray(blob)
+        bad[addr + at] ^= 0x5A
+        path = str(tmp_path / f"bad{k}.nc")
+        open(path, "wb").write(bad)
+        raw = ds.open_raw(path, df)
+        plan = ingest.make_plan(raw, argparse.Namespace(fixed=True, track=False, trackfile=None))
+        try:
+            ingest.device_cube(raw.variables["t"], plan, inflate="device")
+            outcomes.add("decoded")
+        except Hdf5Error as e:
+            assert "(1, 0, 0, 0)" in str(e) and "did not inflate" in str(e)
+            outcomes.add("reported")
+        raw.close()
+    assert "reported" in outcomes
 
 
 ERA5_NAMES = {"tair": "t", "u": "u", "v": "v", "omega": "w", "geo": "z", "lat": "latitude", "lon": "longitude", "level": "level", "time": "time"}

@@ -102,6 +102,7 @@ def bench(lib, dev, n_streams, level, noise):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--bench", action="store_true")
+    ap.add_argument("--bench-one", nargs=3, metavar=("STREAMS", "LEVEL", "NOISE"), help="one configuration (for profiling)")
     ap.add_argument("--cases", type=int, default=300)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-bytes", type=int, default=1 << 20)
@@ -109,6 +110,9 @@ def main():
     rng = np.random.default_rng(a.seed)
     lib = _lib.load()
     dev = "cuda:0"
+    if a.bench_one:
+        bench(lib, dev, int(a.bench_one[0]), int(a.bench_one[1]), float(a.bench_one[2]))
+        return
     if a.bench:
         for n in (1536, 6144):
             for level, noise in ((4, 0.5), (1, 0.5), (4, 0.02)):
