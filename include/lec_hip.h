@@ -302,7 +302,7 @@ int lec_copy_rows_async(void* dst_d, size_t dst_pitch, const void* src_h, size_t
  * host thread (src/utils/preprocessing.py:35-146 -> xr.open_dataset); here the compressed chunks cross the link as they lie in
  * the file and the GPU inflates them, one wave per chunk:
  *   lec_inflate        n_streams independent zlib streams (RFC 1950 / 1951: stored, fixed and dynamic blocks) -> their
- *                      inflated bytes.  desc_d[s] = {byte offset of the stream in src_d (a multiple of 16), its size, byte offset of
+ *                      inflated bytes.  desc_d[s] = {byte offset of the stream in src_d (any), its size, byte offset of
  *                      its output in dst_d (a multiple of 16), the output's exact size}; a NEGATIVE size marks |size| bytes that are
  *                      not compressed (HDF5 stores a chunk as it is when deflate does not pay) and are copied.  src_bytes is the size of the src_d
  *                      allocation (the kernel reads whole dwords: it may touch up to 512 bytes after a stream's end, never beyond

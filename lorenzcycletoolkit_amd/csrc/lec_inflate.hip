@@ -185,29 +185,37 @@ __global__ void __launch_bounds__(64) lec_inflate_kernel(const InflateParams P) 
     const int s = (int)blockIdx.x;
     const long long src_off = P.desc[4 * s + 0], src_len = P.desc[4 * s + 1], dst_off = P.desc[4 * s + 2], dst_len = P.desc[4 * s + 3];
     uint8_t* const out = P.dst + dst_off;
-    const uint8_t* const inb = P.src + src_off;
-    BitIn in;
-    in.in32 = (const uint32_t*)inb; in.lane = lane;
-    in.nwords = (uint32_t)((P.src_bytes - src_off) >> 2);
-    const uint32_t src_bits = (uint32_t)src_len * 8u;
-    const uint32_t out_len = (uint32_t)dst_len;
-
     if (src_len < 0) {
         // the chunk was stored as it is (HDF5 skips an optional filter that does not pay): a plain copy
         const long long n = -src_len;
+        const uint8_t* const raw = P.src + src_off;
         if (n == dst_len) {
-            for (long long q = 16ll * lane; q + 16 <= n; q += 16 * 64) *(uint4*)(out + q) = *(const uint4*)(inb + q);
-            for (long long q = (n & ~15ll) + lane; q < n; q += 64) out[q] = inb[q];
+            if (((uintptr_t)raw & 15u) == 0) {
+                for (long long q = 16ll * lane; q + 16 <= n; q += 16 * 64) *(uint4*)(out + q) = *(const uint4*)(raw + q);
+                for (long long q = (n & ~15ll) + lane; q < n; q += 64) out[q] = raw[q];
+            } else {
+                for (long long q = lane; q < n; q += 64) out[q] = raw[q];
+            }
         }
         if (lane == 0) { P.status[4 * s + 0] = n == dst_len ? ST_OK : ST_SIZE; P.status[4 * s + 1] = 0; P.status[4 * s + 2] = (int)n; P.status[4 * s + 3] = 0; }
         return;
     }
-    uint32_t bitpos = 16;           // after the zlib header
+    // a stream may start at any byte (chunks lie in the file as HDF5 put them): the dword view starts at the aligned address
+    // below it, and every bit position carries the offset
+    const uint32_t lead = (uint32_t)(src_off & 3);
+    const uint8_t* const inb = P.src + (src_off - lead);
+    BitIn in;
+    in.in32 = (const uint32_t*)inb; in.lane = lane;
+    in.nwords = (uint32_t)((P.src_bytes - (src_off - lead)) >> 2);
+    const uint32_t src_end = lead + (uint32_t)src_len;          // in bytes from inb
+    const uint32_t src_bits = src_end * 8u;
+    const uint32_t out_len = (uint32_t)dst_len;
+    uint32_t bitpos = lead * 8u + 16u;           // after the zlib header
     uint32_t opos = 0, flushed = 0, fenced = 0;
     int status = ST_OK, block = 0;
-    in.reset(0);
+    in.reset(lead * 8u);
     {
-        const uint32_t h = in.peek(0);
+        const uint32_t h = in.peek(lead * 8u);
         const uint32_t cmf = h & 0xffu, flg = (h >> 8) & 0xffu;
         if (src_len < 6 || (cmf & 0x0fu) != 8u || (cmf >> 4) > 7u || ((cmf << 8) | flg) % 31u != 0u || (flg & 0x20u)) status = ST_HEADER;
     }
@@ -245,7 +253,7 @@ __global__ void __launch_bounds__(64) lec_inflate_kernel(const InflateParams P) 
             if (len != ((~ll >> 16) & 0xffffu)) { status = ST_STORED; break; }
             bitpos += 32;
             uint32_t at = bitpos >> 3;
-            if ((uint64_t)at + len > (uint64_t)src_len) { status = ST_INPUT_END; break; }
+            if ((uint64_t)at + len > (uint64_t)src_end) { status = ST_INPUT_END; break; }
             if (len > out_len - opos) { status = ST_OUTPUT_FULL; break; }
             while (len) {
                 const uint32_t n = len < (uint32_t)kCap ? len : (uint32_t)kCap;
@@ -546,7 +554,7 @@ extern "C" int lec_inflate(const lec_inflate_args* a) {
     if (!a) return lec_set_error(LEC_ERR_ARG, "lec_inflate: null args");
     if (!a->src_d || !a->desc_d || !a->dst_d || !a->status_d) return lec_set_error(LEC_ERR_ARG, "lec_inflate: null pointer argument");
     if (a->n_streams < 1 || a->src_bytes < 8) return lec_set_error(LEC_ERR_ARG, "lec_inflate: n_streams >= 1 and src_bytes >= 8 needed");
-    if (((uintptr_t)a->src_d & 15u) || ((uintptr_t)a->dst_d & 15u)) return lec_set_error(LEC_ERR_ARG, "lec_inflate: src_d and dst_d must be 16-byte aligned");
+    if (((uintptr_t)a->src_d & 3u) || ((uintptr_t)a->dst_d & 15u)) return lec_set_error(LEC_ERR_ARG, "lec_inflate: src_d must be 4-byte, dst_d 16-byte aligned");
     InflateParams p;
     p.src = (const uint8_t*)a->src_d; p.src_bytes = a->src_bytes; p.desc = (const long long*)a->desc_d; p.n = a->n_streams;
     p.dst = (uint8_t*)a->dst_d; p.status = a->status_d;

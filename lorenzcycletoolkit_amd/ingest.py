@@ -281,13 +281,15 @@ class _ChunkStager:
         kk = sorted({k // ck for k in self.levels})
         jj = range(self.j0 // cj, self.j1 // cj + 1)
         ii = range(-(-shape[3] // ci))
-        self.space = [(k * ck, j * cj, i * ci) for k in kk for j in jj for i in ii]
-        table = info["table"]
-        per_tc = {}                                            # stored bytes per time-chunk (16-byte slots): sizes the buffers
-        for tc in range(-(-shape[0] // ct)):
-            per_tc[tc] = sum((table[(tc * ct,) + o][1] + 15) & ~15 for o in self.space)
-        n_tc = min(len(per_tc), steps)                         # every staged step lies in one time-chunk
-        worst = sum(sorted(per_tc.values(), reverse=True)[:n_tc]) + 1024
+        self.space = np.array([(k * ck, j * cj, i * ci) for k in kk for j in jj for i in ii], dtype=np.int64)
+        self._tc = {}                                          # time-chunk -> (file offsets, stored sizes, stored-as-is flags) of its chunks
+        n_all = -(-shape[0] // ct)
+        n_tc = min(n_all, steps)                               # every staged step lies in one time-chunk
+        # staging capacity: the `steps` largest time-chunks (sampled when the series is long), with room for the gaps of a
+        # span copy (see stage) and the padding of the last stream
+        sample = range(n_all) if n_all <= 64 else sorted(set(np.linspace(0, n_all - 1, 64).astype(int).tolist()))
+        per_tc = sorted((int(((self._time_chunk(tc)[1] + 15) & ~15).sum()) for tc in sample), reverse=True)
+        worst = int(1.35 * sum(per_tc[:n_tc]) * (1.0 if n_all <= 64 else 1.15)) + (4 << 20)
         self.max_chunks = n_tc * len(self.space)
         dev = torch.device(device)
         self.device = dev
@@ -311,9 +313,22 @@ class _ChunkStager:
         self.fetched = [torch.cuda.Event() for _ in range(slots)]
         self.compressed_bytes = 0
         self.view = np.frombuffer(info["map"], dtype=np.uint8)
+        # its own stream: a launch lasts as long as ONE chunk takes one wave (tens of ms for a 0.5 MB chunk) however few chunks it
+        # holds, so the five variables of a step must inflate side by side, not one after the other on the copy stream
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(slots)]      # per slot: consecutive batches overlap too (the tail
+                                                                                   # of one batch leaves most of the GPU idle)
 
     def direct_ok(self) -> bool:
         return False
+
+    def _time_chunk(self, tc: int):
+        got = self._tc.get(tc)
+        if got is None:
+            table, t0 = self.info["table"], tc * self.chunk[0]
+            rows = [table[(t0, int(k), int(j), int(i))] for k, j, i in self.space]
+            got = self._tc[tc] = (np.array([r[0] for r in rows], dtype=np.int64), np.array([r[1] for r in rows], dtype=np.int64),
+                                  np.array([r[2] for r in rows], dtype=bool))
+        return got
 
     def stage(self, slot: int, file_steps: np.ndarray, at: int):
         """The compressed chunks that hold ``file_steps`` -> the slot's pinned buffer (thread pool), descriptors beside them."""
@@ -322,30 +337,49 @@ class _ChunkStager:
             self.staged[slot] = None
             return
         ct = self.chunk[0]
-        table = self.info["table"]
         steps = [int(t) for t in file_steps]
         tcs = sorted({t // ct for t in steps})
-        origins = [(tc * ct,) + o for tc in tcs for o in self.space]
-        n = len(origins)
+        parts = [self._time_chunk(tc) for tc in tcs]
+        addr, size, plain = (np.concatenate([p[i] for p in parts]) for i in range(3))
+        m = len(self.space)
+        n = m * len(tcs)
         if n > self.max_chunks:
             raise RuntimeError("more chunks than the staging buffers were sized for")
+        origins = np.empty((n, 4), dtype=np.int64)
+        origins[:, 0] = np.repeat(np.array(tcs, dtype=np.int64) * ct, m)
+        origins[:, 1:] = np.tile(self.space, (len(tcs), 1))
+        view = self.view
+        lo, hi = int(addr.min()), int((addr + size).max())
+        piece = 8 << 20
+        dense = hi - lo <= 1.3 * int(size.sum()) + (1 << 20)
+        need = (hi - lo + 16) if dense else int(((size + 15) & ~15).sum())
+        if need + 2048 > self.comp_pin[slot].numel():           # a time-chunk larger than the sampled ones: grow this slot's buffers
+            grown = int(1.25 * need) + (4 << 20)                # (its last launch has completed: check() above)
+            self.comp_pin[slot] = torch.empty(grown, dtype=torch.uint8, pin_memory=True)
+            self.comp_dev[slot] = torch.empty(grown, dtype=torch.uint8, device=self.device)
+        comp = self.comp_pin[slot].numpy()
+        if dense:
+            # the chunks lie (almost) back to back in the file, as a writer that fills a variable step by step leaves them: ONE span
+            # copy in 8 MiB pieces (per-chunk jobs of a few 100 KB leave the thread pool waiting for the GIL: 11 GB/s instead of > 50)
+            lead = lo & 15
+            src_off = lead + (addr - lo)
+            used = lead + (hi - lo)
+            jobs = [(comp[lead + a: lead + min(a + piece, hi - lo)], view[lo + a: lo + min(a + piece, hi - lo)]) for a in range(0, hi - lo, piece)]
+        else:
+            pad = (size + 15) & ~15
+            src_off = np.concatenate([[0], np.cumsum(pad)[:-1]])
+            used = int(pad.sum())
+            jobs = [(comp[o: o + z], view[a: a + z]) for o, a, z in zip(src_off.tolist(), addr.tolist(), size.tolist())]
         meta = self.meta_pin[slot].numpy()
         desc, recs = meta[: 4 * n].reshape(n, 4), meta[4 * n: 9 * n].reshape(n, 5)
-        comp = self.comp_pin[slot].numpy()
-        view = self.view
-        jobs, at_byte = [], 0
-        for c, org in enumerate(origins):
-            addr, size, plain = table[org]
-            if at_byte + size + 1024 > comp.size:
-                raise RuntimeError("compressed chunks exceed the staging buffer")
-            desc[c] = (at_byte, -size if plain else size, c * self.slot16, self.chunk_bytes)
-            recs[c] = (c * self.slot16,) + org
-            jobs.append((comp[at_byte: at_byte + size], view[addr: addr + size]))
-            at_byte += (size + 15) & ~15
+        slots16 = np.arange(n, dtype=np.int64) * self.slot16
+        desc[:, 0], desc[:, 1], desc[:, 2], desc[:, 3] = src_off, np.where(plain, -size, size), slots16, self.chunk_bytes
+        recs[:, 0], recs[:, 1:] = slots16, origins
         if len(jobs) == 1:
             np.copyto(*jobs[0])
         else:
             list(_pool().map(lambda j: np.copyto(*j), jobs))
+        at_byte = used
         t_base = tcs[0] * ct
         tmap = self.tmap_pin[slot].numpy()
         n_tmap = (tcs[-1] + 1) * ct - t_base
@@ -397,7 +431,8 @@ class _ChunkStager:
             from .hdf5_lite import Hdf5Error
             c = int(bad[0])
             what = _lib.load().lec_inflate_status_text(int(st[c])).decode()
-            raise Hdf5Error(f"deflated chunk at {origins[c]} (time, level, lat, lon) did not inflate on the device: {what} ({bad.size} of {n} chunks)")
+            raise Hdf5Error(f"deflated chunk at {tuple(int(x) for x in origins[c])} (time, level, lat, lon) did not inflate on the device: {what} "
+                            f"({bad.size} of {n} chunks)")
 
     def finish(self):
         for slot in range(len(self.pending)):
@@ -575,9 +610,10 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
             if not direct:
                 stagers[r].stage(slot, plan.tsel[h0 + a: h0 + b], a)
             host_s += time.perf_counter() - t_host
-            with torch.cuda.stream(copier):
-                if used[slot] and n == 0:
-                    copier.wait_event(consumed[slot])   # the raw device buffers of this slot have been decoded
+            up = stagers[r].streams[slot] if hasattr(stagers[r], "streams") else copier   # a deflated variable uploads and inflates on its own stream
+            with torch.cuda.stream(up):
+                if used[slot] and (n == 0 or up is not copier):
+                    up.wait_event(consumed[slot])       # the raw device buffers of this slot have been decoded
                 if direct:
                     t_host = time.perf_counter()
                     moved += stagers[r].upload_direct(lib, spans, slot, plan.tsel[h0 + a: h0 + b], a, c, C.c_void_p(copier.cuda_stream))
@@ -586,7 +622,7 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
                     stagers[r].upload(slot, a, b)
                     if not isinstance(stagers[r], _ChunkStager):
                         moved += (b - a) * stagers[r].step_elems * stagers[r].itemsize
-                copied[slot][n].record(copier)
+                copied[slot][n].record(up)
             compute.wait_event(copied[slot][n])
             with torch.cuda.device(dev):
                 unit = 1.0 if r == geo_role else ds.field_scale(variable_list_df, r)

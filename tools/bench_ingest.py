@@ -19,7 +19,11 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--src", choices=["i16", "f32", "f64"], default="i16", help="dtype of the 'file' variables in host memory")
+    ap.add_argument("--src", choices=["i16", "f32", "f64", "i16z"], default="i16", help="dtype of the 'file' variables in host memory; "
+                    "i16z: int16 in shuffled + deflated HDF5-style chunks (what a NetCDF-4 ERA5 file holds)")
+    ap.add_argument("--inflate", choices=["auto", "host", "device"], default="auto", help="i16z: where the chunks are inflated")
+    ap.add_argument("--deflate-level", type=int, default=4)
+    ap.add_argument("--chunk-shape", default="1,1,361,720", help="i16z: HDF5 chunk shape (time, level, lat, lon)")
     ap.add_argument("--timesteps", type=int, default=16)
     ap.add_argument("--chunk", type=int, default=4)
     ap.add_argument("--repeat", type=int, default=3)
@@ -55,7 +59,7 @@ def main():
         f = synthetic_cube(n, level, lat, lon, device=dev, dtype=torch.float64, seed=1234, t0_global=t0)
         for name, key in keys.items():
             a = f[key].flip(2).index_select(3, lon_idx)          # file order of lat / lon
-            if args.src == "i16":
+            if args.src in ("i16", "i16z"):
                 if t0 == 0:
                     lo, hi = float(a.min()) - 1.0, float(a.max()) + 1.0
                     variables[name] = dict(scale=(hi - lo) / 64000.0, offset=0.5 * (hi + lo), parts=[])
@@ -68,8 +72,14 @@ def main():
         del f
     torch.cuda.empty_cache()
     raw_vars = {}
+    ratio = None
     for name, v in variables.items():
         a = np.concatenate(v["parts"], axis=0)
+        if args.src == "i16z":
+            dv = DeflatedVar(a, tuple(int(x) for x in args.chunk_shape.split(",")), args.deflate_level)
+            ratio = dv.ratio
+            raw_vars[name] = ds.RawVariable(dv, v["scale"], v["offset"], -32767.0)
+            continue
         be = a.astype(a.dtype.newbyteorder(">"))                   # classic NetCDF stores big-endian
         raw_vars[name] = ds.RawVariable(be, v["scale"], v["offset"], -32767.0 if args.src == "i16" else None)
     time = np.datetime64("2020-01-01T00", "ns") + (np.arange(T) * 3600 * 10 ** 9).astype("timedelta64[ns]")
@@ -85,7 +95,7 @@ def main():
     for r in range(args.repeat + 1):                               # first pass = warm-up (pinned allocations, page faults)
         torch.cuda.synchronize()
         t0 = time_now()
-        res = ingest.lec_fixed_streamed(raw, plan, df, limits, chunk_steps=args.chunk, stats=stats, staging=args.staging)
+        res = ingest.lec_fixed_streamed(raw, plan, df, limits, chunk_steps=args.chunk, stats=stats, staging=args.staging, inflate=args.inflate)
         torch.cuda.synchronize()
         dt = time_now() - t0
         if r > 0:
@@ -96,7 +106,60 @@ def main():
         "value": T / best, "unit": "timesteps/s", "source_dtype": args.src, "timesteps": T, "chunk_steps": args.chunk,
         "seconds": best, "bytes_moved": stats["bytes_moved"], "host_to_device_GBs": stats["bytes_moved"] / best / 1e9,
         "storage_on_device": stats["storage"], "staging": stats["staging"], "host_staging_seconds": stats["host_staging_seconds"],
-        "register_calls": stats.get("register_calls"), "results_finite": finite}))
+        "register_calls": stats.get("register_calls"), "results_finite": finite, "inflate": stats.get("inflate"),
+        "deflate_ratio": ratio, "decoded_GBs": (T * 5 * len(level) * args.ny * args.nx * 2 / best / 1e9) if args.src == "i16z" else None}))
+
+
+class DeflatedVar:
+    """An int16 variable as a NetCDF-4 file holds it -- little-endian, HDF5 chunks, shuffle + deflate -- kept in host memory: the face
+    hdf5_lite.H5Variable shows the ingest (shape, dtype, ``var[t]`` inflating on the host's thread pool, ``chunk_streams()``)."""
+
+    def __init__(self, a, chunk, level):
+        import zlib
+        from concurrent.futures import ThreadPoolExecutor
+        self.shape, self.dtype, self.chunk = a.shape, np.dtype("<i2"), chunk
+        ct, ck, cj, ci = chunk
+        origins = [(t, k, j, i) for t in range(0, a.shape[0], ct) for k in range(0, a.shape[1], ck)
+                   for j in range(0, a.shape[2], cj) for i in range(0, a.shape[3], ci)]
+
+        def pack(o):
+            blk = np.zeros(chunk, dtype="<i2")
+            part = a[o[0]: o[0] + ct, o[1]: o[1] + ck, o[2]: o[2] + cj, o[3]: o[3] + ci]
+            blk[: part.shape[0], : part.shape[1], : part.shape[2], : part.shape[3]] = part
+            return zlib.compress(blk.reshape(-1).view(np.uint8).reshape(-1, 2).T.tobytes(), level)
+
+        with ThreadPoolExecutor(16) as pool:
+            streams = list(pool.map(pack, origins))
+        self.table, at = {}, 0
+        for o, z in zip(origins, streams):
+            self.table[o] = (at, len(z), False)
+            at += len(z)
+        self.blob = np.frombuffer(b"".join(streams), dtype=np.uint8)
+        self.ratio = a.nbytes / self.blob.size
+
+    def chunk_streams(self):
+        return {"chunk": self.chunk, "shuffle": True, "table": self.table, "map": self.blob}
+
+    def __getitem__(self, t):
+        import zlib
+        from lorenzcycletoolkit_amd.hdf5_lite import _inflate_pool
+        ct, ck, cj, ci = self.chunk
+        t0 = (int(t) // ct) * ct
+        out = np.empty(self.shape[1:], dtype=self.dtype)
+        need = [o for o in self.table if o[0] == t0]
+
+        def one(o):
+            addr, size, _ = self.table[o]
+            raw = zlib.decompress(self.blob[addr: addr + size])
+            n = len(raw) // 2
+            blk = np.empty((n, 2), dtype=np.uint8)
+            np.copyto(blk, np.frombuffer(raw, dtype=np.uint8).reshape(2, n).T)
+            blk = blk.reshape(-1).view("<i2").reshape(self.chunk)[int(t) - t0]
+            k1, j1, i1 = min(o[1] + ck, self.shape[1]), min(o[2] + cj, self.shape[2]), min(o[3] + ci, self.shape[3])
+            out[o[1]: k1, o[2]: j1, o[3]: i1] = blk[: k1 - o[1], : j1 - o[2], : i1 - o[3]]
+
+        list(_inflate_pool().map(one, need))
+        return out
 
 
 def time_now():
