@@ -235,7 +235,15 @@ def _create_level_csvs(directory, time_name, vert_name, level_pa):
         pd.DataFrame(columns=columns).to_csv(Path(directory, f"{term}_{vert_name}.csv"), index=None)
 
 
+def _log_ingest(box_obj, app_logger):
+    st = getattr(box_obj, "ingest_stats", None)
+    if st:
+        app_logger.info("Device ingest: %.1f MB over the link in %d chunk(s) of %d step(s), staging %s, inflate %s, storage %s" % (
+            st["bytes_moved"] / 1e6, st["chunks"], st["chunk_steps"], st["staging"], st.get("inflate", "none"), st["storage"]))
+
+
 def _compute_all(box_obj, method, app_logger):
+    _log_ingest(box_obj, app_logger)
     ec = EnergyContents(box_obj, method, app_logger)
     out = {"Az": ec.calc_az(), "Ae": ec.calc_ae(), "Kz": ec.calc_kz(), "Ke": ec.calc_ke()}
     ct = ConversionTerms(box_obj, method, app_logger)

@@ -150,3 +150,31 @@ def test_sharded_over_rccl(workdir, golden_dir):
     _fresh(results)
     _run([infile, "-r", "-f", "--gpus", str(min(torch.cuda.device_count(), 4))], backend="nccl")
     _same_tree(one, _tree(results), "RCCL")
+
+
+def test_deflated_netcdf4_file_through_the_cli(workdir):
+    """A shuffled + deflated NetCDF-4 file (tests/golden/hdf5/packed_chunked_tracked.nc, int16 with fill values) through the command
+    line: host-prepared resident run, ``--device-ingest`` (the chunks inflate on the GPU: lec_inflate) and the same on two ranks, where
+    every rank inflates only its own steps' chunks -- three times the same bytes, for the fixed box and for a track."""
+    src = os.path.join(ROOT, "tests", "golden", "hdf5", "packed_chunked_tracked.nc")
+    (workdir / "inputs" / "namelist").write_text(
+        ";Variable;Units\nAir Temperature;t;K\nGeopotential;z;m**2/s**2\nOmega Velocity;w;Pa/s\n"
+        "Eastward Wind Component;u;m/s\nNorthward Wind Component;v;m/s\nLongitude;longitude\nLatitude;latitude\n"
+        "Time;time\nVertical Level;level\n")
+    (workdir / "inputs" / "box_limits").write_text("min_lon;-60\nmax_lon;30\nmin_lat;-40\nmax_lat;30\n")
+    (workdir / "inputs" / "track").write_text(
+        "time;Lat;Lon;width;length\n" + "".join(f"2020-01-01-{6 * t:02d}00;{-10 + 5 * t};{-30 + 10 * t};60;50\n" for t in range(4)))
+    for flag, name in (("-f", "fixed"), ("-t", "track")):
+        results = workdir / "LEC_Results" / f"packed_chunked_tracked_{name}"
+        _fresh(results)
+        _run([src, "-r", flag])
+        one = _tree(results)
+        df = pd.read_csv(results / f"packed_chunked_tracked_{name}_results.csv", index_col=0)
+        assert len(df) == (5 if name == "fixed" else 4) and np.isfinite(df[["Az", "Ae", "Kz", "Ke"]].values).all()
+        _fresh(results)
+        _run([src, "-r", flag, "--device-ingest"])
+        _same_tree(one, _tree(results), f"{name}: --device-ingest (device inflate)")
+        assert "inflate" in open(results / "log.packed_chunked_tracked").read()
+        _fresh(results)
+        _run([src, "-r", flag, "--device-ingest", "--gpus", "2"])
+        _same_tree(one, _tree(results), f"{name}: --device-ingest on 2 ranks")
