@@ -40,7 +40,7 @@ def pack(a):
     return np.clip(np.round((a - offset) / scale), -32000, 32000).astype(np.int16), float(scale), float(offset)
 
 
-def write(path, libver, track_order, packed, chunks, vlen_units, many_attrs, nt=5, nl=6, ny=13, nx=24, unlimited=False):
+def write(path, libver, track_order, packed, chunks, vlen_units, many_attrs, nt=5, nl=6, ny=13, nx=24, unlimited=False, time_chunk=1):
     lev, lat, lon, f = fields(nt, nl, ny, nx)
     with h5py.File(path, "w", libver=libver, track_order=track_order) as h:
         h.attrs["Conventions"] = np.string_("CF-1.6")
@@ -58,7 +58,7 @@ def write(path, libver, track_order, packed, chunks, vlen_units, many_attrs, nt=
         for name, a in f.items():
             kw = {}
             if chunks:
-                kw = dict(chunks=(1, 2, ny, nx // 2), compression="gzip", compression_opts=4, shuffle=True)
+                kw = dict(chunks=(time_chunk, 2, ny if time_chunk == 1 else 5, nx // 2), compression="gzip", compression_opts=4, shuffle=True)
             if unlimited:
                 kw.update(maxshape=(None, nl, ny, nx), fletcher32=True)
             if packed:
@@ -120,5 +120,7 @@ if __name__ == "__main__":
     write(os.path.join(OUT, "float_chunked_latest.nc"), "latest", False, False, True, False, False)
     write(os.path.join(OUT, "packed_unlimited_v18.nc"), ("earliest", "v108"), True, True, True, False, False, unlimited=True)
     write(os.path.join(OUT, "packed_unlimited_latest.nc"), "latest", False, True, True, True, False, unlimited=True)    # extensible-array chunk index
+    # chunks that span two time steps and tile the latitudes unevenly (5 + 5 + 3 rows): what a writer with its own chunk cache leaves
+    write(os.path.join(OUT, "packed_timechunk2_latest.nc"), "latest", False, True, True, False, False, time_chunk=2)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
