@@ -35,6 +35,9 @@
 #ifndef LEC_INFLATE_RING
 #define LEC_INFLATE_RING 8192
 #endif
+#ifndef LEC_INFLATE_C_WALK
+#define LEC_INFLATE_C_WALK 0
+#endif
 
 namespace {
 
@@ -368,7 +371,9 @@ __global__ void __launch_bounds__(64) lec_inflate_kernel(const InflateParams P) 
             }
             // Follow the true chain through the lanes.  One word per lane carries what the walk needs of a token: bits used (6) |
             // type (3) | output bytes (9); a literal -- the common case -- is recognised by one compare and costs one readlane.
-            auto pack = [](uint32_t ty, uint32_t nbits, uint32_t val) { return nbits | (ty << 6) | ((ty == T_LIT ? 1u : ty == T_MATCH ? val : 0u) << 9); };
+            auto pack = [](uint32_t ty, uint32_t nbits, uint32_t val) {
+                return nbits | (ty << 6) | ((ty == T_LIT ? 1u : ty == T_MATCH ? val : 0u) << 9) | (ty == T_LIT ? 0x80000000u : 0u);      // sign bit: a literal
+            };
             uint32_t info = pack(type, used, value);
             uint32_t pos = 0, extra_out = 0;            // extra_out: output bytes of the chain's matches beyond one each
             uint64_t chain = 0;                         // lanes whose token is on the chain and writes output
@@ -377,12 +382,34 @@ __global__ void __launch_bounds__(64) lec_inflate_kernel(const InflateParams P) 
                 // a run of literals: the scalar unit is shared by the whole CU, so this inner loop is kept to a handful of
                 // scalar instructions and touches no vector register
                 uint32_t inf = 0;
+#if LEC_INFLATE_C_WALK
                 while (pos < 64u) {
                     inf = rl(info, pos);
-                    if ((inf >> 6) != 8u) break;                                  // not (type 0, one byte)
+                    if ((int)inf >= 0) break;                                     // not a literal
                     chain |= 1ull << pos;
                     pos += inf & 63u;
                 }
+#else
+                // written out: the compiler's version of the loop above is 14 scalar instructions per literal (three branches, a
+                // 64-bit shift + or for the chain bit); these are 8.  Leaves with pos >= 64, or with `inf` = the non-literal at pos.
+                if (pos < 64u) {
+                    uint32_t tmp;
+                    asm volatile(
+                        "1:\n\t"
+                        "v_readlane_b32 %[inf], %[info], %[pos]\n\t"
+                        "s_cmp_lt_i32 %[inf], 0\n\t"
+                        "s_cbranch_scc0 2f\n\t"
+                        "s_bitset1_b64 %[chain], %[pos]\n\t"
+                        "s_and_b32 %[tmp], %[inf], 63\n\t"
+                        "s_add_u32 %[pos], %[pos], %[tmp]\n\t"
+                        "s_cmp_lt_u32 %[pos], 64\n\t"
+                        "s_cbranch_scc1 1b\n\t"
+                        "2:"
+                        : [inf] "=&s"(inf), [pos] "+s"(pos), [chain] "+s"(chain), [tmp] "=&s"(tmp)
+                        : [info] "v"(info)
+                        : "scc");
+                }
+#endif
                 if (pos >= 64u) break;
                 const uint32_t ty = (inf >> 6) & 7u;
                 if (ty == T_SLOW) {
