@@ -94,7 +94,7 @@ class DiagArgs(C.Structure):
 
 class InflateArgs(C.Structure):
     """struct lec_inflate_args (include/lec_hip.h)."""
-    _fields_ = [("src_d", C.c_void_p), ("src_bytes", C.c_int64), ("desc_d", C.c_void_p), ("n_streams", C.c_int32), ("reserved0", C.c_int32),
+    _fields_ = [("src_d", C.c_void_p), ("src_bytes", C.c_int64), ("desc_d", C.c_void_p), ("n_streams", C.c_int32), ("flags", C.c_int32),
                 ("dst_d", C.c_void_p), ("status_d", C.c_void_p), ("stream", C.c_void_p)]
 
 

@@ -173,13 +173,33 @@ __device__ int build_code(const uint8_t* lens, int n, uint16_t* table, int bits,
 
 struct InflateParams {
     const uint8_t* src; long long src_bytes;
-    const long long* desc; int n;
+    const long long* desc; int n; int flags;
     uint8_t* dst; int* status;
 };
 
+// HDF5's Fletcher-32 (H5_checksum_fletcher32: 16-bit big-endian words, sums folded with end-around carry) of `len` bytes, by one wave.
+// With S1 = sum w_i and S2 = sum (n - i) w_i exact in 64 bits, the folded sums are ((x - 1) mod 65535) + 1 for x > 0.
+__device__ uint32_t fletcher32_wave(const uint8_t* p, long long len, int lane) {
+    const long long n = (len + 1) / 2;                           // an odd last byte counts as (byte << 8)
+    unsigned long long s1 = 0, s2 = 0;
+    for (long long i = lane; i < n; i += 64) {
+        const uint32_t hi = p[2 * i], lo = (2 * i + 1 < len) ? p[2 * i + 1] : 0u;
+        const unsigned long long w = (hi << 8) | lo;
+        s1 += w;
+        s2 += (unsigned long long)(n - i) * w;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        s1 += ((unsigned long long)__shfl_xor((unsigned)(s1 >> 32), off) << 32) | __shfl_xor((unsigned)s1, off);
+        s2 += ((unsigned long long)__shfl_xor((unsigned)(s2 >> 32), off) << 32) | __shfl_xor((unsigned)s2, off);
+    }
+    const uint32_t f1 = s1 ? (uint32_t)((s1 - 1) % 65535ull) + 1u : 0u, f2 = s2 ? (uint32_t)((s2 - 1) % 65535ull) + 1u : 0u;
+    return (f2 << 16) | f1;
+}
+
 enum {
     ST_OK = 0, ST_HEADER = 1, ST_BLOCK_TYPE = 2, ST_STORED = 3, ST_CODE_LENGTHS = 4, ST_OVERSUBSCRIBED = 5, ST_BAD_CODE = 6,
-    ST_DISTANCE = 7, ST_INPUT_END = 8, ST_OUTPUT_FULL = 9, ST_SIZE = 10, ST_STALLED = 11
+    ST_DISTANCE = 7, ST_INPUT_END = 8, ST_OUTPUT_FULL = 9, ST_SIZE = 10, ST_STALLED = 11, ST_CHECKSUM = 12
 };
 
 __global__ void __launch_bounds__(64) lec_inflate_kernel(const InflateParams P) {
@@ -188,6 +208,19 @@ __global__ void __launch_bounds__(64) lec_inflate_kernel(const InflateParams P) 
     const int s = (int)blockIdx.x;
     const long long src_off = P.desc[4 * s + 0], src_len = P.desc[4 * s + 1], dst_off = P.desc[4 * s + 2], dst_len = P.desc[4 * s + 3];
     uint8_t* const out = P.dst + dst_off;
+    if (P.flags & 1) {
+        // HDF5 filter 3: the stored chunk ends with the Fletcher-32 of everything before it (little-endian; the library also accepts
+        // the byte-swapped form that 1.6.2 wrote on little-endian hosts, H5Zfletcher32.c)
+        const long long n = src_len < 0 ? -src_len : src_len;
+        const uint8_t* q = P.src + src_off;
+        const uint32_t c = fletcher32_wave(q, n, lane);
+        const uint32_t stored = (uint32_t)q[n] | ((uint32_t)q[n + 1] << 8) | ((uint32_t)q[n + 2] << 16) | ((uint32_t)q[n + 3] << 24);
+        const uint32_t swapped = ((c & 0x00ff00ffu) << 8) | ((c >> 8) & 0x00ff00ffu);
+        if (stored != c && stored != swapped) {
+            if (lane == 0) { P.status[4 * s + 0] = ST_CHECKSUM; P.status[4 * s + 1] = 0; P.status[4 * s + 2] = (int)stored; P.status[4 * s + 3] = (int)c; }
+            return;
+        }
+    }
     if (src_len < 0) {
         // the chunk was stored as it is (HDF5 skips an optional filter that does not pay): a plain copy
         const long long n = -src_len;
@@ -571,6 +604,7 @@ const char* status_text(int code) {
         case ST_OUTPUT_FULL: return "stream holds more data than the chunk's size";
         case ST_SIZE: return "stream holds less data than the chunk's size";
         case ST_STALLED: return "decoder made no progress";
+        case ST_CHECKSUM: return "fletcher32 checksum mismatch: the chunk is corrupt";
         default: return "unknown";
     }
 }
@@ -581,9 +615,10 @@ extern "C" int lec_inflate(const lec_inflate_args* a) {
     if (!a) return lec_set_error(LEC_ERR_ARG, "lec_inflate: null args");
     if (!a->src_d || !a->desc_d || !a->dst_d || !a->status_d) return lec_set_error(LEC_ERR_ARG, "lec_inflate: null pointer argument");
     if (a->n_streams < 1 || a->src_bytes < 8) return lec_set_error(LEC_ERR_ARG, "lec_inflate: n_streams >= 1 and src_bytes >= 8 needed");
+    if (a->flags & ~1) return lec_set_error(LEC_ERR_ARG, "lec_inflate: unknown bits in flags");
     if (((uintptr_t)a->src_d & 3u) || ((uintptr_t)a->dst_d & 15u)) return lec_set_error(LEC_ERR_ARG, "lec_inflate: src_d must be 4-byte, dst_d 16-byte aligned");
     InflateParams p;
-    p.src = (const uint8_t*)a->src_d; p.src_bytes = a->src_bytes; p.desc = (const long long*)a->desc_d; p.n = a->n_streams;
+    p.src = (const uint8_t*)a->src_d; p.src_bytes = a->src_bytes; p.desc = (const long long*)a->desc_d; p.n = a->n_streams; p.flags = a->flags;
     p.dst = (uint8_t*)a->dst_d; p.status = a->status_d;
     hipLaunchKernelGGL(lec_inflate_kernel, dim3((unsigned)a->n_streams), dim3(64), 0, (hipStream_t)a->stream, p);
     const hipError_t e = hipGetLastError();

@@ -79,8 +79,8 @@ class H5Variable:
     def chunk_streams(self):
         """What a device-side inflate needs, or None when this variable is not a fully written, deflated, chunked dataset:
         ``{"chunk": chunk shape, "shuffle": bool, "table": {chunk origin (elements) -> (offset in the mapped file, stored bytes,
-        deflate skipped for this chunk)}, "map": the file's memory map}``.  The stored bytes of a chunk are its zlib stream (a
-        fletcher32 checksum at the end is left out; it is not verified on that path)."""
+        deflate skipped for this chunk)}, "fletcher32": bool, "map": the file's memory map}``.  The stored bytes of a chunk are its zlib
+        stream; with ``fletcher32`` four checksum bytes follow them (not counted in "stored bytes"; ``lec_inflate`` verifies them)."""
         lay = self._layout
         ids = [fid for fid, _cd in self._filters]
         if lay.get("class") != "chunked" or 1 not in ids or any(f not in (1, 2, 3) for f in ids):
@@ -99,7 +99,7 @@ class H5Variable:
             if (2 in ids and skip[ids.index(2)]) or (3 in ids and skip[ids.index(3)]):
                 return None
             out[offs] = (addr + self._file.base, size - (4 if 3 in ids else 0), skip[ids.index(1)])
-        return {"chunk": tuple(lay["chunk"]), "shuffle": 2 in ids, "table": out, "map": self._file._m}
+        return {"chunk": tuple(lay["chunk"]), "shuffle": 2 in ids, "fletcher32": 3 in ids, "table": out, "map": self._file._m}
 
 
 class H5File:

@@ -349,10 +349,11 @@ class _ChunkStager:
         origins[:, 0] = np.repeat(np.array(tcs, dtype=np.int64) * ct, m)
         origins[:, 1:] = np.tile(self.space, (len(tcs), 1))
         view = self.view
-        lo, hi = int(addr.min()), int((addr + size).max())
+        tail = 4 if self.info.get("fletcher32") else 0           # the checksum bytes after each stream travel with it
+        lo, hi = int(addr.min()), int((addr + size).max()) + tail
         piece = 8 << 20
         dense = hi - lo <= 1.3 * int(size.sum()) + (1 << 20)
-        need = (hi - lo + 16) if dense else int(((size + 15) & ~15).sum())
+        need = (hi - lo + 16) if dense else int(((size + tail + 15) & ~15).sum())
         if need + 2048 > self.comp_pin[slot].numel():           # a time-chunk larger than the sampled ones: grow this slot's buffers
             grown = int(1.25 * need) + (4 << 20)                # (its last launch has completed: check() above)
             self.comp_pin[slot] = torch.empty(grown, dtype=torch.uint8, pin_memory=True)
@@ -366,10 +367,10 @@ class _ChunkStager:
             used = lead + (hi - lo)
             jobs = [(comp[lead + a: lead + min(a + piece, hi - lo)], view[lo + a: lo + min(a + piece, hi - lo)]) for a in range(0, hi - lo, piece)]
         else:
-            pad = (size + 15) & ~15
+            pad = (size + tail + 15) & ~15
             src_off = np.concatenate([[0], np.cumsum(pad)[:-1]])
             used = int(pad.sum())
-            jobs = [(comp[o: o + z], view[a: a + z]) for o, a, z in zip(src_off.tolist(), addr.tolist(), size.tolist())]
+            jobs = [(comp[o: o + z + tail], view[a: a + z + tail]) for o, a, z in zip(src_off.tolist(), addr.tolist(), size.tolist())]
         meta = self.meta_pin[slot].numpy()
         desc, recs = meta[: 4 * n].reshape(n, 4), meta[4 * n: 9 * n].reshape(n, 5)
         slots16 = np.arange(n, dtype=np.int64) * self.slot16
@@ -404,6 +405,7 @@ class _ChunkStager:
         desc, recs = self.meta_dev[slot][: 4 * n], self.meta_dev[slot][4 * n: 9 * n]
         with torch.cuda.device(self.device):
             ia = _lib.InflateArgs(src_d=self.comp_dev[slot].data_ptr(), src_bytes=used, desc_d=desc.data_ptr(), n_streams=n,
+                                  flags=int(bool(self.info.get("fletcher32"))),
                                   dst_d=self.inflated[slot].data_ptr(), status_d=self.status_dev[slot].data_ptr(), stream=stream)
             _lib.check(lib.lec_inflate(C.byref(ia)), "lec_inflate")
             ct, ck, cj, ci = self.chunk

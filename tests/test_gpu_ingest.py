@@ -162,6 +162,39 @@ def test_corrupt_deflated_chunk_is_reported(workdir, tmp_path):
     assert "reported" in outcomes
 
 
+def test_fletcher32_is_verified_on_the_device_path(workdir, tmp_path):
+    """packed_unlimited_latest.nc carries a Fletcher-32 after every deflated chunk: lec_inflate checks it before it inflates (the
+    clean file passes, so the sum is formed the way the HDF5 library forms it); one flipped bit in the LAST byte of a stream -- inside
+    zlib's own adler32 trailer, which no decoder needs -- is caught by it, on the device as on the host."""
+    from lorenzcycletoolkit_amd.hdf5_lite import Hdf5Error
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    blob = bytearray(open(os.path.join(root, "tests", "golden", "hdf5", "packed_unlimited_latest.nc"), "rb").read())
+    (workdir / "inputs" / "namelist").write_text(ERA5_NAMELIST)
+    (workdir / "inputs" / "box_limits").write_text("min_lon;-60\nmax_lon;30\nmin_lat;-40\nmax_lat;30\n")
+    df = ds.read_namelist("inputs/namelist")
+    args = argparse.Namespace(fixed=True, track=False, trackfile=None)
+    clean = str(tmp_path / "clean.nc")
+    open(clean, "wb").write(blob)
+    raw = ds.open_raw(clean, df)
+    info = raw.variables["u"].data.chunk_streams()
+    assert info["fletcher32"]
+    addr, size, _plain = info["table"][(2, 0, 0, 0)]
+    plan = ingest.make_plan(raw, args)
+    good = ingest.device_cube(raw.variables["u"], plan, inflate="device")
+    assert torch.equal(torch.nan_to_num(good, nan=-1e30), torch.nan_to_num(ingest.device_cube(raw.variables["u"], plan, inflate="host"), nan=-1e30))
+    raw.close()
+    blob[addr + size - 1] ^= 0x04
+    bad = str(tmp_path / "bad.nc")
+    open(bad, "wb").write(blob)
+    raw = ds.open_raw(bad, df)
+    plan = ingest.make_plan(raw, args)
+    with pytest.raises(Hdf5Error, match="fletcher32"):
+        ingest.device_cube(raw.variables["u"], plan, inflate="device")
+    with pytest.raises(Hdf5Error, match="fletcher32"):
+        ingest.device_cube(raw.variables["u"], plan, inflate="host")
+    raw.close()
+
+
 ERA5_NAMES = {"tair": "t", "u": "u", "v": "v", "omega": "w", "geo": "z", "lat": "latitude", "lon": "longitude", "level": "level", "time": "time"}
 ERA5_NAMELIST = (";Variable;Units\nAir Temperature;t;K\nGeopotential;z;m**2/s**2\nOmega Velocity;w;Pa/s\n"
                  "Eastward Wind Component;u;m/s\nNorthward Wind Component;v;m/s\nLongitude;longitude\nLatitude;latitude\n"
