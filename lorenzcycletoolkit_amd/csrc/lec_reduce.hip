@@ -501,7 +501,9 @@ __global__ void __launch_bounds__(64) lec_vertical_kernel(const RedParams p) {
         }
         double r;
         if (k0 > k1) {
-            r = nan("");
+            // no level left: the reference integrates an EMPTY array after dropna -- xarray's integrate gives 0.0 --, while its
+            // bottom-top terms would stop at .isel(level=-1) of nothing (IndexError); here those are NaN
+            r = f >= F_B3 ? nan("") : 0.0;
         } else if (f >= F_B3) {
             r = fn[f][k1] - fn[f][k0];                       // .isel(level=-1) - .isel(level=0)
         } else {

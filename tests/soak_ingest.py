@@ -30,7 +30,7 @@ NAMELIST = (";Variable;Units\nAir Temperature;t;K\nGeopotential;z;m**2/s**2\nOme
 CODES = {"b": np.int8, "h": np.int16, "i": np.int32, "f": np.float32, "d": np.float64}
 
 
-def write_case(rng, path):
+def write_case(rng, path, fill_rate=0.002):
     from scipy.io import netcdf_file
     nt = int(rng.integers(2, 6))
     dlon = float(rng.choice([2.5, 5.0, 1.0]))
@@ -89,7 +89,7 @@ def write_case(rng, path):
             q = ((a - (off if has_offset else 0.0)) / scale).astype(CODES[code])
             fv = CODES[code](rng.choice([9.96921e36, -9999.0, 1e20]))
         if fill_kind != "none":
-            m = rng.random(shape) < 0.002
+            m = rng.random(shape) < fill_rate
             if rng.random() < 0.3:
                 m[int(rng.integers(0, nt)), int(rng.integers(0, nl))] = True        # a whole level of one step
             q[m] = fv

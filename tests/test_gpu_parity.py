@@ -593,6 +593,23 @@ def test_nans_in_T_and_omega_follow_handle_nans(case):
     print(case, max(worst.values()))
 
 
+def test_a_term_with_no_level_left_integrates_to_zero():
+    """T is NaN at one point of levels 1 and 3 of one time step (5 levels): dT*/dp spreads that to every level of Ca's, Gz's and Ge's
+    functions of level, the any-time mask drops them all for the whole series, and the reference then integrates an empty array:
+    0.0 (xarray), not NaN -- found by tests/soak_streamed.py with scattered fill values.  The other terms keep their repaired levels."""
+    dom = synthetic_domain(4, 5, 12, 64, seed=43)
+    dom.tair[1, 1, 4, 20] = np.nan
+    dom.tair[1, 3, 7, 30] = np.nan
+    limits = (dom.lon[1], dom.lon[-2], dom.lat[1], dom.lat[-2])
+    res = run_fixed(dom, limits)
+    with np.errstate(invalid="ignore"):
+        ref_s, ref_l = o.lec_fixed(dom, *limits)
+    compare(res.scalars_dict(), res.levels_dict(), ref_s, ref_l, 1e-9, "no level left", time_s=dom.time_s)
+    got = res.scalars_dict()
+    assert all(np.all(np.asarray(got[k]) == 0.0) for k in ("Ca", "Gz", "Ge")) and all(np.all(np.asarray(ref_s[k]) == 0.0) for k in ("Ca", "Gz", "Ge"))
+    assert all(np.isfinite(got[k]).all() and np.abs(got[k]).min() > 0 for k in ("Az", "Ae", "Kz", "Ke", "Cz", "Ce", "Ck"))
+
+
 def test_polar_rows_off_the_pole():
     """A latitude axis that comes within 1/8 degree of the pole without touching it: [u] / cos(phi), tan(phi) and
     dx ~ cos(phi) are large but finite in the reference, and the engine must follow them."""
