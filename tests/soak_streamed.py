@@ -98,6 +98,67 @@ def one_case(rng, case, tmp):
     return fails
 
 
+def one_track_case(rng, case, tmp):
+    """The moving framework: a random track over a random selection of the file's time steps, boxes of random width / length; the
+    host-prepared resident BoxData, the streamed one (random chunk length) and the oracle's lec_moving on ITS preparation (track-time
+    selection and track-extent crop included)."""
+    path = os.path.join(tmp, f"track{case}.nc")
+    _limits, what = si.write_case(rng, path, fill_rate=0.0)
+    what = f"track case {case}: {what.split(' box ')[0]}"
+    fails = []
+    df = ds.read_namelist("inputs/namelist")
+    try:
+        probe = ds.open_raw(path, df)
+        times, lat, lon = probe.time, np.sort(probe.lat), np.sort(((probe.lon + 180) % 360 - 180) if (probe.lon.min() < -180 or probe.lon.max() > 180) else probe.lon)
+        probe.close()
+        nt = len(times)
+        if nt < 2:
+            os.remove(path)
+            return []
+        keep = np.sort(rng.choice(nt, size=int(rng.integers(2, nt + 1)), replace=False))
+        dlat, dlon = float(np.diff(lat).min()), float(np.diff(lon).min())
+        w = float(rng.choice([3, 4, 6]) * dlon + rng.uniform(0, 0.3))
+        ln = float(rng.choice([3, 4, 5]) * dlat + rng.uniform(0, 0.3))
+        if lon[-1] - lon[0] < w + 2 * dlon or lat[-1] - lat[0] < ln + 2 * dlat or np.diff(lon).max() > 1.5 * dlon:      # (a wrapped axis with a gap)
+            os.remove(path)
+            return []
+        clat = rng.uniform(lat[0] + ln / 2 + dlat, lat[-1] - ln / 2 - dlat, size=keep.size)
+        clon = rng.uniform(lon[0] + w / 2 + dlon, lon[-1] - w / 2 - dlon, size=keep.size)
+        with open(os.path.join(tmp, "inputs", "track"), "w") as fh:
+            fh.write("time;Lat;Lon;width;length\n")
+            for t, la, lo in zip(keep, clat, clon):
+                fh.write("%s;%r;%r;%r;%r\n" % (str(times[t].astype("datetime64[m]")).replace("T", "-").replace(":", ""), float(la), float(lo), w, ln))
+        args = argparse.Namespace(fixed=False, track=True, trackfile="inputs/track", residuals=True, infile=path, cdsapi=False)
+        host = ds.prepare_data(args, "inputs/namelist")
+        track = ds.read_track("inputs/track")
+        limits = [(lo - w / 2, lo + w / 2, la - ln / 2, la + ln / 2) for la, lo in zip(track["Lat"], track["Lon"])]
+        a = BoxData(host, df, args=args, boxes_limits=limits).result
+        chunk = int(rng.integers(1, keep.size + 2))
+        st = ingest.prepare_streamed(args, "inputs/namelist", chunk_steps=chunk)
+        b = BoxData(st, df, args=args, boxes_limits=limits).result
+        st.raw.close()
+        if not (same(a.scalars, b.scalars) and same(a.levels, b.levels)):
+            fails.append(f"{what}: streamed (chunk {chunk}) differs from the resident run, steps {keep.tolist()}")
+        tt = track.index.values.astype("datetime64[ns]")
+        dom = cf.prepare(path, si.NAMES, track=(tt, track["Lat"].values, track["Lon"].values), max_width=w, max_length=ln)
+        try:
+            with np.errstate(all="ignore"):
+                ref_s, _ = o.lec_moving(as_f64(dom), limits)
+        except IndexError:
+            ref_s = {}
+        got = a.scalars_dict()
+        for name in SCALARS:
+            if name in ref_s:
+                e = scale_err(got[name], ref_s[name])
+                if not e <= 1e-9:
+                    fails.append(f"{what}: {name} off the oracle by {e:.3e} (steps {keep.tolist()}, box {w:.2f} x {ln:.2f})")
+    except Exception as e:
+        import traceback
+        fails.append(f"{what}: raised {e!r} at {traceback.format_exc().splitlines()[-3].strip()}")
+    os.remove(path)
+    return fails
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=150)
@@ -115,7 +176,7 @@ def main():
             fh.write(si.NAMELIST)
         os.chdir(tmp)
         for c in range(a.cases):
-            fails += one_case(rng, c, tmp)
+            fails += one_case(rng, c, tmp) if c % 3 else one_track_case(rng, c, tmp)
             if (c + 1) % 25 == 0:
                 print(f"{c + 1} cases, {len(fails)} failures, {time.time() - t0:.0f} s", flush=True)
         os.chdir(ROOT)
