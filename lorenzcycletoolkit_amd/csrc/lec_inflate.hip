@@ -208,6 +208,15 @@ __global__ void __launch_bounds__(64) lec_inflate_kernel(const InflateParams P) 
     const int s = (int)blockIdx.x;
     const long long src_off = P.desc[4 * s + 0], src_len = P.desc[4 * s + 1], dst_off = P.desc[4 * s + 2], dst_len = P.desc[4 * s + 3];
     uint8_t* const out = P.dst + dst_off;
+    {
+        // bit positions and output positions are 32-bit here: a stream of up to 256 MiB, an output of up to 2 GiB (an HDF5 chunk is < 4 GiB
+        // by format, a sensible one a few MiB); and the stream must lie inside the source buffer
+        const long long n = src_len < 0 ? -src_len : src_len;
+        if (n >= (1ll << 28) || dst_len < 0 || dst_len >= (1ll << 31) || src_off < 0 || src_off + n + ((P.flags & 1) ? 4 : 0) > P.src_bytes) {
+            if (lane == 0) { P.status[4 * s + 0] = ST_SIZE; P.status[4 * s + 1] = 0; P.status[4 * s + 2] = 0; P.status[4 * s + 3] = 0; }
+            return;
+        }
+    }
     if (P.flags & 1) {
         // HDF5 filter 3: the stored chunk ends with the Fletcher-32 of everything before it (little-endian; the library also accepts
         // the byte-swapped form that 1.6.2 wrote on little-endian hosts, H5Zfletcher32.c)
@@ -242,7 +251,10 @@ __global__ void __launch_bounds__(64) lec_inflate_kernel(const InflateParams P) 
     const uint8_t* const inb = P.src + (src_off - lead);
     BitIn in;
     in.in32 = (const uint32_t*)inb; in.lane = lane;
-    in.nwords = (uint32_t)((P.src_bytes - (src_off - lead)) >> 2);
+    {
+        const long long words = (P.src_bytes - (src_off - lead)) >> 2;       // readable dwords from the aligned start (a few past the stream are touched)
+        in.nwords = (uint32_t)(words < (1ll << 27) ? words : (1ll << 27));
+    }
     const uint32_t src_end = lead + (uint32_t)src_len;          // in bytes from inb
     const uint32_t src_bits = src_end * 8u;
     const uint32_t out_len = (uint32_t)dst_len;
