@@ -74,30 +74,32 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-// The compressed stream seen through two 64-dword blocks held in registers (lane l: dword blk * 64 + l and the one 64 further):
-// any dword the decoder needs is one v_readlane away, and the next block loads while the current one is consumed.
+// The compressed stream seen through 64-dword blocks held in registers (lane l: dword blk * 64 + l, the one 64 further, and a third
+// block in flight): any dword the decoder needs is a v_readlane away.  The block being loaded is never read -- it becomes readable
+// one block later, when the load has long completed --, so no round waits for memory.
 struct BitIn {
     const uint32_t* in32;
     uint32_t nwords;                // dwords that may be read (the buffer's padding included)
     uint32_t blk;
-    uint32_t a, b;
+    uint32_t a, b, c;               // blocks blk, blk + 1 (readable), blk + 2 (in flight)
     int lane;
     __device__ __forceinline__ uint32_t load(uint32_t block) const {
         const uint32_t i = block * 64u + (uint32_t)lane;
         return i < nwords ? in32[i] : 0u;
     }
-    __device__ __forceinline__ void reset(uint32_t bitpos) { blk = (bitpos >> 5) >> 6; a = load(blk); b = load(blk + 1); }
+    __device__ __forceinline__ void reset(uint32_t bitpos) { blk = (bitpos >> 5) >> 6; a = load(blk); b = load(blk + 1); c = load(blk + 2); }
     // afterwards dwords [bitpos / 32, bitpos / 32 + 64) are held
     __device__ __forceinline__ void seek(uint32_t bitpos) {
-        const uint32_t d = bitpos >> 5;
-        if (d >= blk * 64u + 64u) {
-            if (d < blk * 64u + 128u) { a = b; ++blk; b = load(blk + 1); }
+        const uint32_t rel = (bitpos >> 5) - blk * 64u;        // (wraps when bitpos lies before the held range)
+        if (rel >= 64u) {
+            if (rel < 128u) { a = b; b = c; ++blk; c = load(blk + 2); }
             else reset(bitpos);
-        } else if (d < blk * 64u) reset(bitpos);
+        }
     }
-    __device__ __forceinline__ uint32_t dword(uint32_t d) const {      // d wave-uniform, within the held range
+    __device__ __forceinline__ uint32_t dword(uint32_t d) const {      // d wave-uniform, within the held range: no branch
         const uint32_t rel = d - blk * 64u;
-        return rel < 64u ? rl(a, rel) : rl(b, rel - 64u);
+        const uint32_t x = rl(a, rel & 63u), y = rl(b, rel & 63u);
+        return rel < 64u ? x : y;
     }
     __device__ __forceinline__ uint32_t peek(uint32_t bitpos) const {  // 32 bits at a wave-uniform position
         const uint32_t d = bitpos >> 5, s = bitpos & 31u;
@@ -387,32 +389,29 @@ __global__ void __launch_bounds__(64) lec_inflate_kernel(const InflateParams P) 
                 win = (((uint64_t)x1 << 32) | x0) >> sh;
                 if (sh) win |= (uint64_t)x2 << (64u - sh);
             }
-            // the token that would start here
-            uint32_t type, used, value = 0, dist = 0;        // value: the literal byte, or the match length
+            // the token that would start here -- straight-line code: every lane evaluates the literal AND the match reading (the second
+            // table lookup included: its index is masked, so garbage bits are harmless) and selects; with 64 speculative positions some
+            // lane takes every path anyway, and divergent branches cost scalar instructions on a unit the whole CU shares
+            uint32_t type, used, value, dist;                // value: the literal byte, or the match length
             {
                 const uint32_t e = L.lit[(uint32_t)win & ((1u << kLitBits) - 1u)];
-                used = e & 15u;
-                const uint32_t sym = e >> 4;
-                if (e == 0u) type = T_SLOW;
-                else if (sym < 256u) { type = T_LIT; value = sym; }
-                else if (sym == 256u) type = T_EOB;
-                else if (sym > 285u) type = T_BAD;
-                else {
-                    uint32_t base, extra;
-                    length_of(sym - 257u, base, extra);
-                    value = base + ((uint32_t)(win >> used) & ((1u << extra) - 1u));
-                    used += extra;
-                    const uint32_t de = L.dist[(uint32_t)(win >> used) & ((1u << kDistBits) - 1u)];
-                    if (de == 0u) type = T_SLOW;
-                    else if ((de >> 4) > 29u) type = T_BAD;
-                    else {
-                        used += de & 15u;
-                        distance_of(de >> 4, base, extra);
-                        dist = base + ((uint32_t)(win >> used) & ((1u << extra) - 1u));
-                        used += extra;
-                        type = T_MATCH;
-                    }
-                }
+                const uint32_t l0 = e & 15u, sym = e >> 4;
+                const uint32_t c = sym - 257u;                                   // length code 0..28 if this is one
+                const bool small = c < 8u, top = c >= 28u;
+                const uint32_t lextra = (small || top) ? 0u : (c >> 2) - 1u;
+                const uint32_t lbase = small ? 3u + c : top ? 258u : 3u + ((4u + (c & 3u)) << lextra);
+                const uint32_t length = lbase + ((uint32_t)(win >> l0) & ((1u << lextra) - 1u));
+                const uint32_t l1 = l0 + lextra;
+                const uint32_t de = L.dist[(uint32_t)(win >> l1) & ((1u << kDistBits) - 1u)];
+                const uint32_t dl = de & 15u, dsym = de >> 4;
+                const uint32_t dextra = dsym < 4u ? 0u : ((dsym >> 1) - 1u) & 15u;
+                const uint32_t dbase = dsym < 4u ? 1u + dsym : 1u + ((2u + (dsym & 1u)) << dextra);
+                const uint32_t l2 = l1 + dl;
+                dist = dbase + ((uint32_t)(win >> l2) & ((1u << dextra) - 1u));
+                const bool is_len = sym - 257u <= 28u;
+                type = e == 0u ? T_SLOW : sym < 256u ? T_LIT : sym == 256u ? T_EOB : !is_len ? T_BAD : de == 0u ? T_SLOW : dsym > 29u ? T_BAD : T_MATCH;
+                value = sym < 256u ? sym : length;
+                used = type == T_MATCH ? l2 + dextra : l0;
             }
             // Follow the true chain through the lanes.  One word per lane carries what the walk needs of a token: bits used (6) |
             // type (3) | output bytes (9); a literal -- the common case -- is recognised by one compare and costs one readlane.
