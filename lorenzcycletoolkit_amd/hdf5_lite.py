@@ -602,7 +602,30 @@ class H5File:
         rank = len(var.shape)
         chunk = lay["chunk"]
         nbytes = int(np.prod(chunk)) * var.dtype.itemsize
-        if lay["index"] == "btree1":
+        if lay["index"] == "btree1" and self.O == 8:
+            # a node's entries are fixed-size records (key: stored size, filter mask, rank + 1 offsets; then the child address):
+            # one NumPy view per node instead of a Python loop per chunk (a 4096-step ERA5 variable has ~10^6 chunks)
+            rec = np.dtype([("size", "<u4"), ("mask", "<u4"), ("offs", "<u8", (rank + 1,)), ("child", "<u8")])
+            buf = np.frombuffer(self._m, dtype=np.uint8)
+
+            def walk(addr):
+                a = addr + self.base
+                m = self._m
+                if m[a: a + 4] != b"TREE" or m[a + 4] != 1:
+                    raise Hdf5Error("bad chunk B-tree node")
+                level, n = m[a + 5], self._u(a + 6, 2)
+                if n == 0:
+                    return
+                p = a + 8 + 2 * self.O
+                e = buf[p: p + n * rec.itemsize].view(rec)
+                if level == 0:
+                    table.update(zip(map(tuple, e["offs"][:, :rank].tolist()), zip(e["child"].tolist(), e["size"].tolist(), e["mask"].tolist())))
+                else:
+                    for child in e["child"].tolist():
+                        walk(child)
+            if lay["addr"] != (1 << (8 * self.O)) - 1:
+                walk(lay["addr"])
+        elif lay["index"] == "btree1":
             def walk(addr):
                 a = addr + self.base
                 m = self._m
