@@ -307,8 +307,8 @@ int lec_copy_rows_async(void* dst_d, size_t dst_pitch, const void* src_h, size_t
  *                      not compressed (HDF5 stores a chunk as it is when deflate does not pay) and are copied.  src_bytes is the size of the src_d
  *                      allocation (the kernel reads whole dwords: it may touch up to 512 bytes after a stream's end, never beyond
  *                      src_bytes).  status_d[s] = {code, deflate block, output position, input bit position}; code 0 = ok, anything
- *                      else names what was wrong with the stream (lec_inflate_status_text) -- zlib's adler32 trailer is NOT verified, HDF5's
- *                      Fletcher-32 is when flags says the chunks carry one.
+ *                      else names what was wrong with the stream (lec_inflate_status_text); zlib's Adler-32 trailer is verified against the
+ *                      inflated data, HDF5's Fletcher-32 of the compressed bytes when flags says the chunks carry one.
  *                      Asynchronous like every other entry point: the caller reads status_d after synchronising.
  *   lec_chunk_scatter  the payloads of n_chunks HDF5 chunks (each ct x ck x cj x ci elements of elem_size bytes, all of one
  *                      variable; shuffled = 1: the HDF5 shuffle filter's byte planes, undone here) -> a contiguous array

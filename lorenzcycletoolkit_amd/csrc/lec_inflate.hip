@@ -204,7 +204,7 @@ __device__ uint32_t fletcher32_wave(const uint8_t* p, long long len, int lane) {
 
 enum {
     ST_OK = 0, ST_HEADER = 1, ST_BLOCK_TYPE = 2, ST_STORED = 3, ST_CODE_LENGTHS = 4, ST_OVERSUBSCRIBED = 5, ST_BAD_CODE = 6,
-    ST_DISTANCE = 7, ST_INPUT_END = 8, ST_OUTPUT_FULL = 9, ST_SIZE = 10, ST_STALLED = 11, ST_CHECKSUM = 12
+    ST_DISTANCE = 7, ST_INPUT_END = 8, ST_OUTPUT_FULL = 9, ST_SIZE = 10, ST_STALLED = 11, ST_CHECKSUM = 12, ST_ADLER = 13
 };
 
 __global__ void __launch_bounds__(64) lec_inflate_kernel(const InflateParams P) {
@@ -274,13 +274,33 @@ __global__ void __launch_bounds__(64) lec_inflate_kernel(const InflateParams P) 
     }
 
     // ring -> HBM, whole 16-byte pieces (all of it when `all`)
+    // zlib's own check of the DATA rides on the flush: Adler-32 is s1 = 1 + sum b_i, s2 = N + sum (N - i) b_i (mod 65521, i from 0, N
+    // bytes); every lane keeps its share of both sums for the bytes it flushes -- 16 vector instructions per KiB of output
+    uint32_t ad1 = 0, ad2 = 0;                  // this lane's sums, each < 65521 * 4096
+    auto adler_bytes = [&](uint32_t word, uint32_t pos, uint32_t nbytes) {      // `nbytes` low bytes of `word`, the first at output position pos
+        const uint32_t w0 = (out_len - pos) % 65521u;                            // weight of the first byte
+#pragma unroll
+        for (uint32_t b = 0; b < 4u; ++b) {
+            const uint32_t v = b < nbytes ? (word >> (8u * b)) & 0xffu : 0u;
+            ad1 += v;
+            ad2 += v * ((w0 + 65521u - b) % 65521u);
+        }
+        ad1 %= 65521u; ad2 %= 65521u;
+    };
     auto flush = [&](bool all) {
         const uint32_t end16 = opos & ~15u;
-        for (uint32_t q = flushed + 16u * (uint32_t)lane; q < end16; q += 16u * 64u)
-            *(uint4*)(out + q) = *(const uint4*)&L.ring[q & (kRing - 1)];
+        for (uint32_t q = flushed + 16u * (uint32_t)lane; q < end16; q += 16u * 64u) {
+            const uint4 v = *(const uint4*)&L.ring[q & (kRing - 1)];
+            *(uint4*)(out + q) = v;
+            adler_bytes(v.x, q, 4); adler_bytes(v.y, q + 4, 4); adler_bytes(v.z, q + 8, 4); adler_bytes(v.w, q + 12, 4);
+        }
         if (end16 > flushed) flushed = end16;
         if (all) {
-            for (uint32_t q = flushed + (uint32_t)lane; q < opos; q += 64u) out[q] = L.ring[q & (kRing - 1)];
+            for (uint32_t q = flushed + (uint32_t)lane; q < opos; q += 64u) {
+                const uint8_t v = L.ring[q & (kRing - 1)];
+                out[q] = v;
+                adler_bytes(v, q, 1);
+            }
             flushed = opos;
         }
     };
@@ -551,6 +571,20 @@ __global__ void __launch_bounds__(64) lec_inflate_kernel(const InflateParams P) 
         flush(true);
         if (opos != out_len) status = ST_SIZE;
     }
+    if (status == ST_OK) {
+        // the stream ends with the Adler-32 of the data, big-endian, at the next byte boundary
+        uint32_t s1 = ad1, s2 = ad2;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }      // 64 x 65521 fits
+        s1 = (s1 + 1u) % 65521u;
+        s2 = (s2 + out_len % 65521u) % 65521u;
+        const uint32_t at = (bitpos + 7u) >> 3;
+        if (at + 4u > src_end) status = ST_INPUT_END;
+        else {
+            const uint32_t stored = ((uint32_t)inb[at] << 24) | ((uint32_t)inb[at + 1] << 16) | ((uint32_t)inb[at + 2] << 8) | (uint32_t)inb[at + 3];
+            if (stored != ((s2 << 16) | s1)) status = ST_ADLER;
+        }
+    }
     if (lane == 0) {
         P.status[4 * s + 0] = status; P.status[4 * s + 1] = block; P.status[4 * s + 2] = (int)opos; P.status[4 * s + 3] = (int)bitpos;
     }
@@ -619,6 +653,7 @@ const char* status_text(int code) {
         case ST_SIZE: return "stream holds less data than the chunk's size";
         case ST_STALLED: return "decoder made no progress";
         case ST_CHECKSUM: return "fletcher32 checksum mismatch: the chunk is corrupt";
+        case ST_ADLER: return "adler32 of the inflated data does not match the stream's trailer: the chunk is corrupt";
         default: return "unknown";
     }
 }

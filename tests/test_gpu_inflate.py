@@ -119,13 +119,24 @@ def test_malformed_streams_end_with_a_status():
             z = bytearray(b"\x78\x9c") + bytearray(rng.integers(0, 256, 300, dtype=np.uint8).tobytes())
         bad.append(bytes(z)); sizes.append(20000 if k % 4 != 3 else 19999)              # k % 4 == 3: a good stream, the wrong size
     got, status, out, desc = inflate(bad, sizes)
-    assert (status[:, 0] >= 0).all() and (status[:, 0] <= 12).all()
+    assert (status[:, 0] >= 0).all() and (status[:, 0] <= 13).all()
     assert (status[0::4, 0] != 0).all() and (status[3::4, 0] != 0).all()                # truncated / wrong size: always caught
     for i in range(len(bad)):
         end = desc[i, 2] + ((sizes[i] + 15) & ~15)
         nxt = desc[i + 1, 2] if i + 1 < len(bad) else out.size - 16
         assert (out[end:nxt] == 0xAA).all()
         assert lib.lec_inflate_status_text(int(status[i, 0]))
+    # a flipped DATA bit that leaves the stream's structure intact (a stored block's payload): only zlib's Adler-32 of the inflated
+    # data can see it -- the host's zlib.decompress raises, so must the device; the untouched streams beside it pass
+    data = payload(rng, 5000, 0)
+    stored = bytearray(zlib.compress(data, 0))
+    c = zlib.compressobj(6, zlib.DEFLATED, 15, 8, zlib.Z_FIXED)
+    fixed = c.compress(data) + c.flush()
+    stored[2000] ^= 0x10
+    with pytest.raises(zlib.error):
+        zlib.decompress(bytes(stored))
+    _, st2, _, _ = inflate([bytes(stored), zlib.compress(data, 0), bytes(fixed)], [5000, 5000, 5000])
+    assert st2[0, 0] == 13 and b"adler32" in lib.lec_inflate_status_text(13) and st2[1, 0] == 0 and st2[2, 0] == 0
     # arguments
     st = torch.zeros(4, dtype=torch.int32, device=DEV)
     a = _lib.InflateArgs(src_d=st.data_ptr(), src_bytes=16, desc_d=st.data_ptr(), n_streams=0, dst_d=st.data_ptr(), status_d=st.data_ptr())
