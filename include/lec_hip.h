@@ -322,7 +322,9 @@ typedef struct lec_inflate_args {
     int64_t src_bytes;
     const int64_t* desc_d;      /* [n_streams][4] */
     int32_t n_streams;
-    int32_t flags;              /* bit 0: every stream is followed by 4 bytes of HDF5 Fletcher-32 over its bytes (filter 3): verified first */
+    int32_t flags;              /* bit 0: every stream is followed by 4 bytes of HDF5 Fletcher-32 over its bytes (filter 3): verified first;
+                                   bit 1: a hint -- matches rarely reach more than 3 KB back (byte-shuffled rows of < 3000 elements): a 4 KiB
+                                   instead of an 8 KiB history ring in LDS, 18 instead of 12 streams per CU; any stream still inflates */
     void* dst_d;
     int32_t* status_d;          /* [n_streams][4] */
     void* stream;

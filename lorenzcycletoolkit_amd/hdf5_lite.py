@@ -81,6 +81,11 @@ class H5Variable:
         ``{"chunk": chunk shape, "shuffle": bool, "table": {chunk origin (elements) -> (offset in the mapped file, stored bytes,
         deflate skipped for this chunk)}, "fletcher32": bool, "map": the file's memory map}``.  The stored bytes of a chunk are its zlib
         stream; with ``fletcher32`` four checksum bytes follow them (not counted in "stored bytes"; ``lec_inflate`` verifies them)."""
+        if "streams" not in self._cache:
+            self._cache["streams"] = self._chunk_streams()
+        return self._cache["streams"]
+
+    def _chunk_streams(self):
         lay = self._layout
         ids = [fid for fid, _cd in self._filters]
         if lay.get("class") != "chunked" or 1 not in ids or any(f not in (1, 2, 3) for f in ids):

@@ -312,6 +312,8 @@ class _ChunkStager:
         self.staged = [None] * slots
         self.fetched = [torch.cuda.Event() for _ in range(slots)]
         self.compressed_bytes = 0
+        # shuffled data repeat from one longitude row to the next, ci bytes apart within a byte plane: close enough for the short LDS ring
+        self.short_window = bool(info["shuffle"]) and ci <= 3000
         self.view = np.frombuffer(info["map"], dtype=np.uint8)
         # its own stream: a launch lasts as long as ONE chunk takes one wave (tens of ms for a 0.5 MB chunk) however few chunks it
         # holds, so the five variables of a step must inflate side by side, not one after the other on the copy stream
@@ -405,7 +407,7 @@ class _ChunkStager:
         desc, recs = self.meta_dev[slot][: 4 * n], self.meta_dev[slot][4 * n: 9 * n]
         with torch.cuda.device(self.device):
             ia = _lib.InflateArgs(src_d=self.comp_dev[slot].data_ptr(), src_bytes=used, desc_d=desc.data_ptr(), n_streams=n,
-                                  flags=int(bool(self.info.get("fletcher32"))),
+                                  flags=int(bool(self.info.get("fletcher32"))) | (2 if self.short_window else 0),
                                   dst_d=self.inflated[slot].data_ptr(), status_d=self.status_dev[slot].data_ptr(), stream=stream)
             _lib.check(lib.lec_inflate(C.byref(ia)), "lec_inflate")
             ct, ck, cj, ci = self.chunk
@@ -508,12 +510,13 @@ def device_cube(var: ds.RawVariable, plan: IngestPlan, device="cuda:0", unit: fl
 
 def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_limits, *, per_step_boxes: bool = False,
                  device="cuda:0", chunk_steps: int = 8, with_q: bool = True, stats: Optional[dict] = None,
-                 t_range=None, merge_dropmask=None, out=None, staging: str = "auto", inflate: str = "auto") -> LECResult:
+                 t_range=None, merge_dropmask=None, out=None, staging: str = "auto", inflate: str = "auto",
+                 slots: Optional[int] = None) -> LECResult:
     """All LEC terms for the whole series, streamed from the memory-mapped file.
 
     ``boxes_limits``: one (west, east, south, north) in degrees (fixed framework, as inputs/box_limits) or one per time step
     (``per_step_boxes``: the moving framework; dT/dt is differentiated over the plan's time axis on the device).
-    ``chunk_steps`` time steps are resident per pipeline slot (two slots).  ``stats`` receives counters: bytes moved, chunks, dtype.
+    ``chunk_steps`` time steps are resident per pipeline slot (``slots``: default two, three with the device inflate).  ``stats`` receives counters: bytes moved, chunks, dtype.
     ``staging``: "registered" -- the mapped file's own pages are registered with the HIP runtime chunk by chunk and copied from
     directly (no host copy, no staging threads: with eight ranks streaming at once the host's memory carries a third of the traffic);
     "staged" -- a thread pool copies page cache -> pinned buffers first; "auto" (default): registered where every variable is plain
@@ -544,7 +547,13 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
     rvars = {r: raw.variables[raw.names[r]] for r in roles}
     decode, common = storage_dtypes(rvars)
     out_dtype = torch.float64 if common == np.float64 else torch.float32
-    slots = 2
+    on_gpu = inflate != "host" and any(getattr(v.data, "chunk_streams", lambda: None)() is not None for v in rvars.values())
+    if slots is None:
+        # pipeline slots: two keep a copy-bound pipeline full; a launch of the device inflate lasts as long as its slowest chunk
+        # (tens of ms), so a third slot lets the tail of one batch overlap the next two
+        slots = 3 if on_gpu else 2
+    if slots < 2:
+        raise ValueError("slots must be >= 2")
     span = chunk_steps + 2                                                # own steps + the one-step halo of T either side
     # staged sub-cube of every file time step: the kept levels (already in output order) x the latitude band of the domain
     j0, j1 = int(plan.jmap.min()), int(plan.jmap.max())

@@ -44,7 +44,7 @@ def deflate(rng, data):
     return c.compress(data) + c.flush()
 
 
-def inflate(streams, sizes, *, packed=False, plain=()):
+def inflate(streams, sizes, *, packed=False, plain=(), flags=0):
     """Runs lec_inflate; ``packed``: streams back to back at arbitrary byte offsets; ``plain``: indices passed as stored-as-is."""
     lib = _lib.load()
     n = len(streams)
@@ -60,7 +60,7 @@ def inflate(streams, sizes, *, packed=False, plain=()):
     src_d, desc_d = torch.from_numpy(src).to(DEV), torch.from_numpy(desc).to(DEV)
     dst_d = torch.full((do + 16,), 0xAA, dtype=torch.uint8, device=DEV)
     status_d = torch.full((n, 4), -1, dtype=torch.int32, device=DEV)
-    a = _lib.InflateArgs(src_d=src_d.data_ptr(), src_bytes=src.size, desc_d=desc_d.data_ptr(), n_streams=n, dst_d=dst_d.data_ptr(),
+    a = _lib.InflateArgs(src_d=src_d.data_ptr(), src_bytes=src.size, desc_d=desc_d.data_ptr(), n_streams=n, flags=flags, dst_d=dst_d.data_ptr(),
                          status_d=status_d.data_ptr(), stream=C.c_void_p(torch.cuda.current_stream().cuda_stream))
     _lib.check(lib.lec_inflate(C.byref(a)), "lec_inflate")
     torch.cuda.synchronize()
@@ -68,11 +68,12 @@ def inflate(streams, sizes, *, packed=False, plain=()):
     return [out[desc[i, 2]: desc[i, 2] + sizes[i]].tobytes() for i in range(n)], status, out, desc
 
 
+@pytest.mark.parametrize("short_ring", [False, True])
 @pytest.mark.parametrize("packed", [False, True])
-def test_random_streams_inflate_to_what_zlib_returns(packed):
+def test_random_streams_inflate_to_what_zlib_returns(packed, short_ring):
     """150 streams in one launch: every deflate level and strategy (stored, fixed and dynamic blocks, Huffman-only, RLE), window
-    memory levels, six kinds of data, 0 bytes to 300 KB; 16-byte-aligned and back-to-back (any byte offset) layouts.  Nothing is
-    written outside a stream's own output."""
+    memory levels, six kinds of data, 0 bytes to 300 KB; 16-byte-aligned and back-to-back (any byte offset) layouts; the 8 KiB and the
+    4 KiB history ring (flags bit 1: a hint only -- far matches are then served from HBM).  Nothing is written outside a stream's own output."""
     rng = np.random.default_rng(20 + packed)
     data = []
     for c in range(150):
@@ -80,7 +81,7 @@ def test_random_streams_inflate_to_what_zlib_returns(packed):
         data.append(payload(rng, n, c % 6))
     streams = [deflate(rng, d) for d in data]
     assert all(zlib.decompress(s) == d for s, d in zip(streams, data))
-    got, status, out, desc = inflate(streams, [len(d) for d in data], packed=packed)
+    got, status, out, desc = inflate(streams, [len(d) for d in data], packed=packed, flags=2 if short_ring else 0)
     assert (status[:, 0] == 0).all(), [(i, status[i].tolist()) for i in np.flatnonzero(status[:, 0])][:5]
     for i, d in enumerate(data):
         assert got[i] == d, (i, len(d))
@@ -96,9 +97,10 @@ def test_long_streams_window_sized_matches_and_plain_chunks():
     period = rng.integers(0, 256, 30000, dtype=np.uint8).tobytes()
     data = [payload(rng, 3_000_000, 1), (period * 40)[:1_000_000], bytes(2_000_000), payload(rng, 1_000_001, 5), payload(rng, 70001, 0)]
     streams = [zlib.compress(data[0], 6), zlib.compress(data[1], 9), zlib.compress(data[2], 1), zlib.compress(data[3], 4), data[4]]
-    got, status, _, _ = inflate(streams, [len(d) for d in data], plain={4})
-    assert (status[:, 0] == 0).all(), status.tolist()
-    assert all(g == d for g, d in zip(got, data))
+    for flags in (0, 2):
+        got, status, _, _ = inflate(streams, [len(d) for d in data], plain={4}, flags=flags)
+        assert (status[:, 0] == 0).all(), status.tolist()
+        assert all(g == d for g, d in zip(got, data))
     assert status[0, 1] > 50                                                           # many blocks were walked
 
 

@@ -23,6 +23,7 @@ def main():
                     "i16z: int16 in shuffled + deflated HDF5-style chunks (what a NetCDF-4 ERA5 file holds)")
     ap.add_argument("--inflate", choices=["auto", "host", "device"], default="auto", help="i16z: where the chunks are inflated")
     ap.add_argument("--deflate-level", type=int, default=4)
+    ap.add_argument("--slots", type=int, default=None, help="pipeline slots (default: 2, or 3 with the device inflate)")
     ap.add_argument("--chunk-shape", default="1,1,361,720", help="i16z: HDF5 chunk shape (time, level, lat, lon)")
     ap.add_argument("--timesteps", type=int, default=16)
     ap.add_argument("--chunk", type=int, default=4)
@@ -95,7 +96,7 @@ def main():
     for r in range(args.repeat + 1):                               # first pass = warm-up (pinned allocations, page faults)
         torch.cuda.synchronize()
         t0 = time_now()
-        res = ingest.lec_fixed_streamed(raw, plan, df, limits, chunk_steps=args.chunk, stats=stats, staging=args.staging, inflate=args.inflate)
+        res = ingest.lec_fixed_streamed(raw, plan, df, limits, chunk_steps=args.chunk, stats=stats, staging=args.staging, inflate=args.inflate, slots=args.slots)
         torch.cuda.synchronize()
         dt = time_now() - t0
         if r > 0:

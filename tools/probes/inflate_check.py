@@ -51,7 +51,10 @@ def compress(rng, data):
     return out + c.flush(), (level, strategy, mem)
 
 
-def run(lib, streams, sizes, dev):
+FLAGS = 0
+
+
+def run(lib, streams, sizes, dev, flags=None):
     n = len(streams)
     desc = np.zeros((n, 4), dtype=np.int64)
     so = do = 0
@@ -66,7 +69,7 @@ def run(lib, streams, sizes, dev):
     desc_d = torch.from_numpy(desc).to(dev)
     dst_d = torch.full((do + 16,), 0xAA, dtype=torch.uint8, device=dev)
     status_d = torch.full((n, 4), -1, dtype=torch.int32, device=dev)
-    a = _lib.InflateArgs(src_d=src_d.data_ptr(), src_bytes=src.size, desc_d=desc_d.data_ptr(), n_streams=n, dst_d=dst_d.data_ptr(),
+    a = _lib.InflateArgs(src_d=src_d.data_ptr(), src_bytes=src.size, desc_d=desc_d.data_ptr(), n_streams=n, flags=FLAGS if flags is None else flags, dst_d=dst_d.data_ptr(),
                          status_d=status_d.data_ptr(), stream=C.c_void_p(torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -102,11 +105,14 @@ def bench(lib, dev, n_streams, level, noise):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--bench", action="store_true")
+    ap.add_argument("--flags", type=int, default=0, help="lec_inflate flags (2: the 4 KiB ring)")
     ap.add_argument("--bench-one", nargs=3, metavar=("STREAMS", "LEVEL", "NOISE"), help="one configuration (for profiling)")
     ap.add_argument("--cases", type=int, default=300)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-bytes", type=int, default=1 << 20)
     a = ap.parse_args()
+    global FLAGS
+    FLAGS = a.flags
     rng = np.random.default_rng(a.seed)
     lib = _lib.load()
     dev = "cuda:0"
