@@ -44,7 +44,7 @@ class StreamedDataset:
     the coordinates of the analysis domain now, the field data streamed from the file when the terms are computed."""
     raw: ds.RawDataset
     plan: IngestPlan
-    chunk_steps: int = 8
+    chunk_steps: Optional[int] = None      # None: lec_streamed's choice (8; 12 when the chunks are inflated on the device)
 
     def level_slice(self, role: str, level_pa: float, t_range=None) -> np.ndarray:
         """[time, lat, lon] of one role at one level, decoded on the host from the mapped file (the 850-hPa track diagnostics
@@ -62,7 +62,7 @@ class StreamedDataset:
     names = property(lambda self: self.raw.names)
 
 
-def prepare_streamed(args, varlist: str = "inputs/namelist", app_logger=None, chunk_steps: int = 8) -> StreamedDataset:
+def prepare_streamed(args, varlist: str = "inputs/namelist", app_logger=None, chunk_steps: Optional[int] = None) -> StreamedDataset:
     """prepare_data (preprocessing.py:374-413) for the device ingest: validates the file against the namelist and builds
     the index maps; no field data is read here."""
     if getattr(args, "cdsapi", False):
@@ -509,7 +509,7 @@ def device_cube(var: ds.RawVariable, plan: IngestPlan, device="cuda:0", unit: fl
 
 
 def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_limits, *, per_step_boxes: bool = False,
-                 device="cuda:0", chunk_steps: int = 8, with_q: bool = True, stats: Optional[dict] = None,
+                 device="cuda:0", chunk_steps: Optional[int] = None, with_q: bool = True, stats: Optional[dict] = None,
                  t_range=None, merge_dropmask=None, out=None, staging: str = "auto", inflate: str = "auto",
                  slots: Optional[int] = None) -> LECResult:
     """All LEC terms for the whole series, streamed from the memory-mapped file.
@@ -540,7 +540,6 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
     t0, t1 = (0, nt) if t_range is None else (int(t_range[0]), int(t_range[1]))
     if not (0 <= t0 < t1 <= nt):
         raise ValueError("t_range outside the series")
-    chunk_steps = max(1, min(int(chunk_steps), t1 - t0))
     geo_role = raw.geo_role
     roles = list(_ROLE_KEYS) + [geo_role]
     keys = {**_ROLE_KEYS, geo_role: "geopt"}
@@ -554,6 +553,9 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
         slots = 3 if on_gpu else 2
     if slots < 2:
         raise ValueError("slots must be >= 2")
+    if chunk_steps is None:          # the more chunks a launch of the device inflate holds, the better its tail is hidden
+        chunk_steps = 12 if on_gpu else 8
+    chunk_steps = max(1, min(int(chunk_steps), t1 - t0))
     span = chunk_steps + 2                                                # own steps + the one-step halo of T either side
     # staged sub-cube of every file time step: the kept levels (already in output order) x the latitude band of the domain
     j0, j1 = int(plan.jmap.min()), int(plan.jmap.max())
