@@ -284,25 +284,27 @@ class _ChunkStager:
         self.space = np.array([(k * ck, j * cj, i * ci) for k in kk for j in jj for i in ii], dtype=np.int64)
         self._tc = {}                                          # time-chunk -> (file offsets, stored sizes, stored-as-is flags) of its chunks
         n_all = -(-shape[0] // ct)
-        n_tc = min(n_all, steps)                               # every staged step lies in one time-chunk
+        n_tc = min(n_all, steps // ct + 2)                     # time-chunks that `steps` consecutive steps touch (stage() grows the buffers for more)
         # staging capacity: the `steps` largest time-chunks (sampled when the series is long), with room for the gaps of a
         # span copy (see stage) and the padding of the last stream
         sample = range(n_all) if n_all <= 64 else sorted(set(np.linspace(0, n_all - 1, 64).astype(int).tolist()))
         per_tc = sorted((int(((self._time_chunk(tc)[1] + 15) & ~15).sum()) for tc in sample), reverse=True)
         worst = int(1.35 * sum(per_tc[:n_tc]) * (1.0 if n_all <= 64 else 1.15)) + (4 << 20)
-        self.max_chunks = n_tc * len(self.space)
+        # buffers are sized for consecutive steps (steps / ct + 2 time-chunks); a track that picks scattered steps out of chunks that
+        # span several steps needs more -- stage() grows the slot then
+        self.max_chunks = [min(n_all, steps // ct + 2) * len(self.space)] * slots
         dev = torch.device(device)
         self.device = dev
         carrier = {1: torch.int8, 2: torch.int16, 4: torch.int32, 8: torch.int64}[self.itemsize]
         self.raw_dev = [torch.empty((steps, self.step_elems), dtype=carrier, device=dev) for _ in range(slots)]
         self.comp_pin = [torch.empty(worst, dtype=torch.uint8, pin_memory=True) for _ in range(slots)]
         self.comp_dev = [torch.empty(worst, dtype=torch.uint8, device=dev) for _ in range(slots)]
-        self.inflated = [torch.empty(self.max_chunks * self.slot16 + 16, dtype=torch.uint8, device=dev) for _ in range(slots)]
+        self.inflated = [torch.empty(self.max_chunks[0] * self.slot16 + 16, dtype=torch.uint8, device=dev) for _ in range(slots)]
         # per chunk: the lec_inflate descriptor (4 int64) and the lec_chunk_scatter record (5 int64), one upload
-        self.meta_pin = [torch.zeros(self.max_chunks * 9, dtype=torch.int64, pin_memory=True) for _ in range(slots)]
-        self.meta_dev = [torch.zeros(self.max_chunks * 9, dtype=torch.int64, device=dev) for _ in range(slots)]
-        self.status_dev = [torch.zeros((self.max_chunks, 4), dtype=torch.int32, device=dev) for _ in range(slots)]
-        self.status_pin = [torch.zeros((self.max_chunks, 4), dtype=torch.int32, pin_memory=True) for _ in range(slots)]
+        self.meta_pin = [torch.zeros(self.max_chunks[0] * 9, dtype=torch.int64, pin_memory=True) for _ in range(slots)]
+        self.meta_dev = [torch.zeros(self.max_chunks[0] * 9, dtype=torch.int64, device=dev) for _ in range(slots)]
+        self.status_dev = [torch.zeros((self.max_chunks[0], 4), dtype=torch.int32, device=dev) for _ in range(slots)]
+        self.status_pin = [torch.zeros((self.max_chunks[0], 4), dtype=torch.int32, pin_memory=True) for _ in range(slots)]
         self.tmap_pin = [torch.zeros(steps * max(ct, 1) + 2 * ct + 8, dtype=torch.int32, pin_memory=True) for _ in range(slots)]
         self.tmap_dev = [torch.zeros_like(t, device=dev) for t in self.tmap_pin]
         kmap = np.full(shape[1], -1, dtype=np.int32)
@@ -345,8 +347,14 @@ class _ChunkStager:
         addr, size, plain = (np.concatenate([p[i] for p in parts]) for i in range(3))
         m = len(self.space)
         n = m * len(tcs)
-        if n > self.max_chunks:
-            raise RuntimeError("more chunks than the staging buffers were sized for")
+        if n > self.max_chunks[slot]:              # (the slot's last launch has completed: check() above)
+            dev = self.device
+            self.max_chunks[slot] = n
+            self.inflated[slot] = torch.empty(n * self.slot16 + 16, dtype=torch.uint8, device=dev)
+            self.meta_pin[slot] = torch.zeros(n * 9, dtype=torch.int64, pin_memory=True)
+            self.meta_dev[slot] = torch.zeros(n * 9, dtype=torch.int64, device=dev)
+            self.status_dev[slot] = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+            self.status_pin[slot] = torch.zeros((n, 4), dtype=torch.int32, pin_memory=True)
         origins = np.empty((n, 4), dtype=np.int64)
         origins[:, 0] = np.repeat(np.array(tcs, dtype=np.int64) * ct, m)
         origins[:, 1:] = np.tile(self.space, (len(tcs), 1))
