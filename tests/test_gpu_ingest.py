@@ -334,3 +334,44 @@ def test_random_file_layouts_device_decode_equals_the_oracle(workdir):
     for case in range(60):
         fails += soak.one_case(rng, case, str(workdir), gpu=True)
     assert not fails, fails[:3]
+
+
+def test_chunk_stager_grows_for_scattered_steps_of_time_spanning_chunks():
+    """Chunks of 3 time steps x 2 levels x 4 x 5 points; a plan that takes every third step needs one time-chunk PER step -- more than the
+    stager sized its buffers for (consecutive steps) -- and a band of levels and latitudes: the slot's buffers grow, the rows are right."""
+    import zlib
+    rng = np.random.default_rng(5)
+    shape, chunk = (14, 5, 9, 10), (3, 2, 4, 5)
+    a = rng.integers(-30000, 30000, shape).astype("<i2")
+    table, blobs, at = {}, [], 64                               # (a file does not start with a chunk)
+    for t in range(0, 14, 3):
+        for k in range(0, 5, 2):
+            for j in range(0, 9, 4):
+                for i in range(0, 10, 5):
+                    blk = np.zeros(chunk, dtype="<i2")
+                    part = a[t: t + 3, k: k + 2, j: j + 4, i: i + 5]
+                    blk[: part.shape[0], : part.shape[1], : part.shape[2], : part.shape[3]] = part
+                    z = zlib.compress(blk.reshape(-1).view(np.uint8).reshape(-1, 2).T.tobytes(), 5)
+                    table[(t, k, j, i)] = (at, len(z), False)
+                    blobs.append(z)
+                    at += len(z)
+    blob = np.frombuffer(b"\0" * 64 + b"".join(blobs), dtype=np.uint8)
+
+    class Var:
+        pass
+    v = Var()
+    v.shape, v.dtype = shape, np.dtype("<i2")
+    info = {"chunk": chunk, "shuffle": True, "table": table, "map": blob}
+    var = ds.RawVariable(v, None, None, None)
+    levels, j0, j1 = np.array([1, 2, 4]), 2, 7
+    st = ingest._ChunkStager(var, info, 5, "cuda:0", levels, j0, j1, slots=2)
+    sized = st.max_chunks[0]
+    steps = np.array([0, 3, 6, 9, 12])                          # five steps, five time-chunks (5 // 3 + 2 = 3 were planned)
+    for slot, use in ((0, steps), (1, steps[:2]), (0, steps[::-1].copy())):
+        st.stage(slot, use, 0)
+        with torch.cuda.stream(st.streams[slot]):
+            st.upload(slot, 0, len(use))
+        st.check(slot)
+        got = st.raw_dev[slot][: len(use)].cpu().numpy().reshape(len(use), 3, j1 - j0 + 1, 10)
+        assert np.array_equal(got, a[use][:, levels][:, :, j0: j1 + 1]), slot
+    assert st.max_chunks[0] > sized and st.max_chunks[1] == sized
