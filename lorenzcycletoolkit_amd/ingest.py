@@ -360,27 +360,32 @@ class _ChunkStager:
         origins[:, 1:] = np.tile(self.space, (len(tcs), 1))
         view = self.view
         tail = 4 if self.info.get("fletcher32") else 0           # the checksum bytes after each stream travel with it
-        lo, hi = int(addr.min()), int((addr + size).max()) + tail
-        piece = 8 << 20
-        dense = hi - lo <= 1.3 * int(size.sum()) + (1 << 20)
-        need = (hi - lo + 16) if dense else int(((size + tail + 15) & ~15).sum())
-        if need + 2048 > self.comp_pin[slot].numel():           # a time-chunk larger than the sampled ones: grow this slot's buffers
+        # Copy plan: RUNS of chunks that lie (almost) back to back in the file -- a whole variable written in one go is one run per call, a
+        # file written step by step (the variables interleaved) one run per step -- each run one span, gaps of up to 64 KiB included, in
+        # 8 MiB pieces (per-chunk jobs of a few 100 KB leave the thread pool waiting for the GIL: 11 GB/s instead of > 50).  Streams keep
+        # their file alignment modulo 16 inside a run; lec_inflate takes them at any byte offset.
+        order = np.argsort(addr, kind="stable")
+        a_s, e_s = addr[order], (addr + size + tail)[order]
+        reach = np.maximum.accumulate(e_s)                        # (repeated or overlapping chunks: a run's end is the furthest byte so far)
+        starts = np.flatnonzero(np.concatenate([[True], a_s[1:] > reach[:-1] + (64 << 10)]))
+        run_lo = a_s[starts]
+        run_hi = np.concatenate([reach[starts[1:] - 1], reach[-1:]])
+        run_len = run_hi - run_lo
+        lead = run_lo & 15
+        base = np.concatenate([[0], np.cumsum((lead + run_len + 15) & ~15)[:-1]]) + lead      # where each run's first byte lands
+        need = int(((lead + run_len + 15) & ~15).sum())
+        if need + 2048 > self.comp_pin[slot].numel():           # larger than the sampled time-chunks (or many gaps): grow this slot's buffers
             grown = int(1.25 * need) + (4 << 20)                # (its last launch has completed: check() above)
             self.comp_pin[slot] = torch.empty(grown, dtype=torch.uint8, pin_memory=True)
             self.comp_dev[slot] = torch.empty(grown, dtype=torch.uint8, device=self.device)
         comp = self.comp_pin[slot].numpy()
-        if dense:
-            # the chunks lie (almost) back to back in the file, as a writer that fills a variable step by step leaves them: ONE span
-            # copy in 8 MiB pieces (per-chunk jobs of a few 100 KB leave the thread pool waiting for the GIL: 11 GB/s instead of > 50)
-            lead = lo & 15
-            src_off = lead + (addr - lo)
-            used = lead + (hi - lo)
-            jobs = [(comp[lead + a: lead + min(a + piece, hi - lo)], view[lo + a: lo + min(a + piece, hi - lo)]) for a in range(0, hi - lo, piece)]
-        else:
-            pad = (size + tail + 15) & ~15
-            src_off = np.concatenate([[0], np.cumsum(pad)[:-1]])
-            used = int(pad.sum())
-            jobs = [(comp[o: o + z + tail], view[a: a + z + tail]) for o, a, z in zip(src_off.tolist(), addr.tolist(), size.tolist())]
+        run_of = np.searchsorted(starts, np.arange(n), side="right") - 1           # run of the i-th chunk in address order
+        src_off = np.empty(n, dtype=np.int64)
+        src_off[order] = base[run_of] + (a_s - run_lo[run_of])
+        used = need
+        piece = 8 << 20
+        jobs = [(comp[d + a: d + min(a + piece, ln)], view[lo + a: lo + min(a + piece, ln)])
+                for lo, ln, d in zip(run_lo.tolist(), run_len.tolist(), base.tolist()) for a in range(0, ln, piece)]
         meta = self.meta_pin[slot].numpy()
         desc, recs = meta[: 4 * n].reshape(n, 4), meta[4 * n: 9 * n].reshape(n, 5)
         slots16 = np.arange(n, dtype=np.int64) * self.slot16

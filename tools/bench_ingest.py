@@ -23,6 +23,8 @@ def main():
                     "i16z: int16 in shuffled + deflated HDF5-style chunks (what a NetCDF-4 ERA5 file holds)")
     ap.add_argument("--inflate", choices=["auto", "host", "device"], default="auto", help="i16z: where the chunks are inflated")
     ap.add_argument("--deflate-level", type=int, default=4)
+    ap.add_argument("--cycle", type=int, default=0, help="i16z: build only this many distinct time steps and repeat them (long series without "
+                    "the host memory for them); 0 = all distinct")
     ap.add_argument("--slots", type=int, default=None, help="pipeline slots (default: 2, or 3 with the device inflate)")
     ap.add_argument("--chunk-shape", default="1,1,361,720", help="i16z: HDF5 chunk shape (time, level, lat, lon)")
     ap.add_argument("--timesteps", type=int, default=16)
@@ -44,6 +46,7 @@ def main():
     lat = np.linspace(-90.0, 90.0, args.ny)
     lon = np.linspace(-180.0, 180.0 - 360.0 / args.nx, args.nx)
     T = args.timesteps
+    T_build = min(T, args.cycle) if (args.cycle and args.src == "i16z") else T
     # the "file": ERA5 axis conventions (lat N -> S, lon 0..360, levels in hPa from the top down), big-endian
     file_lat, file_lon = lat[::-1].copy(), np.where(lon < 0, lon + 360.0, lon)
     lon_order = np.argsort(file_lon, kind="stable")
@@ -55,8 +58,8 @@ def main():
     variables = {}
     keys = {"t": "tair", "u": "u", "v": "v", "w": "omega", "z": "geopt"}
     lon_idx = torch.as_tensor(lon_order, device=dev)
-    for t0 in range(0, T, 4):
-        n = min(4, T - t0)
+    for t0 in range(0, T_build, 4):
+        n = min(4, T_build - t0)
         f = synthetic_cube(n, level, lat, lon, device=dev, dtype=torch.float64, seed=1234, t0_global=t0)
         for name, key in keys.items():
             a = f[key].flip(2).index_select(3, lon_idx)          # file order of lat / lon
@@ -77,7 +80,7 @@ def main():
     for name, v in variables.items():
         a = np.concatenate(v["parts"], axis=0)
         if args.src == "i16z":
-            dv = DeflatedVar(a, tuple(int(x) for x in args.chunk_shape.split(",")), args.deflate_level)
+            dv = DeflatedVar(a, tuple(int(x) for x in args.chunk_shape.split(",")), args.deflate_level, repeat_to=T)
             ratio = dv.ratio
             raw_vars[name] = ds.RawVariable(dv, v["scale"], v["offset"], -32767.0)
             continue
@@ -115,7 +118,7 @@ class DeflatedVar:
     """An int16 variable as a NetCDF-4 file holds it -- little-endian, HDF5 chunks, shuffle + deflate -- kept in host memory: the face
     hdf5_lite.H5Variable shows the ingest (shape, dtype, ``var[t]`` inflating on the host's thread pool, ``chunk_streams()``)."""
 
-    def __init__(self, a, chunk, level):
+    def __init__(self, a, chunk, level, repeat_to=None):
         import zlib
         from concurrent.futures import ThreadPoolExecutor
         self.shape, self.dtype, self.chunk = a.shape, np.dtype("<i2"), chunk
@@ -137,6 +140,13 @@ class DeflatedVar:
             at += len(z)
         self.blob = np.frombuffer(b"".join(streams), dtype=np.uint8)
         self.ratio = a.nbytes / self.blob.size
+        if repeat_to and repeat_to > a.shape[0]:              # a long series that repeats the built steps (chunks of one time step only)
+            assert ct == 1
+            n = a.shape[0]
+            for t in range(n, repeat_to):
+                for (t0, k, j, i), loc in [(o, self.table[o]) for o in origins if o[0] == t % n]:
+                    self.table[(t, k, j, i)] = loc
+            self.shape = (repeat_to,) + a.shape[1:]
 
     def chunk_streams(self):
         return {"chunk": self.chunk, "shuffle": True, "table": self.table, "map": self.blob}
