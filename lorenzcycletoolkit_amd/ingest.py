@@ -397,8 +397,11 @@ class _ChunkStager:
             list(_pool().map(lambda j: np.copyto(*j), jobs))
         at_byte = used
         t_base = tcs[0] * ct
-        tmap = self.tmap_pin[slot].numpy()
         n_tmap = (tcs[-1] + 1) * ct - t_base
+        if n_tmap > self.tmap_pin[slot].numel():                 # a track that takes every n-th file step spans many more file steps than it stages
+            self.tmap_pin[slot] = torch.zeros(n_tmap + 64, dtype=torch.int32, pin_memory=True)
+            self.tmap_dev[slot] = torch.zeros(n_tmap + 64, dtype=torch.int32, device=self.device)
+        tmap = self.tmap_pin[slot].numpy()
         tmap[:n_tmap] = -1
         for r, t in enumerate(steps):
             tmap[t - t_base] = at + r

@@ -341,10 +341,10 @@ def test_chunk_stager_grows_for_scattered_steps_of_time_spanning_chunks():
     stager sized its buffers for (consecutive steps) -- and a band of levels and latitudes: the slot's buffers grow, the rows are right."""
     import zlib
     rng = np.random.default_rng(5)
-    shape, chunk = (14, 5, 9, 10), (3, 2, 4, 5)
+    shape, chunk = (40, 5, 9, 10), (3, 2, 4, 5)
     a = rng.integers(-30000, 30000, shape).astype("<i2")
     table, blobs, at = {}, [], 64                               # (a file does not start with a chunk)
-    for t in range(0, 14, 3):
+    for t in range(0, 40, 3):
         for k in range(0, 5, 2):
             for j in range(0, 9, 4):
                 for i in range(0, 10, 5):
@@ -367,11 +367,11 @@ def test_chunk_stager_grows_for_scattered_steps_of_time_spanning_chunks():
     st = ingest._ChunkStager(var, info, 5, "cuda:0", levels, j0, j1, slots=2)
     sized = st.max_chunks[0]
     steps = np.array([0, 3, 6, 9, 12])                          # five steps, five time-chunks (5 // 3 + 2 = 3 were planned)
-    for slot, use in ((0, steps), (1, steps[:2]), (0, steps[::-1].copy())):
+    for slot, use in ((0, steps), (1, steps[:2]), (0, steps[::-1].copy()), (1, np.array([39, 0, 20]))):      # (the last: the whole file's span for three steps)
         st.stage(slot, use, 0)
         with torch.cuda.stream(st.streams[slot]):
             st.upload(slot, 0, len(use))
         st.check(slot)
         got = st.raw_dev[slot][: len(use)].cpu().numpy().reshape(len(use), 3, j1 - j0 + 1, 10)
         assert np.array_equal(got, a[use][:, levels][:, :, j0: j1 + 1]), slot
-    assert st.max_chunks[0] > sized and st.max_chunks[1] == sized
+    assert st.max_chunks[0] > sized and st.max_chunks[1] == sized and st.tmap_pin[1].numel() >= 42
