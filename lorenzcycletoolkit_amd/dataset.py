@@ -498,7 +498,10 @@ def gather_on_host(var: RawVariable, plan: IngestPlan, t_range=None) -> np.ndarr
     out = None
     tsel = plan.tsel if t_range is None else plan.tsel[t_range[0]: t_range[1]]
     for n, ft in enumerate(tsel):
-        raw = np.asarray(var.data[int(ft)])[plan.kmap][:, plan.jmap][:, :, plan.imap]
+        if hasattr(var.data, "read_step"):          # a lazily inflated NetCDF-4 variable: only the chunks of the wanted levels
+            raw = var.data.read_step(int(ft), plan.kmap)[:, plan.jmap][:, :, plan.imap]
+        else:
+            raw = np.asarray(var.data[int(ft)])[plan.kmap][:, plan.jmap][:, :, plan.imap]
         raw = raw.astype(raw.dtype.newbyteorder("="))
         a = decode_values(raw, var.scale_factor, var.add_offset, var.fill_value)
         if out is None:

@@ -76,6 +76,15 @@ class H5Variable:
         return self._file._read_dataset(self, t)
 
 
+    def read_step(self, t: int, levels) -> np.ndarray:
+        """``var[t][levels]`` for a variable of rank >= 2 (axis 1 = level) that inflates only the chunks those levels lie in -- the
+        850-hPa diagnostics of a track need one level of three variables, not the 37 a whole time step holds."""
+        levels = [int(k) for k in levels]
+        t = int(t) + (self.shape[0] if t < 0 else 0)
+        if not 0 <= t < self.shape[0] or any(not 0 <= k < self.shape[1] for k in levels):
+            raise IndexError((t, levels))
+        return self._file._read_dataset(self, t, levels)[levels]
+
     def chunk_streams(self):
         """What a device-side inflate needs, or None when this variable is not a fully written, deflated, chunked dataset:
         ``{"chunk": chunk shape, "shuffle": bool, "table": {chunk origin (elements) -> (offset in the mapped file, stored bytes,
@@ -818,7 +827,9 @@ class H5File:
                 raise Hdf5Error(f"HDF5 filter {fid} not supported (deflate, shuffle and fletcher32 are)")
         return np.frombuffer(raw, dtype=var.dtype)
 
-    def _read_dataset(self, var: H5Variable, t: Optional[int]) -> np.ndarray:
+    def _read_dataset(self, var: H5Variable, t: Optional[int], axis1=None) -> np.ndarray:
+        """``axis1``: with a time step ``t`` -- only the chunks that hold these indices of axis 1 are read (the rest of the returned
+        block is fill)."""
         lay = var._layout
         shape = var.shape
         if lay["class"] in ("contiguous", "compact"):
@@ -850,6 +861,9 @@ class H5File:
         by_t = var._cache["by_t"]
         first = (lo0 // chunk[0]) * chunk[0]
         need = [item for o0 in range(first, hi0, chunk[0]) for item in by_t.get(o0, ())]
+        if axis1 is not None and t is not None and len(shape) >= 2:
+            wanted = {k // chunk[1] for k in axis1}
+            need = [item for item in need if item[0][1] // chunk[1] in wanted]
         if t is None:                                          # a whole-variable read is used once: nothing to keep (the cache would hold
             missing, keep = need, False                        # the variable a second time)
         else:

@@ -172,3 +172,24 @@ def test_chunks_that_were_never_written_read_as_the_hdf5_fill_value():
             assert np.array_equal(v[t], want[t]), (name, t)
     assert f.variables["a"].attrs["_FillValue"] == -32767
     f.close()
+
+
+@pytest.mark.parametrize("name", ["packed_chunked_tracked.nc", "packed_timechunk2_latest.nc", "float_contiguous_latest.nc", "packed_unlimited_v18.nc"])
+def test_read_step_inflates_only_the_levels_asked_for(name):
+    """``var.read_step(t, levels)`` = ``var[t][levels]`` (any order, repeats allowed) while touching only the chunks those levels lie in
+    -- counted through the reader's chunk cache."""
+    f = hdf5_lite.H5File(os.path.join(FIX, name))
+    v = f.variables["u"]
+    for t in (0, 3, 4, -1):
+        full = v[t]
+        for lv in ([1], [5, 0], [2, 3, 4], [4, 4]):
+            assert np.array_equal(v.read_step(t, lv), full[lv]), (t, lv)
+    if v._layout.get("class") == "chunked":
+        v._cache = {k: x for k, x in v._cache.items() if not (isinstance(k, tuple) and k and k[0] == "chunk")}
+        v.read_step(2, [1])
+        held = [k[1] for k in v._cache if isinstance(k, tuple) and k and k[0] == "chunk"]
+        ck = v._layout["chunk"][1]
+        assert held and all(o[1] // ck == 1 // ck for o in held)          # only the level chunk that holds level 1
+    with pytest.raises(IndexError):
+        v.read_step(0, [99])
+    f.close()
