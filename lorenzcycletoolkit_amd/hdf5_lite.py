@@ -86,7 +86,9 @@ class H5Variable:
         return self._file._read_dataset(self, t, levels)[levels]
 
     def chunk_streams(self):
-        """What a device-side inflate needs, or None when this variable is not a fully written, deflated, chunked dataset:
+        """What a device-side inflate needs, or None when this variable is not a fully written chunked dataset with no filter other
+        than shuffle / deflate / fletcher32 (a chunked variable WITHOUT deflate -- every record variable of an uncompressed NetCDF-4
+        file -- qualifies: its chunks are "stored as they are" and are copied into place):
         ``{"chunk": chunk shape, "shuffle": bool, "table": {chunk origin (elements) -> (offset in the mapped file, stored bytes,
         deflate skipped for this chunk)}, "fletcher32": bool, "map": the file's memory map}``.  The stored bytes of a chunk are its zlib
         stream; with ``fletcher32`` four checksum bytes follow them (not counted in "stored bytes"; ``lec_inflate`` verifies them)."""
@@ -97,7 +99,7 @@ class H5Variable:
     def _chunk_streams(self):
         lay = self._layout
         ids = [fid for fid, _cd in self._filters]
-        if lay.get("class") != "chunked" or 1 not in ids or any(f not in (1, 2, 3) for f in ids):
+        if lay.get("class") != "chunked" or any(f not in (1, 2, 3) for f in ids):
             return None
         if sorted(ids, key=lambda f: {2: 0, 1: 1, 3: 2}[f]) != ids or len(set(ids)) != len(ids):
             return None                                    # the usual pipeline order only: shuffle, deflate, fletcher32
@@ -112,7 +114,7 @@ class H5Variable:
             skip = [bool(mask & (1 << i)) for i in range(len(ids))]
             if (2 in ids and skip[ids.index(2)]) or (3 in ids and skip[ids.index(3)]):
                 return None
-            out[offs] = (addr + self._file.base, size - (4 if 3 in ids else 0), skip[ids.index(1)])
+            out[offs] = (addr + self._file.base, size - (4 if 3 in ids else 0), skip[ids.index(1)] if 1 in ids else True)
         return {"chunk": tuple(lay["chunk"]), "shuffle": 2 in ids, "fletcher32": 3 in ids, "table": out, "map": self._file._m}
 
 

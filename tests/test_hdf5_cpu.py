@@ -18,7 +18,9 @@ FIX = os.path.join(ROOT, "tests", "golden", "hdf5")
 FILES = ["packed_chunked_earliest.nc", "packed_chunked_tracked.nc", "float_contiguous_latest.nc", "float_chunked_latest.nc",
          "packed_unlimited_v18.nc",       # unlimited time dimension (chunked coordinate), fletcher32 checksums
          "packed_unlimited_latest.nc",    # the same with libver latest: extensible-array chunk index
-         "packed_timechunk2_latest.nc"]   # chunks of 2 time steps x 2 levels x 5 latitudes: edge chunks along three axes
+         "packed_timechunk2_latest.nc",   # chunks of 2 time steps x 2 levels x 5 latitudes: edge chunks along three axes
+         "float_chunked_plain_latest.nc", # chunked, no filter at all
+         "packed_shuffle_only_v18.nc"]    # unlimited, shuffle + fletcher32 but no deflate
 
 
 def _generator():

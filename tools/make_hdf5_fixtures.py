@@ -40,7 +40,8 @@ def pack(a):
     return np.clip(np.round((a - offset) / scale), -32000, 32000).astype(np.int16), float(scale), float(offset)
 
 
-def write(path, libver, track_order, packed, chunks, vlen_units, many_attrs, nt=5, nl=6, ny=13, nx=24, unlimited=False, time_chunk=1):
+def write(path, libver, track_order, packed, chunks, vlen_units, many_attrs, nt=5, nl=6, ny=13, nx=24, unlimited=False, time_chunk=1,
+          deflate=True, shuffle=True):
     lev, lat, lon, f = fields(nt, nl, ny, nx)
     with h5py.File(path, "w", libver=libver, track_order=track_order) as h:
         h.attrs["Conventions"] = np.string_("CF-1.6")
@@ -58,7 +59,9 @@ def write(path, libver, track_order, packed, chunks, vlen_units, many_attrs, nt=
         for name, a in f.items():
             kw = {}
             if chunks:
-                kw = dict(chunks=(time_chunk, 2, ny if time_chunk == 1 else 5, nx // 2), compression="gzip", compression_opts=4, shuffle=True)
+                kw = dict(chunks=(time_chunk, 2, ny if time_chunk == 1 else 5, nx // 2), shuffle=shuffle)
+                if deflate:
+                    kw.update(compression="gzip", compression_opts=4)
             if unlimited:
                 kw.update(maxshape=(None, nl, ny, nx), fletcher32=True)
             if packed:
@@ -122,5 +125,8 @@ if __name__ == "__main__":
     write(os.path.join(OUT, "packed_unlimited_latest.nc"), "latest", False, True, True, True, False, unlimited=True)    # extensible-array chunk index
     # chunks that span two time steps and tile the latitudes unevenly (5 + 5 + 3 rows): what a writer with its own chunk cache leaves
     write(os.path.join(OUT, "packed_timechunk2_latest.nc"), "latest", False, True, True, False, False, time_chunk=2)
+    # chunked WITHOUT deflate: what every record variable of an uncompressed NetCDF-4 file is (the device path copies such chunks into place)
+    write(os.path.join(OUT, "float_chunked_plain_latest.nc"), "latest", False, False, True, False, False, deflate=False, shuffle=False)
+    write(os.path.join(OUT, "packed_shuffle_only_v18.nc"), ("earliest", "v108"), True, True, True, False, False, unlimited=True, deflate=False)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
