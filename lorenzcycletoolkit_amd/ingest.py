@@ -254,6 +254,29 @@ class _Stager:
         return moved
 
 
+def chunk_copy_plan(addr: np.ndarray, size: np.ndarray, tail: int = 0, gap: int = 64 << 10):
+    """Where the stored chunks at file offsets ``addr`` (``size`` + ``tail`` bytes each) go in a staging buffer, copied as few large
+    spans as possible: RUNS of chunks that lie (almost) back to back in the file -- a whole variable written in one go is one run per
+    call, a file written step by step (the variables interleaved) one run per step -- each run one span, gaps of up to ``gap`` bytes
+    included (per-chunk copy jobs of a few 100 KB leave the thread pool waiting for the GIL: 11 GB/s instead of > 50).  A stream keeps
+    its file alignment modulo 16 (``lec_inflate`` takes streams at any byte offset); repeated or overlapping chunks share their bytes.
+    Returns (offset of every chunk in the buffer, the runs' file offsets, lengths and buffer offsets, bytes of buffer used)."""
+    n = len(addr)
+    order = np.argsort(addr, kind="stable")
+    a_s, e_s = addr[order], (addr + size + tail)[order]
+    reach = np.maximum.accumulate(e_s)                            # a run's end is the furthest byte seen so far
+    starts = np.flatnonzero(np.concatenate([[True], a_s[1:] > reach[:-1] + gap]))
+    run_lo = a_s[starts]
+    run_len = np.concatenate([reach[starts[1:] - 1], reach[-1:]]) - run_lo
+    lead = run_lo & 15
+    padded = (lead + run_len + 15) & ~15
+    base = np.concatenate([[0], np.cumsum(padded)[:-1]]) + lead   # where each run's first byte lands
+    run_of = np.searchsorted(starts, np.arange(n), side="right") - 1
+    src_off = np.empty(n, dtype=np.int64)
+    src_off[order] = base[run_of] + (a_s - run_lo[run_of])
+    return src_off, run_lo, run_len, base, int(padded.sum())
+
+
 class _ChunkStager:
     """The path of a DEFLATED NetCDF-4 variable to the GPU: the compressed chunks cross the link as they lie in the file and
     ``lec_inflate`` (one wave per chunk) + ``lec_chunk_scatter`` (un-shuffle, chunk tiling) rebuild the raw sub-cube on the device --
@@ -360,28 +383,12 @@ class _ChunkStager:
         origins[:, 1:] = np.tile(self.space, (len(tcs), 1))
         view = self.view
         tail = 4 if self.info.get("fletcher32") else 0           # the checksum bytes after each stream travel with it
-        # Copy plan: RUNS of chunks that lie (almost) back to back in the file -- a whole variable written in one go is one run per call, a
-        # file written step by step (the variables interleaved) one run per step -- each run one span, gaps of up to 64 KiB included, in
-        # 8 MiB pieces (per-chunk jobs of a few 100 KB leave the thread pool waiting for the GIL: 11 GB/s instead of > 50).  Streams keep
-        # their file alignment modulo 16 inside a run; lec_inflate takes them at any byte offset.
-        order = np.argsort(addr, kind="stable")
-        a_s, e_s = addr[order], (addr + size + tail)[order]
-        reach = np.maximum.accumulate(e_s)                        # (repeated or overlapping chunks: a run's end is the furthest byte so far)
-        starts = np.flatnonzero(np.concatenate([[True], a_s[1:] > reach[:-1] + (64 << 10)]))
-        run_lo = a_s[starts]
-        run_hi = np.concatenate([reach[starts[1:] - 1], reach[-1:]])
-        run_len = run_hi - run_lo
-        lead = run_lo & 15
-        base = np.concatenate([[0], np.cumsum((lead + run_len + 15) & ~15)[:-1]]) + lead      # where each run's first byte lands
-        need = int(((lead + run_len + 15) & ~15).sum())
+        src_off, run_lo, run_len, base, need = chunk_copy_plan(addr, size, tail)
         if need + 2048 > self.comp_pin[slot].numel():           # larger than the sampled time-chunks (or many gaps): grow this slot's buffers
             grown = int(1.25 * need) + (4 << 20)                # (its last launch has completed: check() above)
             self.comp_pin[slot] = torch.empty(grown, dtype=torch.uint8, pin_memory=True)
             self.comp_dev[slot] = torch.empty(grown, dtype=torch.uint8, device=self.device)
         comp = self.comp_pin[slot].numpy()
-        run_of = np.searchsorted(starts, np.arange(n), side="right") - 1           # run of the i-th chunk in address order
-        src_off = np.empty(n, dtype=np.int64)
-        src_off[order] = base[run_of] + (a_s - run_lo[run_of])
         used = need
         piece = 8 << 20
         jobs = [(comp[d + a: d + min(a + piece, ln)], view[lo + a: lo + min(a + piece, ln)])

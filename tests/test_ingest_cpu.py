@@ -178,3 +178,42 @@ def test_registered_spans_bookkeeping():
     assert [b[:2] for b in sp.blocks] == [[base + 200704 - 4096, base + 208896]] or len(sp.blocks) == 1
     sp.close()
     assert rt.reg == {} and sp.blocks == []
+
+
+def test_chunk_copy_plan_places_every_stream_and_keeps_its_alignment():
+    """ingest.chunk_copy_plan on random layouts: adjacent chunks, small and large gaps, repeated chunks, any order, with and without
+    the 4 checksum bytes: copying the runs reproduces every stream at its planned offset, offsets keep the file alignment modulo 16,
+    runs do not overlap in the buffer, and chunks further apart than the gap get separate runs."""
+    from lorenzcycletoolkit_amd.ingest import chunk_copy_plan
+    rng = np.random.default_rng(0)
+    multi = 0
+    for trial in range(300):
+        n, tail = int(rng.integers(1, 40)), int(rng.choice([0, 4]))
+        size = rng.integers(1, 5000, n).astype(np.int64)
+        addr = np.zeros(n, dtype=np.int64)
+        cur = int(rng.integers(0, 1000))
+        for i in range(n):
+            if i and rng.random() < 0.15:                     # the same chunk again (a repeated time step)
+                j = int(rng.integers(0, i))
+                addr[i], size[i] = addr[j], size[j]
+                continue
+            cur += int(rng.choice([0, 0, 0, 3, 70000, 200000]))
+            addr[i] = cur
+            cur += int(size[i]) + tail
+        perm = rng.permutation(n)
+        addr, size = addr[perm], size[perm]
+        blob = rng.integers(0, 256, int((addr + size + tail).max()) + 10, dtype=np.uint8)
+        src_off, run_lo, run_len, base, need = chunk_copy_plan(addr, size, tail)
+        multi += len(run_lo) > 1
+        comp = np.zeros(need, dtype=np.uint8)
+        spans = sorted(zip(base.tolist(), run_len.tolist()))
+        assert all(b0 + l0 <= b1 for (b0, l0), (b1, _l1) in zip(spans, spans[1:])) and spans[-1][0] + spans[-1][1] <= need
+        for lo, ln, d in zip(run_lo.tolist(), run_len.tolist(), base.tolist()):
+            comp[d: d + ln] = blob[lo: lo + ln]
+        for c in range(n):
+            assert np.array_equal(comp[src_off[c]: src_off[c] + size[c] + tail], blob[addr[c]: addr[c] + size[c] + tail]), (trial, c)
+            assert (src_off[c] - addr[c]) % 16 == 0
+        a_sorted = np.sort(addr)
+        far = int(np.sum(np.diff(a_sorted) > 5000 + tail + (64 << 10)))
+        assert len(run_lo) >= far + 1
+    assert multi > 50
