@@ -98,7 +98,8 @@ def test_netcdf4_file_streamed_equals_resident(workdir, name, storage):
 
 HDF5_DEFLATED = ["packed_chunked_earliest.nc", "packed_chunked_tracked.nc", "float_chunked_latest.nc", "packed_unlimited_v18.nc",
                  "packed_unlimited_latest.nc", "packed_timechunk2_latest.nc",
-                 "float_chunked_plain_latest.nc", "packed_shuffle_only_v18.nc"]       # chunked without deflate: chunks copied, not inflated
+                 "float_chunked_plain_latest.nc", "packed_shuffle_only_v18.nc",       # chunked without deflate: chunks copied, not inflated
+                 "packed_interleaved_v18.nc"]                                         # written step by step: the variables' chunks interleave
 
 
 @pytest.mark.parametrize("name", HDF5_DEFLATED)

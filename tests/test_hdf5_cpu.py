@@ -20,7 +20,8 @@ FILES = ["packed_chunked_earliest.nc", "packed_chunked_tracked.nc", "float_conti
          "packed_unlimited_latest.nc",    # the same with libver latest: extensible-array chunk index
          "packed_timechunk2_latest.nc",   # chunks of 2 time steps x 2 levels x 5 latitudes: edge chunks along three axes
          "float_chunked_plain_latest.nc", # chunked, no filter at all
-         "packed_shuffle_only_v18.nc"]    # unlimited, shuffle + fletcher32 but no deflate
+         "packed_shuffle_only_v18.nc",    # unlimited, shuffle + fletcher32 but no deflate
+         "packed_interleaved_v18.nc"]     # written step by step: the variables' chunks interleave in the file
 
 
 def _generator():

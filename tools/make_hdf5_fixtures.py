@@ -87,6 +87,39 @@ def write(path, libver, track_order, packed, chunks, vlen_units, many_attrs, nt=
                 h.create_dataset("pad_%d" % i, data=np.arange(3, dtype=np.int32))
 
 
+def write_interleaved(path, nt=5, nl=6, ny=13, nx=24):
+    """The same fields written the way a model writes a record file: step by step, all variables of a step before the next one -- the
+    chunks of one variable are then scattered through the file between the other variables' (extendible time axis, v1 B-trees)."""
+    lev, lat, lon, f = fields(nt, nl, ny, nx)
+    with h5py.File(path, "w", libver=("earliest", "v108")) as h:
+        coords = {"level": lev.astype(np.int32), "latitude": lat.astype(np.float32), "longitude": lon.astype(np.float32)}
+        d = h.create_dataset("time", (nt,), dtype=np.int32, maxshape=(None,), chunks=(4,))
+        d.make_scale("time")
+        for name, vals in coords.items():
+            h.create_dataset(name, data=vals).make_scale(name)
+        for name, u in {"time": "hours since 2020-01-01 00:00:00", "level": "millibars", "latitude": "degrees_north", "longitude": "degrees_east"}.items():
+            h[name].attrs["units"] = np.string_(u)
+        packed = {}
+        for name, a in f.items():
+            q, scale, offset = pack(a)
+            if name == "v":
+                q[1, 0, :, :] = -32767
+            packed[name] = q
+            d = h.create_dataset(name, (nt, nl, ny, nx), dtype=np.int16, maxshape=(None, nl, ny, nx), chunks=(1, 2, ny, nx // 2),
+                                 compression="gzip", compression_opts=4, shuffle=True)
+            d.attrs["scale_factor"], d.attrs["add_offset"] = np.float64(scale), np.float64(offset)
+            d.attrs["_FillValue"] = np.int16(-32767)
+            d.attrs["missing_value"] = np.int16(-32767)
+            d.attrs["units"] = np.string_("K")
+            d.attrs["long_name"] = np.string_("field " + name)
+            for i, dn in enumerate(("time", "level", "latitude", "longitude")):
+                d.dims[i].attach_scale(h[dn])
+        for t in range(nt):
+            h["time"][t] = 6 * t
+            for name in f:
+                h[name][t] = packed[name][t]
+
+
 def sparse_arrays():
     """What write_sparse() writes and what a reader must return for it (pure function: the test regenerates it)."""
     rng = np.random.default_rng(11)
@@ -128,5 +161,6 @@ if __name__ == "__main__":
     # chunked WITHOUT deflate: what every record variable of an uncompressed NetCDF-4 file is (the device path copies such chunks into place)
     write(os.path.join(OUT, "float_chunked_plain_latest.nc"), "latest", False, False, True, False, False, deflate=False, shuffle=False)
     write(os.path.join(OUT, "packed_shuffle_only_v18.nc"), ("earliest", "v108"), True, True, True, False, False, unlimited=True, deflate=False)
+    write_interleaved(os.path.join(OUT, "packed_interleaved_v18.nc"))
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
