@@ -47,7 +47,10 @@ namespace {
 constexpr int kLitBits = LEC_INFLATE_LITBITS;        // lookup width of the literal / length code (codes up to 15 bits: the rest resolves on demand)
 constexpr int kDistBits = LEC_INFLATE_DISTBITS;
 constexpr int kRingDefault = LEC_INFLATE_RING;       // LDS history ring (bytes, power of two): what most matches refer to
-constexpr int kRingShort = 4096;                     // ... for streams whose matches stay close (flags bit 1): 18 instead of 12 waves per CU
+#ifndef LEC_INFLATE_RING_SHORT
+#define LEC_INFLATE_RING_SHORT 4096
+#endif
+constexpr int kRingShort = LEC_INFLATE_RING_SHORT;                     // ... for streams whose matches stay close (flags bit 1): 18 instead of 12 waves per CU
 
 enum { T_LIT = 0, T_MATCH = 1, T_EOB = 2, T_SLOW = 3, T_BAD = 4 };
 
@@ -207,8 +210,13 @@ enum {
     ST_DISTANCE = 7, ST_INPUT_END = 8, ST_OUTPUT_FULL = 9, ST_SIZE = 10, ST_STALLED = 11, ST_CHECKSUM = 12, ST_ADLER = 13
 };
 
+#ifdef LEC_INFLATE_WAVES
+#define LEC_INFLATE_OCC __attribute__((amdgpu_waves_per_eu(LEC_INFLATE_WAVES)))
+#else
+#define LEC_INFLATE_OCC
+#endif
 template <int kRing>
-__global__ void __launch_bounds__(64) lec_inflate_kernel(const InflateParams P) {
+__global__ void __launch_bounds__(64) LEC_INFLATE_OCC lec_inflate_kernel(const InflateParams P) {
     constexpr int kCap = kRing / 4;             // most output bytes one round of tokens may produce (up to its last match)
     constexpr int kFlushAt = kRing / 8;         // pending bytes that trigger a flush of the ring to HBM
     __shared__ InflateLds<kRing> L;
