@@ -377,3 +377,24 @@ def test_chunk_stager_grows_for_scattered_steps_of_time_spanning_chunks():
         got = st.raw_dev[slot][: len(use)].cpu().numpy().reshape(len(use), 3, j1 - j0 + 1, 10)
         assert np.array_equal(got, a[use][:, levels][:, :, j0: j1 + 1]), slot
     assert st.max_chunks[0] > sized and st.max_chunks[1] == sized and st.tmap_pin[1].numel() >= 42
+
+
+def test_inflate_and_slot_arguments_are_validated(workdir, golden_dir):
+    """``inflate="device"`` on a variable that is not a chunked NetCDF-4 one is refused (no silent host inflate), unknown values and
+    fewer than two pipeline slots too."""
+    (workdir / "inputs" / "box_limits").write_text("min_lon;-55\nmax_lon;-36\nmin_lat;-35\nmax_lat;-20\n")
+    args = argparse.Namespace(fixed=True, track=False, trackfile=None)
+    df = ds.read_namelist("inputs/namelist")
+    raw = ds.open_raw(os.path.join(golden_dir, "Catarina_NCEP-R2.nc"), df)          # classic NetCDF: plain mapped memory
+    plan = ingest.make_plan(raw, args)
+    limits = [(-55.0, -36.0, -35.0, -20.0)]
+    with pytest.raises(ValueError, match="inflate='device'"):
+        ingest.lec_streamed(raw, plan, df, limits, inflate="device")
+    with pytest.raises(ValueError, match="inflate must be"):
+        ingest.lec_streamed(raw, plan, df, limits, inflate="gpu")
+    with pytest.raises(ValueError, match="slots"):
+        ingest.lec_streamed(raw, plan, df, limits, slots=1)
+    a = ingest.lec_streamed(raw, plan, df, limits, slots=2)
+    b = ingest.lec_streamed(raw, plan, df, limits, slots=4, chunk_steps=3)
+    assert torch.equal(a.scalars, b.scalars) and torch.equal(a.levels, b.levels)
+    raw.close()
