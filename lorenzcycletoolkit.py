@@ -46,6 +46,8 @@ def create_arg_parser():
     parser.add_argument("--box_limits", type=str, default="inputs/box_limits", help="box-limits file for -f (default: inputs/box_limits)")
     parser.add_argument("--device-ingest", action="store_true", help="stream the file's bytes to the GPU in chunks and decode / sort / crop them "
                         "there, instead of preparing the whole data set on the host (same results, bit for bit)")
+    parser.add_argument("--inflate", choices=["auto", "host", "device"], default="auto", help="with --device-ingest and a chunked NetCDF-4 file: where "
+                        "the (deflated) chunks are inflated -- on the GPU (lec_inflate; the default wherever the variables allow it) or on the host's threads")
     parser.add_argument("--vorticity-form", choices=["metpy_no_crs", "spherical"], default="metpy_no_crs", help="with -t: formulation of the 850-hPa "
                         "relative vorticity in the trackfile (default: what MetPy 1.6.2 evaluates for data without a CRS, as the reference passes them)")
     parser.add_argument("--gpus", type=int, default=1, help="shard the time steps over this many GPUs of the node (one process per GPU, "

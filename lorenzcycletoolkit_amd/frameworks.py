@@ -97,7 +97,7 @@ class BoxData:
                 raise NotImplementedError("the device ingest differentiates T in time itself; do not pass a dTdt cube")
             self.ingest_stats = {}
             self.result: LECResult = lec_streamed(data.raw, data.plan, variable_list_df, limits, per_step_boxes=boxes_limits is not None,
-                                                  device=dev, chunk_steps=data.chunk_steps, stats=self.ingest_stats,
+                                                  device=dev, chunk_steps=data.chunk_steps, stats=self.ingest_stats, inflate=data.inflate,
                                                   t_range=None if shard is None else (t0, t1), merge_dropmask=merge, out=out)
         else:
             self.result = self._compute_resident(data, variable_list_df, dev, dTdt, merge, out)

@@ -45,6 +45,7 @@ class StreamedDataset:
     raw: ds.RawDataset
     plan: IngestPlan
     chunk_steps: Optional[int] = None      # None: lec_streamed's choice (8; 12 when the chunks are inflated on the device)
+    inflate: str = "auto"                   # where chunked NetCDF-4 variables are inflated (lec_streamed)
 
     def level_slice(self, role: str, level_pa: float, t_range=None) -> np.ndarray:
         """[time, lat, lon] of one role at one level, decoded on the host from the mapped file (the 850-hPa track diagnostics
@@ -71,7 +72,7 @@ def prepare_streamed(args, varlist: str = "inputs/namelist", app_logger=None, ch
         raise NotImplementedError("the device ingest serves the fixed (-f) and the track (-t) frameworks")
     df = ds.read_namelist(varlist, app_logger)
     raw = ds.open_raw(args.infile, df)
-    return StreamedDataset(raw, make_plan(raw, args, app_logger), chunk_steps)
+    return StreamedDataset(raw, make_plan(raw, args, app_logger), chunk_steps, getattr(args, "inflate", None) or "auto")
 
 
 def _src_code(dtype: np.dtype) -> int:

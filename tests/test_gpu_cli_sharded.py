@@ -174,7 +174,11 @@ def test_deflated_netcdf4_file_through_the_cli(workdir):
         _fresh(results)
         _run([src, "-r", flag, "--device-ingest"])
         _same_tree(one, _tree(results), f"{name}: --device-ingest (device inflate)")
-        assert "inflate" in open(results / "log.packed_chunked_tracked").read()
+        assert "inflate device" in open(results / "log.packed_chunked_tracked").read()
+        _fresh(results)
+        _run([src, "-r", flag, "--device-ingest", "--inflate", "host"])
+        _same_tree(one, _tree(results), f"{name}: --device-ingest --inflate host")
+        assert "inflate host" in open(results / "log.packed_chunked_tracked").read()
         _fresh(results)
         _run([src, "-r", flag, "--device-ingest", "--gpus", "2"])
         _same_tree(one, _tree(results), f"{name}: --device-ingest on 2 ranks")
