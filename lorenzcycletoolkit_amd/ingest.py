@@ -577,8 +577,24 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
         slots = 3 if on_gpu else 2
     if slots < 2:
         raise ValueError("slots must be >= 2")
-    if chunk_steps is None:          # the more chunks a launch of the device inflate holds, the better its tail is hidden
-        chunk_steps = 12 if on_gpu else 8
+    if chunk_steps is None:
+        chunk_steps = 8
+        if on_gpu:
+            # A launch of the device inflate lasts as long as its slowest chunk however few chunks it holds, and the GPU takes ~4600
+            # of them at a time: a batch should hold ~13000 (files with one chunk per level need more steps for that than files with
+            # six), as far as 45 % of the free device memory allows for the three slots' buffers.
+            jb0, jb1 = int(plan.jmap.min()), int(plan.jmap.max())
+            per_step = 0
+            for v in rvars.values():
+                info = getattr(v.data, "chunk_streams", lambda: None)()
+                if info is not None:
+                    ct, ck, cj, ci = info["chunk"]
+                    per_step += (len({int(k) // ck for k in plan.kmap}) * (jb1 // cj - jb0 // cj + 1) * -(-int(v.data.shape[3]) // ci)) / ct
+            sub = nl * (jb1 - jb0 + 1) * int(rvars["Air Temperature"].data.shape[3])
+            per_slot_step = sum(2 * sub * v.data.dtype.itemsize for v in rvars.values()) + 5 * nl * ny * nx * (8 if common == np.float64 else 4)
+            avail = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)      # free + what torch caches
+            by_memory = int(0.45 * avail / (slots * per_slot_step)) - 2
+            chunk_steps = int(np.clip(-(-13000 // max(int(per_step), 1)), 8, max(8, min(32, by_memory))))
     chunk_steps = max(1, min(int(chunk_steps), t1 - t0))
     span = chunk_steps + 2                                                # own steps + the one-step halo of T either side
     # staged sub-cube of every file time step: the kept levels (already in output order) x the latitude band of the domain
