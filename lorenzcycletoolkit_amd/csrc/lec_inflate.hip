@@ -472,16 +472,21 @@ __global__ void __launch_bounds__(64) LEC_INFLATE_OCC lec_inflate_kernel(const I
                 // 64-bit shift + or for the chain bit); these are 8.  Leaves with pos >= 64, or with `inf` = the non-literal at pos.
                 if (pos < 64u) {
                     uint32_t tmp;
+#define LEC_WALK_STEP \
+                        "v_readlane_b32 %[inf], %[info], %[pos]\n\t" \
+                        "s_cmp_lt_i32 %[inf], 0\n\t" \
+                        "s_cbranch_scc0 2f\n\t" \
+                        "s_bitset1_b64 %[chain], %[pos]\n\t" \
+                        "s_and_b32 %[tmp], %[inf], 63\n\t" \
+                        "s_add_u32 %[pos], %[pos], %[tmp]\n\t" \
+                        "s_cmp_lt_u32 %[pos], 64\n\t"
+                    // four tokens per trip: a TAKEN branch empties the wave's instruction buffer, the exits here fall through
                     asm volatile(
                         "1:\n\t"
-                        "v_readlane_b32 %[inf], %[info], %[pos]\n\t"
-                        "s_cmp_lt_i32 %[inf], 0\n\t"
-                        "s_cbranch_scc0 2f\n\t"
-                        "s_bitset1_b64 %[chain], %[pos]\n\t"
-                        "s_and_b32 %[tmp], %[inf], 63\n\t"
-                        "s_add_u32 %[pos], %[pos], %[tmp]\n\t"
-                        "s_cmp_lt_u32 %[pos], 64\n\t"
-                        "s_cbranch_scc1 1b\n\t"
+                        LEC_WALK_STEP "s_cbranch_scc0 2f\n\t"
+                        LEC_WALK_STEP "s_cbranch_scc0 2f\n\t"
+                        LEC_WALK_STEP "s_cbranch_scc0 2f\n\t"
+                        LEC_WALK_STEP "s_cbranch_scc1 1b\n\t"
                         "2:"
                         : [inf] "=&s"(inf), [pos] "+s"(pos), [chain] "+s"(chain), [tmp] "=&s"(tmp)
                         : [info] "v"(info)
