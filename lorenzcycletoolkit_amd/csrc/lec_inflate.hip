@@ -38,6 +38,10 @@
 #ifndef LEC_INFLATE_RING
 #define LEC_INFLATE_RING 8192
 #endif
+#ifndef LEC_INFLATE_TIMING
+#define LEC_INFLATE_TIMING 0          // debug builds (tools/probes/inflate_timing.py): 1..4 = time the round's window / decode / walk / write
+#endif                                // phase, 6..8 = within the write phase: offsets + literals / the matches / sync + flush
+#define LEC_TICK(k, var) if (LEC_INFLATE_TIMING == (k)) var = (uint32_t)__builtin_amdgcn_s_memtime()
 #ifndef LEC_INFLATE_C_WALK
 #define LEC_INFLATE_C_WALK 0
 #endif
@@ -316,6 +320,7 @@ __global__ void __launch_bounds__(64) LEC_INFLATE_OCC lec_inflate_kernel(const I
         }
     };
 
+    uint32_t tsum = 0, trounds = 0, tmatches = 0;      // (timing builds)
     bool last = false;
     while (status == ST_OK && !last) {
         // ------------------------------------------------------------------ block header (wave-uniform)
@@ -409,6 +414,8 @@ __global__ void __launch_bounds__(64) LEC_INFLATE_OCC lec_inflate_kernel(const I
         bool eob = false;
         uint32_t rounds = 0;
         while (!eob) {
+            uint32_t tk0 = 0, tk1 = 0;
+            LEC_TICK(1, tk0);
             if (++rounds > src_bits + 8u) { status = ST_STALLED; break; }
             in.seek(bitpos);
             // 64 bits of the stream from bit (bitpos + lane)
@@ -423,6 +430,8 @@ __global__ void __launch_bounds__(64) LEC_INFLATE_OCC lec_inflate_kernel(const I
                 win = (((uint64_t)x1 << 32) | x0) >> sh;
                 if (sh) win |= (uint64_t)x2 << (64u - sh);
             }
+            LEC_TICK(1, tk1);
+            LEC_TICK(2, tk0);
             // the token that would start here -- straight-line code: every lane evaluates the literal AND the match reading (the second
             // table lookup included: its index is masked, so garbage bits are harmless) and selects; with 64 speculative positions some
             // lane takes every path anyway, and divergent branches cost scalar instructions on a unit the whole CU shares
@@ -447,6 +456,8 @@ __global__ void __launch_bounds__(64) LEC_INFLATE_OCC lec_inflate_kernel(const I
                 value = sym < 256u ? sym : length;
                 used = type == T_MATCH ? l2 + dextra : l0;
             }
+            LEC_TICK(2, tk1);
+            LEC_TICK(3, tk0);
             // Follow the true chain through the lanes.  One word per lane carries what the walk needs of a token: bits used (6) |
             // type (3) | output bytes (9); a literal -- the common case -- is recognised by one compare and costs one readlane.
             auto pack = [](uint32_t ty, uint32_t nbits, uint32_t val) {
@@ -531,12 +542,16 @@ __global__ void __launch_bounds__(64) LEC_INFLATE_OCC lec_inflate_kernel(const I
                 extra_out += n_out - 1u;
                 pos += inf & 63u;
             }
+            LEC_TICK(3, tk1);
+            LEC_TICK(4, tk0);
             if (status != ST_OK) break;
             if (bitpos + pos > src_bits) { status = ST_INPUT_END; break; }
             const uint32_t produced = (uint32_t)__popcll(chain) + extra_out;
             if (produced > out_len - opos) { status = ST_OUTPUT_FULL; break; }
             const bool mine = (chain >> lane) & 1ull;
             uint64_t mm = chain & __ballot(type == T_MATCH);
+            LEC_TICK(6, tk0);
+            if (LEC_INFLATE_TIMING) tmatches += (uint32_t)__popcll(mm);
             // where each token's output starts: one byte per chain token below it, plus what the matches below it add
             uint32_t ooff = (uint32_t)__popcll(chain & ((1ull << lane) - 1ull));
             for (uint64_t m2 = mm; m2;) {
@@ -550,6 +565,8 @@ __global__ void __launch_bounds__(64) LEC_INFLATE_OCC lec_inflate_kernel(const I
             // matches, in stream order, 64 bytes at a time
             const int safe_lo = (int)opos + kCap + 64 - kRing;                 // positions from here on are in the ring for the whole round (a round
                                                                                 // writes at most kCap bytes up to its last match, then < 64 literals)
+            LEC_TICK(6, tk1);
+            LEC_TICK(7, tk0);
             while (mm) {
                 const uint32_t i = (uint32_t)__builtin_ctzll(mm);
                 mm &= mm - 1ull;
@@ -571,16 +588,22 @@ __global__ void __launch_bounds__(64) LEC_INFLATE_OCC lec_inflate_kernel(const I
                         kk = (uint32_t)r;
                     }
                     const int sp = from + (int)kk;
-                    const uint8_t byte = sp >= safe_lo ? L.ring[(uint32_t)sp & (kRing - 1)] : out[sp];
-                    L.ring[(p + k) & (kRing - 1)] = byte;
+                    uint8_t byte = L.ring[(uint32_t)sp & (kRing - 1)];         // (always read: a select between an LDS and a global POINTER
+                    if (sp < safe_lo) byte = out[sp];                          // makes this compiler build a flat pointer it then mis-compiles
+                    L.ring[(p + k) & (kRing - 1)] = byte;                      // when the surrounding code changes, e.g. in the timing builds)
                 }
                 wave_sync();
             }
+            LEC_TICK(7, tk1);
+            LEC_TICK(8, tk0);
             if (status != ST_OK) break;
             wave_sync();
             opos += produced;
             bitpos += pos;
             if (opos - flushed >= (uint32_t)kFlushAt) flush(false);
+            LEC_TICK(4, tk1);
+            LEC_TICK(8, tk1);
+            if (LEC_INFLATE_TIMING) { tsum += tk1 - tk0; ++trounds; }
         }
     }
     if (status == ST_OK) {
@@ -603,6 +626,7 @@ __global__ void __launch_bounds__(64) LEC_INFLATE_OCC lec_inflate_kernel(const I
     }
     if (lane == 0) {
         P.status[4 * s + 0] = status; P.status[4 * s + 1] = block; P.status[4 * s + 2] = (int)opos; P.status[4 * s + 3] = (int)bitpos;
+        if (LEC_INFLATE_TIMING) { P.status[4 * s + 1] = (int)tsum; P.status[4 * s + 2] = (int)tmatches; P.status[4 * s + 3] = (int)trounds; }
     }
 }
 
