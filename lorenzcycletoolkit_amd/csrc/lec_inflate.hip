@@ -480,27 +480,49 @@ __global__ void __launch_bounds__(64) LEC_INFLATE_OCC lec_inflate_kernel(const I
                 }
 #else
                 // written out: the compiler's version of the loop above is 14 scalar instructions per literal (three branches, a
-                // 64-bit shift + or for the chain bit); these are 8.  Leaves with pos >= 64, or with `inf` = the non-literal at pos.
+                // 64-bit shift + or for the chain bit); these are 8.  Matches are taken here too (label 3: their output bytes go to
+                // extra_out) as long as the round stays well below its output cap -- a round of a real field holds about three, and
+                // each trip through the general path below costs as much as several literals.  Leaves with pos >= 64, or with `inf` =
+                // the token at pos that the general path has to look at (end of block, a long code, a bad one, a match near the cap).
                 if (pos < 64u) {
                     uint32_t tmp;
 #define LEC_WALK_STEP \
                         "v_readlane_b32 %[inf], %[info], %[pos]\n\t" \
                         "s_cmp_lt_i32 %[inf], 0\n\t" \
-                        "s_cbranch_scc0 2f\n\t" \
+                        "s_cbranch_scc0 3f\n\t" \
                         "s_bitset1_b64 %[chain], %[pos]\n\t" \
                         "s_and_b32 %[tmp], %[inf], 63\n\t" \
                         "s_add_u32 %[pos], %[pos], %[tmp]\n\t" \
                         "s_cmp_lt_u32 %[pos], 64\n\t"
-                    // four tokens per trip: a TAKEN branch empties the wave's instruction buffer, the exits here fall through
+                    // four literals per trip: a TAKEN branch empties the wave's instruction buffer, the exits here fall through
                     asm volatile(
                         "1:\n\t"
                         LEC_WALK_STEP "s_cbranch_scc0 2f\n\t"
                         LEC_WALK_STEP "s_cbranch_scc0 2f\n\t"
                         LEC_WALK_STEP "s_cbranch_scc0 2f\n\t"
                         LEC_WALK_STEP "s_cbranch_scc1 1b\n\t"
+                        "s_branch 2f\n\t"
+                        "3:\n\t"                                              // not a literal: a match (type field = 1)?
+                        "s_bfe_u32 %[tmp], %[inf], 0x30006\n\t"
+                        "s_cmp_eq_u32 %[tmp], 1\n\t"
+                        "s_cbranch_scc0 2f\n\t"
+                        "s_lshr_b32 %[tmp], %[inf], 9\n\t"                    // its length
+                        "s_add_u32 %[extra], %[extra], %[tmp]\n\t"
+                        "s_sub_u32 %[extra], %[extra], 1\n\t"
+                        "s_cmp_gt_u32 %[extra], %[limit]\n\t"
+                        "s_cbranch_scc1 4f\n\t"
+                        "s_bitset1_b64 %[chain], %[pos]\n\t"
+                        "s_and_b32 %[tmp], %[inf], 63\n\t"
+                        "s_add_u32 %[pos], %[pos], %[tmp]\n\t"
+                        "s_cmp_lt_u32 %[pos], 64\n\t"
+                        "s_cbranch_scc1 1b\n\t"
+                        "s_branch 2f\n\t"
+                        "4:\n\t"                                              // near the cap: undo, the general path decides
+                        "s_sub_u32 %[extra], %[extra], %[tmp]\n\t"
+                        "s_add_u32 %[extra], %[extra], 1\n\t"
                         "2:"
-                        : [inf] "=&s"(inf), [pos] "+s"(pos), [chain] "+s"(chain), [tmp] "=&s"(tmp)
-                        : [info] "v"(info)
+                        : [inf] "=&s"(inf), [pos] "+s"(pos), [chain] "+s"(chain), [tmp] "=&s"(tmp), [extra] "+s"(extra_out)
+                        : [info] "v"(info), [limit] "s"((uint32_t)(kCap - 65))
                         : "scc");
                 }
 #endif
