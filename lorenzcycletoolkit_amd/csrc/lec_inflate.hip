@@ -77,6 +77,18 @@ __device__ __forceinline__ uint32_t rl(uint32_t v, uint32_t lane) { return (uint
 __device__ __forceinline__ uint32_t wl(uint32_t value, uint32_t lane, uint32_t old) {      // `old` with lane `lane` set to the uniform `value`
     return (uint32_t)__lane_id() == lane ? value : old;
 }
+// exclusive prefix sum over the 64 lanes in the vector ALU (DPP row shifts, then the row totals handed on): no LDS, no scalar loop
+__device__ __forceinline__ uint32_t wave_exclusive_sum(uint32_t x) {
+    int v = (int)x;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111 /* row_shr:1 */, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112 /* row_shr:2 */, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114 /* row_shr:4 */, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118 /* row_shr:8 */, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142 /* row_bcast:15 */, 0xA, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143 /* row_bcast:31 */, 0xC, 0xF, false);
+    return (uint32_t)v - x;
+}
+
 // One wave per workgroup: its LDS operations execute in program order, so only the COMPILER has to be kept from moving them
 // across this point (an s_barrier would also wait for the prefetched input block, every round).
 __device__ __forceinline__ void wave_sync() {
@@ -574,14 +586,9 @@ __global__ void __launch_bounds__(64) LEC_INFLATE_OCC lec_inflate_kernel(const I
             uint64_t mm = chain & __ballot(type == T_MATCH);
             LEC_TICK(6, tk0);
             if (LEC_INFLATE_TIMING) tmatches += (uint32_t)__popcll(mm);
-            // where each token's output starts: one byte per chain token below it, plus what the matches below it add
-            uint32_t ooff = (uint32_t)__popcll(chain & ((1ull << lane) - 1ull));
-            for (uint64_t m2 = mm; m2;) {
-                const uint32_t i = (uint32_t)__builtin_ctzll(m2);
-                m2 &= m2 - 1ull;
-                const uint32_t add = rl(value, i) - 1u;
-                if ((uint32_t)lane > i) ooff += add;
-            }
+            // where each token's output starts: the output bytes of the chain tokens below it (a prefix sum in the vector ALU)
+            const uint32_t ooff = wave_exclusive_sum(mine ? (type == T_MATCH ? value : type == T_LIT ? 1u : 0u) : 0u);
+            const uint32_t mdesc = value | (dist << 9);                        // a match in one word (length <= 258, distance <= 32768)
             // literals
             if (mine && type == T_LIT) L.ring[(opos + ooff) & (kRing - 1)] = (uint8_t)value;
             // matches, in stream order, 64 bytes at a time
@@ -589,10 +596,15 @@ __global__ void __launch_bounds__(64) LEC_INFLATE_OCC lec_inflate_kernel(const I
                                                                                 // writes at most kCap bytes up to its last match, then < 64 literals)
             LEC_TICK(6, tk1);
             LEC_TICK(7, tk0);
+            uint32_t nx_md = 0, nx_off = 0;
+            if (mm) { const uint32_t i = (uint32_t)__builtin_ctzll(mm); nx_md = rl(mdesc, i); nx_off = rl(ooff, i); }
             while (mm) {
-                const uint32_t i = (uint32_t)__builtin_ctzll(mm);
                 mm &= mm - 1ull;
-                const uint32_t len = rl(value, i), d = rl(dist, i), p = opos + rl(ooff, i);
+                const uint32_t len = nx_md & 511u, d = nx_md >> 9, p = opos + nx_off;
+                if (mm) {                                                       // the next match's two words: fetched before this one's copy
+                    const uint32_t i = (uint32_t)__builtin_ctzll(mm);
+                    nx_md = rl(mdesc, i); nx_off = rl(ooff, i);
+                }
                 if (d > p) { status = ST_DISTANCE; break; }
                 const int from = (int)(p - d);
                 if (from < safe_lo && (uint32_t)from + (len < d ? len : d) > fenced) {
