@@ -40,7 +40,7 @@
 #endif
 #ifndef LEC_INFLATE_TIMING
 #define LEC_INFLATE_TIMING 0          // debug builds (tools/probes/inflate_timing.py): 1..4 = time the round's window / decode / walk / write
-#endif                                // phase, 6..8 = within the write phase: offsets + literals / the matches / sync + flush
+#endif                                // phase, 6..8 = within the write phase: offsets + literals / the matches / sync + flush; 9 = a census of far / all / overlapping matches
 #define LEC_TICK(k, var) if (LEC_INFLATE_TIMING == (k)) var = (uint32_t)__builtin_amdgcn_s_memtime()
 #ifndef LEC_INFLATE_C_WALK
 #define LEC_INFLATE_C_WALK 0
@@ -607,6 +607,7 @@ __global__ void __launch_bounds__(64) LEC_INFLATE_OCC lec_inflate_kernel(const I
                 }
                 if (d > p) { status = ST_DISTANCE; break; }
                 const int from = (int)(p - d);
+                if (LEC_INFLATE_TIMING == 9) { tsum += (from < safe_lo); trounds += (d < len); }     // (a census: far / overlapping matches)
                 if (from < safe_lo && (uint32_t)from + (len < d ? len : d) > fenced) {
                     // the source was flushed by this wave's own earlier stores: make them visible to its loads
                     __threadfence();
@@ -652,7 +653,7 @@ __global__ void __launch_bounds__(64) LEC_INFLATE_OCC lec_inflate_kernel(const I
             if (opos - flushed >= (uint32_t)kFlushAt) flush(false);
             LEC_TICK(4, tk1);
             LEC_TICK(8, tk1);
-            if (LEC_INFLATE_TIMING) { tsum += tk1 - tk0; ++trounds; }
+            if (LEC_INFLATE_TIMING && LEC_INFLATE_TIMING != 9) { tsum += tk1 - tk0; ++trounds; }
         }
     }
     if (status == ST_OK) {
