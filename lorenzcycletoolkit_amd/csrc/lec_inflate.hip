@@ -619,7 +619,7 @@ __global__ void __launch_bounds__(64) LEC_INFLATE_OCC lec_inflate_kernel(const I
                     for (uint32_t k = (uint32_t)lane; k < len; k += 64u)
                         L.ring[(p + k) & (kRing - 1)] = L.ring[((uint32_t)from + k) & (kRing - 1)];
                 } else if (from >= safe_lo) {
-                    const float rd = __frcp_rn((float)d);
+                    const float rd = __builtin_amdgcn_rcpf((float)d);          // (within an ulp: the remainder below is corrected by one step)
                     for (uint32_t k = (uint32_t)lane; k < len; k += 64u) {
                         const uint32_t q = (uint32_t)((float)k * rd);
                         int r = (int)k - (int)(q * d);
@@ -627,16 +627,9 @@ __global__ void __launch_bounds__(64) LEC_INFLATE_OCC lec_inflate_kernel(const I
                         L.ring[(p + k) & (kRing - 1)] = L.ring[((uint32_t)from + (uint32_t)r) & (kRing - 1)];
                     }
                 } else {
-                    const float rd = __frcp_rn((float)d);
+                    // (a source behind the ring lies more than kRing - kCap - 64 > 258 bytes back: it cannot overlap its output)
                     for (uint32_t k = (uint32_t)lane; k < len; k += 64u) {
-                        uint32_t kk = k;
-                        if (d < len) {
-                            const uint32_t q = (uint32_t)((float)k * rd);
-                            int r = (int)k - (int)(q * d);
-                            if (r < 0) r += (int)d; else if (r >= (int)d) r -= (int)d;
-                            kk = (uint32_t)r;
-                        }
-                        const int sp = from + (int)kk;
+                        const int sp = from + (int)k;
                         uint8_t byte = L.ring[(uint32_t)sp & (kRing - 1)];     // (always read: a select between an LDS and a global POINTER
                         if (sp < safe_lo) byte = out[sp];                      // makes this compiler build a flat pointer it then mis-compiles
                         L.ring[(p + k) & (kRing - 1)] = byte;                  // when the surrounding code changes, e.g. in the timing builds)
