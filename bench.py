@@ -60,6 +60,9 @@ def parse_args(argv=None):
     ap.add_argument("--tuning", type=str, default="", help="A/B runs: lec_tuning fields, e.g. kernel=row_sweep,tile_t=4 (default: the library's choice)")
     ap.add_argument("--force-dist", action="store_true", help="with one rank: still create the process group and run the collectives "
                     "(the N > 1 code path -- RCCL init, barrier, mask all_reduce, gather -- on a one-GPU box)")
+    ap.add_argument("--digest-file", type=str, default=os.path.join(ROOT, "profiles", "series_digests.json"),
+                    help="per-step checksums of the packed series of one-GPU runs: what config.series_equals_n1 compares an N-GPU run with")
+    ap.add_argument("--write-digest", action="store_true", help="N = 1 only: add this run's series digest to --digest-file")
     ap.add_argument("--ny", type=int, default=721)
     ap.add_argument("--nx", type=int, default=1440)
     return ap.parse_args(argv)
@@ -263,8 +266,14 @@ def run_rank(args):
         dist.init_process_group(backend=backend, rank=rank, world_size=world)      # the rank's GPU is already current
 
     from lorenzcycletoolkit_amd.engine import LECEngine
-    from lorenzcycletoolkit_amd.parallel import SeriesGatherer, halo_range, merge_dropmask, shard_range
+    from lorenzcycletoolkit_amd.parallel import (SeriesGatherer, halo_range, merge_dropmask, ranks_and_devices, record_checksums,
+                                                 shard_range, verify_gather)
     from lorenzcycletoolkit_amd.synthetic import era5_like_levels, synthetic_cube
+
+    # who is really there: ranks the backend connected, the GPU each one drives (N > 1 runs happen on nodes nobody watches)
+    who = ranks_and_devices(device) if use_dist else None
+    if who is not None and (who["ranks_seen"] != world or (backend == "nccl" and not who["devices_distinct"])):
+        raise SystemExit(f"bench.py: rank {rank}: the process group is not what was asked for: {json.dumps(who)}")
 
     level = era5_like_levels()
     lat = np.linspace(-90.0, 90.0, args.ny)
@@ -450,6 +459,7 @@ def run_rank(args):
     sync()
     wall = time.perf_counter() - tic
     elapsed = wall if resident else timed_total
+    elapsed_own = elapsed
     if use_dist:
         el = torch.tensor([elapsed, wall], dtype=torch.float64, device=device)
         if backend == "gloo":
@@ -458,6 +468,13 @@ def run_rank(args):
         elapsed, wall = float(el[0]), float(el[1])
     res = last["res"]
     series = last.get("series")
+    # every rank's block of the gathered series against the checksums of what that rank sent (not only rank 0's own block)
+    peers = verify_gather(series, res.packed, T_global) if use_dist else None
+    per_rank = None
+    if use_dist:      # each rank's own clock for the timed region (the line's ms_per_step is their maximum)
+        mine = torch.tensor([elapsed_own], dtype=torch.float64, device=device)
+        from lorenzcycletoolkit_amd.parallel import _all_gather_small
+        per_rank = [float(x) / args.steps * 1e3 for x in _all_gather_small(mine).view(-1)]
 
     # Where a pass's time goes: three instrumented passes (every segment closed by a device synchronisation, the gather completed
     # inside its pass), median per segment.  Reported beside the timed figure, never inside it.
@@ -478,12 +495,16 @@ def run_rank(args):
                 "gather.staging_h2d", "gather.unpack", "pass_total_synchronised"]
         assert all(k in keys for sg in seg_runs for k in sg)
         med = {k: float(np.median([sg.get(k, 0.0) for sg in seg_runs])) * 1e3 for k in keys}
-        if use_dist:      # the slowest rank's figure per segment
+        segments_min = None
+        if use_dist:      # the slowest and the fastest rank's figure per segment: a straggler (link, GPU) shows as a gap
             tt = torch.tensor([med[k] for k in keys], dtype=torch.float64, device=device)
             if backend == "gloo":
                 tt = tt.cpu()
+            lo = tt.clone()
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
             med = {k: float(v) for k, v in zip(keys, tt)}
+            segments_min = {k: float(v) for k, v in zip(keys, lo)}
         segments = med
 
     # the BASELINE target configuration (conversion terms: T, u, v, omega) on the same resident fields, rank 0
@@ -581,6 +602,9 @@ def run_rank(args):
                                  "lec_rowstats per chunk + lec_reduce + collectives (synchronised segments); synthetic generation excluded"),
                 "results_finite": finite,
                 **({"gathered_series_ok": gathered_ok} if gathered_ok is not None else {}),
+                **({"peer_blocks_ok": peers["peer_blocks_ok"], "peer_blocks": peers["blocks_ok"],
+                    "rccl_ranks_seen": who["ranks_seen"], "devices_distinct": who["devices_distinct"], "rank_devices": who["devices"],
+                    "ms_per_step_per_rank": per_rank} if peers is not None else {}),
                 **({"tuning": args.tuning} if args.tuning else {}),
             },
             "roofline": {
@@ -600,6 +624,8 @@ def run_rank(args):
             # what a pass costs beyond its kernels, in the timed (pipelined) loop: host gaps + whatever of the collective is not hidden
             segments["fixed_cost_per_pass"] = pass_ms - k1 - segments.get("stage2", 0.0)
             out["config"]["segments_ms"] = segments
+            if segments_min is not None:
+                out["config"]["segments_ms_min_over_ranks"] = segments_min
             out["config"]["segments_note"] = ("median of 3 instrumented passes (a device synchronisation closes every segment; max over ranks); "
                                               "stage2 includes its launch and host time; fixed_cost_per_pass = pass_timed_unsynchronised - "
                                               "stage1_kernels_hip_events - stage2")
@@ -611,6 +637,35 @@ def run_rank(args):
             out["config"]["generation_ms_per_step"] = gen_s[0] / args.steps * 1e3
         if conv is not None:
             out["roofline"]["conversion_terms"] = conv
+        # the synthetic fields are seeded per GLOBAL time step and the kernels are bitwise reproducible under sharding and chunking,
+        # so the series does not depend on N: compare it with the digest a one-GPU run stored (profiles/series_digests.json)
+        dkey = (f"{'moving' if args.moving else 'fixed'}_{args.storage}_{'noq' if args.no_q else 'all'}_{nl}x{lat.size}x{lon.size}_T{T_global}")
+        full = series if (series is not None and gat.active) else res.packed
+        sums = record_checksums(full).cpu().numpy() if full.shape[0] == T_global else None
+        if sums is not None:
+            import hashlib
+            digest = {"sha256": hashlib.sha256(sums.tobytes()).hexdigest(), "steps": int(T_global),
+                      "per_step": "".join("%016x" % (int(x) & 0xFFFFFFFFFFFFFFFF) for x in sums)}
+            try:
+                stored = json.load(open(args.digest_file)).get(dkey)
+            except Exception:
+                stored = None
+            out["config"]["series_digest_key"] = dkey
+            out["config"]["series_sha256"] = digest["sha256"]
+            out["config"]["series_equals_n1"] = None if stored is None else bool(stored["sha256"] == digest["sha256"])
+            if stored is not None and stored["sha256"] != digest["sha256"] and len(stored.get("per_step", "")) == 16 * T_global:
+                bad = [i for i in range(T_global) if stored["per_step"][16 * i:16 * i + 16] != digest["per_step"][16 * i:16 * i + 16]]
+                out["config"]["series_steps_differing_from_n1"] = {"count": len(bad), "first": bad[:8]}
+            if args.write_digest and world == 1:
+                try:
+                    book = json.load(open(args.digest_file))
+                except Exception:
+                    book = {"_note": "per-step checksums (parallel.record_checksums) of the packed series of one-GPU bench.py runs, keyed by "
+                                     "configuration and global series length; bench.py compares an N-GPU run's gathered series with them "
+                                     "(config.series_equals_n1)"}
+                book[dkey] = digest
+                os.makedirs(os.path.dirname(os.path.abspath(args.digest_file)), exist_ok=True)
+                json.dump(book, open(args.digest_file, "w"), indent=1)
         if strong:
             ref = os.path.join(ROOT, "profiles", "strong_scaling_n1.json")
             try:

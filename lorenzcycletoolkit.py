@@ -144,6 +144,8 @@ def main(argv=None):
         finally:
             if args.device_ingest:
                 data.raw.close()
+        if args.shard is not None:
+            args.shard.barrier()                       # the ranks leave together, after rank 0 has written the files
     except Exception:
         app_logger.exception("LEC analysis failed")
         raise

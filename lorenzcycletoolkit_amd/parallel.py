@@ -60,7 +60,7 @@ class ShardContext:
         return (t0, t1) + halo_range(t0, t1, n_steps)
 
     def merge_dropmask(self, mask: torch.Tensor) -> None:
-        merge_dropmask(mask, self.group)
+        merge_dropmask(mask, self.group, force=True)      # a ShardContext exists only with a process group: world 1 (rehearsal) still reduces
 
     def gather_rows(self, local: torch.Tensor, n_steps: int) -> Optional[torch.Tensor]:
         """[T_local, n] rows of every rank -> [n_steps, n] on rank 0 (None elsewhere): one gather."""
@@ -80,11 +80,18 @@ class ShardContext:
 def shard_from_env() -> Optional[ShardContext]:
     """The shard context of a process started by ``python -m torch.distributed.run`` (or by ``lorenzcycletoolkit.py --gpus N``):
     RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment, one GPU per rank (LOCAL_RANK), process group over
-    LEC_DIST_BACKEND (default "nccl" = RCCL).  None when WORLD_SIZE is absent or 1: the ordinary one-process run."""
+    LEC_DIST_BACKEND (default "nccl" = RCCL).  None when WORLD_SIZE is absent or 1: the ordinary one-process run --
+    unless ``LEC_FORCE_SHARD=1``, which builds the world-1 context: process group, ``barrier(device_ids)``, the gather and the
+    device-side mask all_reduce all run over the backend with ONE rank (the rehearsal of the N > 1 code path a one-GPU box allows)."""
     import os
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1:
+    if world <= 1 and os.environ.get("LEC_FORCE_SHARD", "0") != "1":
         return None
+    if world <= 1 and "MASTER_PORT" not in os.environ:
+        import socket
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
     rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     backend = os.environ.get("LEC_DIST_BACKEND", "nccl")
     ndev = torch.cuda.device_count()
@@ -305,11 +312,12 @@ def gather_timeseries(local: torch.Tensor, n_steps: int, group=None) -> torch.Te
     return g.finish(0).clone()
 
 
-def merge_dropmask(mask: torch.Tensor, group=None) -> None:
+def merge_dropmask(mask: torch.Tensor, group=None, force: bool = False) -> None:
     """Element-wise max of every rank's any-time NaN-level mask, in place (a [28, nl] int32 all_reduce): a level
     that stays NaN at any time step of ANY shard is dropped from the pressure integrals of every time step, as
-    the reference's dropna(dim=level) on the whole [time, level] array does (energy_contents.py:203-207)."""
-    if not _dist_on(group):
+    the reference's dropna(dim=level) on the whole [time, level] array does (energy_contents.py:203-207).
+    ``force``: reduce even in a world of one (rehearsals of the N > 1 path)."""
+    if not (_dist_on(group) or (force and dist.is_available() and dist.is_initialized())):
         return
     if dist.get_backend(group) == "gloo" and mask.is_cuda:      # CPU rehearsal: stage through host memory
         host = mask.cpu()
@@ -342,3 +350,80 @@ def gather_result(res, n_steps: int, group=None):
     """One-shot form: the packed records [T_local, 16 + 21 nl] of every rank -> the full series on every rank."""
     local = res.packed if res.packed is not None else torch.cat([res.scalars, res.levels.reshape(res.levels.shape[0], -1)], dim=1)
     return gather_timeseries(local, n_steps, group)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Self-verification of a sharded run (what a first N > 1 run on hardware nobody has watched must say about itself)
+# ---------------------------------------------------------------------------------------------------------------------------
+def record_checksums(rows: torch.Tensor) -> torch.Tensor:
+    """[T, ncol] fp64 records -> [T] int64: the wrapping sum of every record's 64-bit patterns weighted by the odd numbers
+    1, 3, 5 ... (so swapped columns change it; +0.0 / -0.0 and NaN payloads count as the bits they are)."""
+    if rows.dtype != torch.float64 or rows.dim() != 2:
+        raise ValueError("record_checksums wants [T, ncol] float64")
+    bits = rows.contiguous().view(torch.int64)
+    w = torch.arange(rows.shape[1], dtype=torch.int64, device=rows.device) * 2 + 1
+    return (bits * w).sum(dim=1)
+
+
+def _all_gather_small(t: torch.Tensor, group=None) -> torch.Tensor:
+    """[n] tensor of every rank -> [world, n] on every rank (gloo with device tensors: through host memory)."""
+    world = dist.get_world_size(group)
+    staged = dist.get_backend(group) == "gloo" and t.is_cuda
+    src = t.cpu() if staged else t.contiguous()
+    out = torch.empty((world,) + tuple(src.shape), dtype=src.dtype, device=src.device)
+    dist.all_gather_into_tensor(out.view(-1), src.view(-1), group=group)
+    return out.to(t.device) if staged else out
+
+
+def verify_gather(series: Optional[torch.Tensor], local: torch.Tensor, n_steps: int, group=None, dst: int = 0) -> Optional[dict]:
+    """Checks EVERY rank's block of a gathered series, not only the receiving rank's own (collective: call it on every rank).
+
+    Each rank checksums the records it SENT (``local`` [T_local, ncol]); the checksums travel by an all_gather -- another
+    collective than the gather that moved the records --; the receiving rank recomputes them from ``series`` [n_steps, ncol]
+    block by block.  A permuted, stale, truncated or zero-filled peer block shows as ``blocks_ok[r] = False``.
+    Returns {"peer_blocks_ok", "blocks_ok", "blocks_checked", "steps_checked"} on rank ``dst``, None elsewhere."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    width = (n_steps + world - 1) // world
+    own = torch.zeros((width,), dtype=torch.int64, device=local.device)
+    t0, t1 = shard_range(n_steps, world, rank)
+    if local.shape[0] != t1 - t0:
+        raise ValueError(f"rank {rank}: expected {t1 - t0} local records, got {local.shape[0]}")
+    own[: t1 - t0] = record_checksums(local)
+    allsums = _all_gather_small(own, group)
+    if rank != dst:
+        return None
+    ok = []
+    if series is None or tuple(series.shape) != (n_steps, local.shape[1]):
+        ok = [False] * world
+    else:
+        got = record_checksums(series)
+        for r in range(world):
+            a, b = shard_range(n_steps, world, r)
+            ok.append(bool(torch.equal(got[a:b], allsums[r, : b - a].to(got.device))))
+    return {"peer_blocks_ok": all(ok), "blocks_ok": ok, "blocks_checked": world, "steps_checked": n_steps}
+
+
+def ranks_and_devices(device, group=None) -> dict:
+    """How many ranks the backend really connected (an all_reduce of ones) and which GPU each one drives (host name, device
+    index, PCI bus id, gathered): under "nccl" (= RCCL) the GPUs must be pairwise distinct -- two ranks on one card is a
+    mis-launch that would still print a plausible line.  Collective: call it on every rank; every rank gets the dict."""
+    import socket
+    device = torch.device(device)
+    backend = dist.get_backend(group)
+    one = torch.ones((1,), dtype=torch.int64, device=device if backend != "gloo" else "cpu")
+    dist.all_reduce(one, op=dist.ReduceOp.SUM, group=group)
+    ident = {"host": socket.gethostname(), "device_index": device.index, "pci": None, "name": None}
+    if device.type == "cuda":
+        pr = torch.cuda.get_device_properties(device)
+        ident["name"] = pr.name
+        bus = [getattr(pr, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id")]
+        if bus[1] is not None:
+            ident["pci"] = "%04x:%02x:%02x" % tuple(int(b or 0) for b in bus)
+        uuid = getattr(pr, "uuid", None)
+        if uuid is not None:
+            ident["uuid"] = str(uuid)
+    idents = [None] * dist.get_world_size(group)
+    dist.all_gather_object(idents, ident, group=group)
+    keys = [(d["host"], d.get("uuid") or d["pci"] or d["device_index"]) for d in idents]
+    return {"ranks_seen": int(one.item()), "world_size": dist.get_world_size(group), "backend": backend, "devices": idents,
+            "devices_distinct": len(set(keys)) == len(keys)}

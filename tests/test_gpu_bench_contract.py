@@ -61,6 +61,13 @@ def test_bench_starts_its_own_ranks_and_counts_them():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["world_size"] == 2 and d["config"]["timesteps_global"] == 6 and d["scaling"] == "weak"
     assert d["config"]["backend"] == "gloo" and d["config"]["results_finite"] is True and d["config"]["gathered_series_ok"] is True
+    # the run verifies itself: ranks connected, every rank's block of the gathered series, per-rank clocks and segments
+    c = d["config"]
+    assert c["rccl_ranks_seen"] == 2 and c["peer_blocks_ok"] is True and c["peer_blocks"] == [True, True] and len(c["rank_devices"]) == 2
+    assert len(c["ms_per_step_per_rank"]) == 2 and max(c["ms_per_step_per_rank"]) <= d["ms_per_step"] * (1 + 1e-9)
+    assert set(c["segments_ms_min_over_ranks"]) == set(k for k in c["segments_ms"] if k in c["segments_ms_min_over_ranks"])
+    assert all(c["segments_ms_min_over_ranks"][k] <= c["segments_ms"][k] + 1e-12 for k in c["segments_ms_min_over_ranks"])
+    assert len(c["series_sha256"]) == 64 and c["series_digest_key"] == "fixed_f64_all_37x61x128_T6" and c["series_equals_n1"] is None
     sg = d["config"]["segments_ms"]
     for k in ("stage1", "stage2", "mask_all_reduce", "gather", "gather.staging_d2h", "gather.collective", "gather.staging_h2d", "fixed_cost_per_pass"):
         assert k in sg, k
@@ -74,6 +81,34 @@ def test_bench_runs_the_rccl_code_path_with_one_rank():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["config"]["backend"] == "nccl" and d["config"]["results_finite"] is True and d["config"]["gathered_series_ok"] is True
     assert "mask_all_reduce" in d["config"]["segments_ms"] and "gather.collective" in d["config"]["segments_ms"]
+    c = d["config"]
+    assert c["rccl_ranks_seen"] == 1 and c["devices_distinct"] is True and c["peer_blocks_ok"] is True and c["peer_blocks"] == [True]
+    assert c["rank_devices"][0]["device_index"] == 0 and c["rank_devices"][0]["name"]
+
+
+def test_series_digest_of_a_two_rank_run_equals_the_one_gpu_digest(tmp_path):
+    """The synthetic fields are seeded per GLOBAL time step and the kernels are bitwise reproducible under sharding, so the series of
+    an N-rank run is the series of the one-GPU run: `--write-digest` stores the N = 1 per-step checksums, and a run finds
+    `series_equals_n1` true -- or says which steps differ."""
+    book = str(tmp_path / "digests.json")
+    r, lines = _bench(["--timesteps-global", "6", "--cpu-baseline", "none", "--digest-file", book, "--write-digest"] + SMALL)
+    assert r.returncode == 0, r.stderr[-2000:]
+    one = json.loads(lines[0])["config"]
+    stored = json.load(open(book))["fixed_f64_all_37x61x128_T6"]
+    assert stored["sha256"] == one["series_sha256"] and stored["steps"] == 6 and len(stored["per_step"]) == 96
+    r, lines = _bench(["--gpus", "2", "--timesteps", "3", "--cpu-baseline", "none", "--digest-file", book] + SMALL, env={"LEC_DIST_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    two = json.loads(lines[0])["config"]
+    assert two["series_digest_key"] == "fixed_f64_all_37x61x128_T6" and two["series_sha256"] == one["series_sha256"]
+    assert two["series_equals_n1"] is True and "series_steps_differing_from_n1" not in two
+    # a stored digest that differs in two steps: the line says false and names them
+    bk = json.load(open(book))
+    ps = bk["fixed_f64_all_37x61x128_T6"]["per_step"]
+    bk["fixed_f64_all_37x61x128_T6"].update(sha256="0" * 64, per_step=ps[:16] + "f" * 16 + ps[32:80] + "0" * 16)
+    json.dump(bk, open(book, "w"))
+    r, lines = _bench(["--gpus", "2", "--timesteps", "3", "--cpu-baseline", "none", "--digest-file", book] + SMALL, env={"LEC_DIST_BACKEND": "gloo"})
+    bad = json.loads(lines[0])["config"]
+    assert bad["series_equals_n1"] is False and bad["series_steps_differing_from_n1"] == {"count": 2, "first": [1, 5]}
 
 
 def test_bench_moving_checks_its_kernel_against_the_independent_one():

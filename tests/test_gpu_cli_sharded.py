@@ -30,10 +30,11 @@ def workdir(tmp_path, golden_dir, monkeypatch):
     return tmp_path
 
 
-def _run(argv, backend="gloo", launcher=None, timeout=600):
+def _run(argv, backend="gloo", launcher=None, timeout=600, extra_env=None):
     env = dict(os.environ, LEC_DIST_BACKEND=backend)
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LEC_FORCE_SHARD"):
         env.pop(k, None)
+    env.update(extra_env or {})
     cmd = [sys.executable, CLI] + argv if launcher is None else launcher + [CLI] + argv
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
@@ -150,6 +151,45 @@ def test_sharded_over_rccl(workdir, golden_dir):
     _fresh(results)
     _run([infile, "-r", "-f", "--gpus", str(min(torch.cuda.device_count(), 4))], backend="nccl")
     _same_tree(one, _tree(results), "RCCL")
+
+
+@pytest.mark.parametrize("ingest", [[], ["--device-ingest"]])
+def test_the_rccl_branch_of_the_cli_with_one_rank(workdir, golden_dir, ingest):
+    """LEC_FORCE_SHARD=1: the command line builds the world-1 shard context over backend "nccl" (= RCCL) -- process group,
+    ``dist.gather`` into the unbound receive views, the mask all_reduce on DEVICE tensors, the nine-number diagnostics gather,
+    ``barrier(device_ids)`` -- i.e. every line of the N > 1 branch that a one-GPU box can execute, for -f and -t, and must write
+    the bytes of the plain run (more RCCL ranks need more GPUs: test_sharded_over_rccl)."""
+    (workdir / "inputs" / "box_limits").write_text("min_lon;-55\nmax_lon;-36\nmin_lat;-35\nmax_lat;-20\n")
+    shutil.copy(os.path.join(golden_dir, "inputs", "track_testdata_NCEP-R2"), workdir / "inputs" / "track")
+    for flag, infile, name in (("-f", "Catarina_NCEP-R2.nc", "Catarina_NCEP-R2_fixed"), ("-t", "testdata_NCEP-R2.nc", "testdata_NCEP-R2_track")):
+        infile = os.path.join(golden_dir, infile)
+        results = workdir / "LEC_Results" / name
+        _fresh(results)
+        _run([infile, "-r", flag] + ingest)
+        one = _tree(results)
+        _fresh(results)
+        _run([infile, "-r", flag] + ingest, backend="nccl", extra_env={"LEC_FORCE_SHARD": "1"})
+        _same_tree(one, _tree(results), f"{flag} {ingest} through the world-1 RCCL shard context")
+        log = [f for f in os.listdir(results) if f.startswith("log.")][0]
+        assert "Time-sharded run: 1 ranks (backend nccl)" in open(results / log).read()
+
+
+def test_nan_mask_all_reduce_on_device_tensors_with_one_rccl_rank(workdir):
+    """The NaN sample (a level that is NaN at one step only) through the world-1 RCCL context: ``merge_dropmask`` all_reduces the
+    [28, L] int32 mask where it lies -- in device memory -- and the files equal the plain run's."""
+    path = str(workdir / "packed.nc")
+    write_packed_era5_style(path)
+    (workdir / "inputs" / "namelist").write_text(
+        ";Variable;Units\nAir Temperature;t;K\nGeopotential;z;m**2/s**2\nOmega Velocity;w;Pa/s\n"
+        "Eastward Wind Component;u;m/s\nNorthward Wind Component;v;m/s\nLongitude;longitude\nLatitude;latitude\n"
+        "Time;time\nVertical Level;level\n")
+    (workdir / "inputs" / "box_limits").write_text("min_lon;-60\nmax_lon;20\nmin_lat;-45\nmax_lat;30\n")
+    results = workdir / "LEC_Results" / "packed_fixed"
+    _run([path, "-r", "-f"])
+    one = _tree(results)
+    _fresh(results)
+    _run([path, "-r", "-f"], backend="nccl", extra_env={"LEC_FORCE_SHARD": "1"})
+    _same_tree(one, _tree(results), "NaN sample through the world-1 RCCL shard context")
 
 
 def test_deflated_netcdf4_file_through_the_cli(workdir):

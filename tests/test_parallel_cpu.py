@@ -9,7 +9,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from lorenzcycletoolkit_amd.parallel import SeriesGatherer, gather_timeseries, halo_range, merge_dropmask, shard_range
+from lorenzcycletoolkit_amd.parallel import (SeriesGatherer, gather_timeseries, halo_range, merge_dropmask, ranks_and_devices,
+                                             record_checksums, shard_range, verify_gather)
 from lorenzcycletoolkit_amd.tables import budgets_and_residuals
 
 
@@ -77,6 +78,34 @@ def _worker(rank, world, port, n_steps, out_dir):
             np.save(os.path.join(out_dir, "passes.npy"), np.stack([x.numpy() for x in got]))
         else:
             assert all(x is None for x in got)
+        # self-verification of a sharded run: every rank's block of the gathered series against the checksums of what that rank
+        # sent.  The honest series passes; a series whose PEER blocks are permuted, stale (another pass) or zeroed does not --
+        # rank 0's own block is intact in each of them, which is all the round-3 bench line looked at
+        g3 = SeriesGatherer(n_steps, 3, "cpu", dst=0, slots=1)
+        g3.send(0)[:] = local
+        g3.start(0)
+        s3 = g3.finish(0)
+        verdicts = {"honest": verify_gather(s3, local, n_steps)}
+        if rank == 0:
+            w0 = shard_range(n_steps, world, 0)[1]
+            swapped = s3.clone()
+            swapped[w0:] = s3[w0:].flip(0)                   # the peers' rows in another order
+            stale = s3.clone()
+            stale[w0:, 2] += 1.0                             # the peers' rows of some other pass
+            zero = s3.clone()
+            zero[-1] = 0.0                                   # a row that never arrived
+            own = s3.clone()
+            own[0, 0] = -1.0                                 # and rank 0's own block
+            tampered = {"swapped": swapped, "stale": stale, "zero": zero, "own": own, "short": s3[:-1]}
+        for name in ("swapped", "stale", "zero", "own", "short"):
+            verdicts[name] = verify_gather(tampered[name] if rank == 0 else None, local, n_steps)
+        who = ranks_and_devices("cpu")
+        assert who["ranks_seen"] == world and who["world_size"] == world and len(who["devices"]) == world and who["backend"] == "gloo"
+        if rank == 0:
+            import json
+            json.dump({k: v for k, v in verdicts.items()}, open(os.path.join(out_dir, "verdicts.json"), "w"))
+        else:
+            assert all(v is None for v in verdicts.values())
         # a backend without gather: the gatherer switches to an all_gather on the first call, rank 0 still gets the series, the others None
         real_gather = dist.gather
 
@@ -113,6 +142,13 @@ def test_gather_timeseries_gloo(tmp_path, world, n_steps):
         assert np.array_equal(np.load(tmp_path / f"full_{r}.npy"), want)
         assert np.array_equal(np.load(tmp_path / f"mask_{r}.npy"), want_mask)
     assert np.array_equal(np.load(tmp_path / "fallback.npy"), want)
+    import json
+    vd = json.load(open(tmp_path / "verdicts.json"))
+    assert vd["honest"]["peer_blocks_ok"] is True and vd["honest"]["blocks_ok"] == [True] * world and vd["honest"]["steps_checked"] == n_steps
+    for name in ("swapped", "stale", "zero"):
+        assert vd[name]["peer_blocks_ok"] is False and vd[name]["blocks_ok"][0] is True and not all(vd[name]["blocks_ok"][1:]), name
+    assert vd["own"]["blocks_ok"][0] is False and all(vd["own"]["blocks_ok"][1:])
+    assert vd["short"]["peer_blocks_ok"] is False
     passes = np.load(tmp_path / "passes.npy")
     assert passes.shape == (3, n_steps, 4)
     for p in range(3):
@@ -149,3 +185,16 @@ def test_budgets_on_gathered_series_equal_single_process():
     again = budgets_and_residuals(glued, t)
     for k in whole:
         assert np.array_equal(whole[k], again[k])
+
+
+def test_record_checksums_see_order_sign_of_zero_and_nan_payloads():
+    a = torch.tensor([[1.0, 2.0, 3.0], [0.0, -0.0, float("nan")]], dtype=torch.float64)
+    c = record_checksums(a)
+    assert c.dtype == torch.int64 and c.shape == (2,)
+    assert record_checksums(a[:, [1, 0, 2]])[0] != c[0]                    # swapped columns
+    b = a.clone()
+    b[1, 0] = -0.0
+    assert record_checksums(b)[1] != c[1]                                   # the sign of a zero is a bit
+    assert torch.equal(record_checksums(a.clone()), c)
+    with pytest.raises(ValueError):
+        record_checksums(a.float())
