@@ -554,7 +554,9 @@ def run_rank(args):
         avg_launch_ms = float(np.mean(launch_ms))
         steps_per_launch = T_local if resident else float(np.mean([b - a for a, b in chunks]))
         achieved = bytes_per_step_t * steps_per_launch / (avg_launch_ms * 1e-3) / 1e9
-        traffic, traffic_src = None, None
+        traffic, traffic_src, traffic_sha = None, None, None
+        from lorenzcycletoolkit_amd._lib import source_digest
+        csrc_sha = source_digest()
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if os.path.exists(pmc) and (args.ny, args.nx) == (721, 1440):
             try:
@@ -564,6 +566,7 @@ def run_rank(args):
                 per_t = summ.get(key)
                 traffic = None if per_t is None else per_t * steps_per_launch
                 traffic_src = summ.get(key.replace("_hbm_bytes_per_timestep", "_source"))
+                traffic_sha = summ.get(key.replace("_hbm_bytes_per_timestep", "_csrc_sha"))
             except Exception:
                 traffic = None
         if args.moving:
@@ -600,7 +603,7 @@ def run_rank(args):
                 "timed_region": ("wall clock around all passes (stage 1 + stage 2 + collectives, every pass's series delivered to rank 0), inputs resident in HBM"
                                  if resident else
                                  "lec_rowstats per chunk + lec_reduce + collectives (synchronised segments); synthetic generation excluded"),
-                "results_finite": finite,
+                "results_finite": finite, "csrc_sha": csrc_sha,
                 **({"gathered_series_ok": gathered_ok} if gathered_ok is not None else {}),
                 **({"peer_blocks_ok": peers["peer_blocks_ok"], "peer_blocks": peers["blocks_ok"],
                     "rccl_ranks_seen": who["ranks_seen"], "devices_distinct": who["devices_distinct"], "rank_devices": who["devices"],
@@ -612,6 +615,8 @@ def run_rank(args):
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": (None if traffic is None else f"{traffic_src}: rocprofv3 --pmc FETCH_SIZE pass of this command on an MI355X box, "
                                    "corrected per MI355X_MICROARCH.md, per launch; a stored measurement, not re-measured in this run"),
+                # the stored counter pass was taken on kernel sources with this digest; stale = the kernels have changed since
+                "traffic_csrc_sha": traffic_sha, "traffic_stale": (None if traffic is None else bool(traffic_sha != csrc_sha)),
                 "kernel": kname, "avg_launch_ms": avg_launch_ms,
                 "algorithmic_bytes_per_launch": bytes_per_step_t * steps_per_launch,
             },

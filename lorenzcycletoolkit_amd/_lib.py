@@ -22,6 +22,24 @@ LEC_F64, LEC_F32, LEC_I16, LEC_I32, LEC_I8 = 0, 1, 2, 3, 4
 KERNEL_AUTO, KERNEL_TWO_SWEEP, KERNEL_ROW_SWEEP, KERNEL_ROW_BLOCK, KERNEL_BOX_TILE = 0, 1, 2, 3, 4
 ORDER_AUTO, ORDER_MEMORY, ORDER_XCD_LAT, ORDER_XCD_TILED = 0, 1, 2, 7
 
+
+
+def source_digest() -> str:
+    """sha256 (first 16 hex digits) over the kernel sources the library is built from (csrc/*.hip|.h|.inc + include/lec_hip.h,
+    names and contents, sorted): stored with a profile so that a later run can tell whether a stored counter measurement was
+    taken on the kernels it runs (the GPU box has the sources but no git history)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h"))
+                   + glob.glob(os.path.join(_HERE, "csrc", "*.inc")))
+    files.append(os.path.join(os.path.dirname(_HERE), "include", "lec_hip.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 EXPORTS = ["lec_version", "lec_last_error", "lec_max_row", "lec_rowstats", "lec_reduce", "lec_dropmask", "lec_ingest", "lec_track_diag",
            "lec_check_boxes", "lec_check_maps", "lec_host_register", "lec_host_unregister", "lec_copy_rows_async",
            "lec_inflate", "lec_inflate_status_text", "lec_chunk_scatter"]

@@ -41,13 +41,32 @@ with open(os.path.join(dst, f"{rnd}_{tag}_kernel_stats.csv"), "w", newline="") a
             w.writerow(r)
 s1 = [r for r in rows if stage1(r["Name"])]
 main = max(s1, key=lambda r: float(r["TotalDurationNs"]))
-calls = int(main["Calls"])
-# (the --moving line's 8-step check launches add ~1 % to this per-call figure; the dominant kernel's own average below is exact only for the
-# fixed-box configurations, where every launch of it is a timed-pass launch)
-stage1_ms = sum(float(r["TotalDurationNs"]) for r in s1) / calls / 1e6
+# Per-launch figures come from the kernel TRACE, over the launches at each kernel's modal grid size: a bench line may launch a stage-1
+# kernel at other sizes as well (the --moving line checks 8 steps against the one-wave-per-row kernel; VERDICT r3 "weak" 2: the stats
+# file's AverageNs had that 28-us launch inside the mean of eleven and flattered the kernel by 9 %).
+trace = os.path.join(os.path.dirname(stats), os.path.basename(stats).replace("_kernel_stats.csv", "_kernel_trace.csv"))
+by_kernel = {}
+for r in csv.DictReader(open(trace)):
+    if stage1(r["Kernel_Name"]):
+        grid = (r["Grid_Size_X"], r["Grid_Size_Y"], r["Grid_Size_Z"])
+        by_kernel.setdefault(r["Kernel_Name"], {}).setdefault(grid, []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+modal = {k: max(g.items(), key=lambda kv: len(kv[1])) for k, g in by_kernel.items()}
+modal = {k: v for k, v in modal.items() if len(v[1]) > 1 or len(modal) == 1}      # kernels seen once only are not the timed pass's
+calls = len(modal[main["Name"]][1])
+stage1_ms = sum(sum(d) / len(d) for _, d in modal.values()) / 1e6
 bench = json.load(open(os.path.join(src, "bench_stats.json")))
+dom = modal[main["Name"]][1]
 out = {"tag": tag, "bench_line": bench, "stage1_kernels_ms_per_call": stage1_ms, "dominant_kernel": main["Name"],
-       "dominant_kernel_avg_ms": float(main["AverageNs"]) / 1e6, "calls": calls}
+       "dominant_kernel_avg_ms": sum(dom) / len(dom) / 1e6, "dominant_kernel_min_ms": min(dom) / 1e6, "dominant_kernel_max_ms": max(dom) / 1e6,
+       "calls": calls, "dominant_kernel_grid": "x".join(modal[main["Name"]][0]),
+       "launches_at_other_grid_sizes": {k[:60]: {"x".join(g): len(d) for g, d in by_kernel[k].items() if g != modal[k][0]} for k in modal
+                                        if len(by_kernel[k]) > 1},
+       "stats_file_average_ms": float(main["AverageNs"]) / 1e6, "stats_file_calls": int(main["Calls"]),
+       "how": "means over the kernel-trace launches at each stage-1 kernel's modal grid size (the timed passes)",
+       "csrc_sha": bench.get("config", {}).get("csrc_sha")}
+alg0 = bench["roofline"]["algorithmic_bytes_per_launch"]
+out["dominant_kernel_frac_of_8TBs"] = alg0 / (out["dominant_kernel_avg_ms"] * 1e-3) / 8e12
+out["stage1_frac_of_8TBs"] = alg0 / (stage1_ms * 1e-3) / 8e12
 pm = glob.glob(os.path.join(src, "pmc_1", "*", "*_counter_collection.csv"))
 if pm:
     per = {}
@@ -70,7 +89,9 @@ if pm:
         summ = json.load(open(p)) if os.path.exists(p) else {}
         summ[key] = read_bytes / t_per_launch
         summ[key.replace("_hbm_bytes_per_timestep", "_source")] = f"profiles/{rnd}_{tag}_pmc.json"
+        summ[key.replace("_hbm_bytes_per_timestep", "_csrc_sha")] = bp.get("config", {}).get("csrc_sha")
         json.dump(summ, open(p, "w"), indent=1)
 json.dump(out, open(os.path.join(dst, f"{rnd}_{tag}_pmc.json"), "w"), indent=1)
-print(tag, "stage1 ms/call %.3f" % stage1_ms, "dominant", main["Name"][:70], "%.3f ms" % (float(main["AverageNs"]) / 1e6),
+print(tag, "stage1 ms/call %.3f" % stage1_ms, "dominant", main["Name"][:70], "%.3f ms x %d (stats file: %.3f x %d)" % (
+    out["dominant_kernel_avg_ms"], calls, out["stats_file_average_ms"], out["stats_file_calls"]), "frac %.3f" % out["dominant_kernel_frac_of_8TBs"],
       "traffic/alg %.3f" % out.get("traffic_over_algorithmic", float("nan")))
