@@ -214,10 +214,27 @@ def _close_mapped(nc):
             pass
 
 
-def _open_nc(path: str, variable_list_df: pd.DataFrame, mmap: bool):
+MPAS_DROPPED_DIM = "standard_height"
+
+
+def _drop_mpas_dims(nc, path: str, app_logger=None) -> None:
+    """-m / --mpas: the reference drops the MPAS-BR post-processor's ``standard_height`` dimension and with it every variable on it
+    (``data.drop_dims("standard_height")``, preprocessing.py:367-368), so the analysis reads isobaric variables only; a namelist
+    that names one of the dropped variables then fails with a KeyError, as it does there."""
+    gone = [n for n, v in nc.variables.items() if MPAS_DROPPED_DIM in tuple(v.dimensions)]
+    for n in gone:
+        del nc.variables[n]
+    if app_logger is not None:
+        app_logger.info(f"--mpas: dropped the '{MPAS_DROPPED_DIM}' dimension of {path}" +
+                        (f" and the variables on it: {', '.join(gone)}" if gone else " (no variable uses it)"))
+
+
+def _open_nc(path: str, variable_list_df: pd.DataFrame, mmap: bool, mpas: bool = False, app_logger=None):
     """Opens a data file and checks it against the namelist (get_data, preprocessing.py:35-146;
     validate_variable_match / validate_required_coordinates, validation.py:247-356)."""
     nc = _Container(path, mmap)
+    if mpas:
+        _drop_mpas_dims(nc, path, app_logger)
     var = lambda role: str(variable_list_df.loc[role]["Variable"])
     names = {r: var(r) for r in REQUIRED_ROLES}
     geo_role = "Geopotential" if "Geopotential" in variable_list_df.index else "Geopotential Height"
@@ -299,9 +316,9 @@ def decode_values(raw: np.ndarray, scale, offset, fill) -> np.ndarray:
     return np.asarray(a, dtype=out)
 
 
-def open_dataset(path: str, variable_list_df: pd.DataFrame) -> LECDataset:
+def open_dataset(path: str, variable_list_df: pd.DataFrame, mpas: bool = False, app_logger=None) -> LECDataset:
     """Host-side decode of the whole file with the semantics of ``xr.open_dataset`` (decode_values)."""
-    nc, names, geo_role, lat, lon, lev, time, level_units, want = _open_nc(path, variable_list_df, mmap=False)
+    nc, names, geo_role, lat, lon, lev, time, level_units, want = _open_nc(path, variable_list_df, mmap=False, mpas=mpas, app_logger=app_logger)
     variables = {}
     for role in FIELD_ROLES + (geo_role,):
         v = nc.variables[names[role]]
@@ -344,9 +361,9 @@ class RawDataset:
             self._nc = None
 
 
-def open_raw(path: str, variable_list_df: pd.DataFrame) -> RawDataset:
+def open_raw(path: str, variable_list_df: pd.DataFrame, mpas: bool = False, app_logger=None) -> RawDataset:
     """Like open_dataset, but nothing is decoded or copied: the variables stay memory-mapped file bytes."""
-    nc, names, geo_role, lat, lon, lev, time, level_units, want = _open_nc(path, variable_list_df, mmap=True)
+    nc, names, geo_role, lat, lon, lev, time, level_units, want = _open_nc(path, variable_list_df, mmap=True, mpas=mpas, app_logger=app_logger)
     variables = {}
     for role in FIELD_ROLES + (geo_role,):
         v = nc.variables[names[role]]
@@ -519,12 +536,13 @@ def prepare_data(args, varlist: str = "inputs/namelist", app_logger=None) -> LEC
         raise NotImplementedError("--cdsapi downloads need network access and are out of scope")
     variable_list_df = read_namelist(varlist, app_logger)
     shard = getattr(args, "shard", None)          # time-sharded run (parallel.ShardContext): this rank decodes its own steps + halo only
+    mpas = bool(getattr(args, "mpas", False))
     try:
-        raw = open_raw(args.infile, variable_list_df)
+        raw = open_raw(args.infile, variable_list_df, mpas=mpas, app_logger=app_logger)
     except ValueError as e:
         if "order" not in str(e) and "device ingest reads" not in str(e):
             raise
-        data = open_dataset(args.infile, variable_list_df)
+        data = open_dataset(args.infile, variable_list_df, mpas=mpas)
         data = slice_domain(process_data(data, args, variable_list_df, app_logger), args, variable_list_df)
         return data if shard is None else data.held_steps(shard.ranges(len(data.time))[2:])
     try:

@@ -175,6 +175,7 @@ class H5File:
         self.attrs = self._attributes(msgs)
         links = self._group_links(msgs)
         by_addr = {}
+        self.skipped: Dict[str, str] = {}              # datasets that are not numeric arrays (name -> kind): strings, compounds, references
         for name, addr in links.items():
             try:
                 dm = self._object_messages(addr)
@@ -531,6 +532,8 @@ class H5File:
             elif mtype == 0x0B:
                 filters = self._filter_pipeline(p)
         if dt is None or shape is None or layout is None or dt.kind != "num":
+            if dt is not None and shape is not None:           # e.g. the CDS's per-time string coordinate `expver`: nothing numeric to hand out
+                self.skipped[name] = dt.kind
             return None
         var = H5Variable(name, tuple(shape), dt.np_dtype, self._attributes(msgs), (), self, layout, filters)
         for mtype, p, size in msgs:                            # fill value of chunks that were never written

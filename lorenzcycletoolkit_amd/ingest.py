@@ -71,7 +71,7 @@ def prepare_streamed(args, varlist: str = "inputs/namelist", app_logger=None, ch
     if not (getattr(args, "fixed", False) or getattr(args, "track", False)):
         raise NotImplementedError("the device ingest serves the fixed (-f) and the track (-t) frameworks")
     df = ds.read_namelist(varlist, app_logger)
-    raw = ds.open_raw(args.infile, df)
+    raw = ds.open_raw(args.infile, df, mpas=bool(getattr(args, "mpas", False)), app_logger=app_logger)
     return StreamedDataset(raw, make_plan(raw, args, app_logger), chunk_steps, getattr(args, "inflate", None) or "auto")
 
 

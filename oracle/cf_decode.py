@@ -131,7 +131,14 @@ def prepare(path: str, names: Dict[str, str], fixed_limits=None, track: Optional
     ``fixed_limits``: (west, east, south, north) -> the fixed framework's nearest-point crop (select_area.py:272-295);
     ``track``: (times datetime64, lats, lons) -> track-time selection (preprocessing.py:273) and the track-extent crop
     (select_area.py:297-313).  Returns the arrays BoxData would see, geopotential already in m2 s-2."""
-    var, dims, attrs = open_classic(path)
+    return prepare_opened(open_classic(path), names, fixed_limits, track, geo_is_height, max_width, max_length)
+
+
+def prepare_opened(opened, names: Dict[str, str], fixed_limits=None, track=None, geo_is_height: bool = False, max_width=15,
+                   max_length=15) -> o.Domain:
+    """``prepare`` on an already opened data set ``(decoded variables, dimensions, attributes)`` -- what ``xr.open_dataset`` presents,
+    whatever container it came from (tests build the triple of a NetCDF-4 fixture from the arrays its writer wrote)."""
+    var, dims, attrs = opened
     want = (names["time"], names["level"], names["lat"], names["lon"])
     f = {r: np.transpose(var[names[r]], [dims[names[r]].index(d) for d in want]) for r in ("tair", "u", "v", "omega", "geo")}
     lat, lon, lev, time = var[names["lat"]], var[names["lon"]], var[names["level"]], var[names["time"]]

@@ -222,3 +222,52 @@ def test_deflated_netcdf4_file_through_the_cli(workdir):
         _fresh(results)
         _run([src, "-r", flag, "--device-ingest", "--gpus", "2"])
         _same_tree(one, _tree(results), f"{name}: --device-ingest on 2 ranks")
+
+
+def test_cds_new_layout_through_the_cli(workdir):
+    """The layout the Copernicus CDS delivers today (tests/golden/hdf5/cds_new_layout.nc: `valid_time` int64 seconds since 1970,
+    `pressure_level` float64 hPa descending, scalar `number`, per-time string `expver`, float32 + shuffle + deflate, NaN _FillValue) with
+    the reference's own preset inputs/namelist_ERA5-copernicus-new: host-prepared resident run, `--device-ingest` (chunks inflated on
+    the GPU) and the same on two ranks write the same bytes, for the fixed box and for a track; the fixed-box numbers agree with the
+    oracle on the oracle's preparation of the arrays the fixture's writer wrote (not of what the package's reader read)."""
+    src = os.path.join(ROOT, "tests", "golden", "hdf5", "cds_new_layout.nc")
+    shutil.copy(os.path.join(ROOT, "inputs", "namelist_ERA5-copernicus-new"), workdir / "inputs" / "namelist")
+    (workdir / "inputs" / "box_limits").write_text("min_lon;-60\nmax_lon;30\nmin_lat;-40\nmax_lat;30\n")
+    (workdir / "inputs" / "track").write_text(
+        "time;Lat;Lon;width;length\n" + "".join(f"2020-01-01-{t:02d}00;{-10 + 5 * t};{-30 + 10 * t};60;50\n" for t in range(5)))
+    for flag, name in (("-f", "fixed"), ("-t", "track")):
+        results = workdir / "LEC_Results" / f"cds_new_layout_{name}"
+        _fresh(results)
+        _run([src, "-r", flag])
+        one = _tree(results)
+        df = pd.read_csv(results / f"cds_new_layout_{name}_results.csv", index_col=0)
+        assert len(df) == (6 if name == "fixed" else 5) and np.isfinite(df[["Az", "Ae", "Kz", "Ke", "Cz", "Ca", "Ck", "Ce"]].values).all()
+        assert str(df.index[1]) == "2020-01-01 01:00:00"
+        if name == "fixed":
+            assert "NaN level values" in open(results / "log.cds_new_layout").read()      # v's 1000-hPa level is NaN at step 1: dropped for every step
+            fixed = df
+        _fresh(results)
+        _run([src, "-r", flag, "--device-ingest"])
+        _same_tree(one, _tree(results), f"{name}: --device-ingest")
+        assert "inflate device" in open(results / "log.cds_new_layout").read()
+        _fresh(results)
+        _run([src, "-r", flag, "--device-ingest", "--gpus", "2"])
+        _same_tree(one, _tree(results), f"{name}: --device-ingest on 2 ranks")
+        _fresh(results)
+        _run([src, "-r", flag, "--gpus", "2", "-m"])              # --mpas: nothing on `standard_height` here, same files
+        _same_tree(one, _tree(results), f"{name}: resident on 2 ranks with --mpas")
+    from oracle import cf_decode as cf
+    from oracle import lec_oracle as o
+    from tests.helpers import as_f64
+    from tests.test_hdf5_cpu import _cds_expected
+    lev, lat, lon, f = _cds_expected()
+    var = dict(f, valid_time=cf.decode_cf_time(1577836800 + 3600 * np.arange(6, dtype=np.int64), "seconds since 1970-01-01"),
+               pressure_level=lev[:6].astype(np.float64), latitude=lat, longitude=lon)
+    dims = {k: ("valid_time", "pressure_level", "latitude", "longitude") for k in f}
+    names = {"tair": "t", "u": "u", "v": "v", "omega": "w", "geo": "z", "lat": "latitude", "lon": "longitude", "level": "pressure_level",
+             "time": "valid_time"}
+    dom = as_f64(cf.prepare_opened((var, dims, {"pressure_level": {"units": "hPa"}}), names, fixed_limits=(-60.0, 30.0, -40.0, 30.0)))
+    ref, _ = o.lec_fixed(dom, -60.0, 30.0, -40.0, 30.0)
+    for c in ("Az", "Ae", "Kz", "Ke", "Cz", "Ca", "Ck", "Ce", "BAz", "BAe", "BKz", "BKe", "Gz", "Ge"):
+        r = np.asarray(ref[c], dtype=np.float64)
+        assert np.array_equal(np.isnan(fixed[c].values), np.isnan(r)) and np.nanmax(np.abs(fixed[c].values - r)) <= 1e-9 * np.nanmax(np.abs(r)), c

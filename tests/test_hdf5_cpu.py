@@ -196,3 +196,99 @@ def test_read_step_inflates_only_the_levels_asked_for(name):
     with pytest.raises(IndexError):
         v.read_step(0, [99])
     f.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The layout the Copernicus CDS delivers today (VERDICT r3 "missing" 2): the reference's inputs/namelist_ERA5-copernicus-new
+# ---------------------------------------------------------------------------------------------------------------------------
+CDS_NEW = os.path.join(FIX, "cds_new_layout.nc")
+
+
+def _cds_expected():
+    gen = _generator()
+    lev, lat, lon, f = gen["fields"](6, 6, 13, 24)
+    lon = -90.0 + 7.5 * np.arange(24)
+    f = {k: a.astype(np.float32) for k, a in f.items()}
+    f["v"][1, 0, :, :] = np.nan
+    f["w"][3, 2, 4, 5] = np.nan
+    return lev, lat, lon, f
+
+
+def test_cds_new_layout_reader():
+    """valid_time int64 seconds since 1970, pressure_level float64 hPa DESCENDING, float64 latitude / longitude, a scalar `number`, a
+    per-time variable-length STRING `expver` (not a numeric array: reported in `skipped`, never handed out), float32 + shuffle + deflate
+    fields with a NaN _FillValue -- every array and attribute as written."""
+    lev, lat, lon, f = _cds_expected()
+    h = hdf5_lite.H5File(CDS_NEW)
+    assert h.skipped == {"expver": "vlen_str"} and "expver" not in h.variables
+    assert h.variables["number"].shape == () and int(h.variables["number"].read()) == 0
+    vt = h.variables["valid_time"]
+    assert vt.read().dtype == np.int64 and vt.read().tolist() == [1577836800 + 3600 * i for i in range(6)]
+    assert vt.attrs["units"] == "seconds since 1970-01-01" and vt.attrs["calendar"] == "proleptic_gregorian"
+    pl = h.variables["pressure_level"]
+    assert pl.read().dtype == np.float64 and pl.read().tolist() == [1000.0, 850.0, 700.0, 500.0, 300.0, 200.0] and pl.attrs["units"] == "hPa"
+    assert np.array_equal(h.variables["latitude"].read(), lat) and np.array_equal(h.variables["longitude"].read(), lon)
+    for vn, a in f.items():
+        v = h.variables[vn]
+        assert v.dims == ("valid_time", "pressure_level", "latitude", "longitude") and v.dtype == np.float32
+        assert np.array_equal(v.read(), a, equal_nan=True) and np.isnan(v.attrs["_FillValue"]) and v.attrs["coordinates"] == "number expver"
+    h.close()
+
+
+@pytest.fixture
+def cds_workdir(tmp_path, monkeypatch):
+    import shutil
+    os.makedirs(tmp_path / "inputs")
+    shutil.copy(os.path.join(ROOT, "inputs", "namelist_ERA5-copernicus-new"), tmp_path / "inputs" / "namelist")     # the reference's own preset
+    (tmp_path / "inputs" / "box_limits").write_text("min_lon;-60\nmax_lon;30\nmin_lat;-40\nmax_lat;30\n")
+    monkeypatch.chdir(tmp_path)
+    return tmp_path
+
+
+def test_cds_new_layout_prepare_data(cds_workdir):
+    """prepare_data with the reference's namelist_ERA5-copernicus-new: int64 seconds decoded, levels to Pa and ascending, latitudes
+    S -> N, `number` / `expver` never enter (preprocessing.py:291-296), NaN fill values stay NaN, float32 cubes; the oracle's own
+    preparation of the file gives the same arrays; so does the device-ingest plan."""
+    lev, lat, lon, f = _cds_expected()
+    args = argparse.Namespace(infile=CDS_NEW, fixed=True, track=False, trackfile=None, cdsapi=False, mpas=False)
+    data = ds.prepare_data(args, "inputs/namelist")
+    assert data.level.tolist() == [20000.0, 30000.0, 50000.0, 70000.0, 85000.0, 100000.0]
+    assert data.time[0] == np.datetime64("2020-01-01T00:00:00") and data.time[1] - data.time[0] == np.timedelta64(1, "h") and len(data.time) == 6
+    assert data.lon[0] == -60.0 and data.lon[-1] == 30.0 and data.lat[0] == -40.0 and data.lat[-1] == 30.0 and np.all(np.diff(data.lat) > 0)
+    jj = [int(np.argmin(np.abs(lat - y))) for y in data.lat]
+    ii = [int(np.argmin(np.abs(lon - x))) for x in data.lon]
+    for vn, a in f.items():
+        want = a[:, ::-1][:, :, jj][:, :, :, ii]
+        assert data.variables[vn].dtype == np.float32 and np.array_equal(data.variables[vn], want, equal_nan=True), vn
+    assert np.isnan(data.variables["v"][1, -1]).all() and np.isnan(data.variables["w"]).sum() == 1
+    df = ds.read_namelist("inputs/namelist")
+    raw = ds.open_raw(CDS_NEW, df)
+    plan = ingest.make_plan(raw, args)
+    from tests.test_ingest_cpu import _emulate_lec_ingest
+    for vn, var in raw.variables.items():
+        assert np.array_equal(_emulate_lec_ingest(var, plan), data.variables[vn], equal_nan=True), vn
+    raw.close()
+
+
+def test_mpas_flag_drops_the_standard_height_variables(cds_workdir):
+    """-m / --mpas: variables on the MPAS-BR `standard_height` dimension are dropped before the namelist is matched
+    (preprocessing.py:367-368: `data.drop_dims("standard_height")`); isobaric variables are untouched, and a namelist that names a
+    dropped variable fails with the KeyError the reference's later lookup raises."""
+    import logging
+    df = ds.read_namelist("inputs/namelist")
+    nc = ds._Container(CDS_NEW, mmap=False)
+    nc.variables["t_isobaric_on_height"] = ds._NcVar(np.zeros((6, 3, 13, 24), np.float32),
+                                                     ("valid_time", "standard_height", "latitude", "longitude"), lambda n: None)
+    log = logging.getLogger("mpas-test")
+    records = []
+    log.addHandler(type("H", (logging.Handler,), {"emit": lambda self, r: records.append(r.getMessage())})())
+    log.setLevel(logging.INFO)
+    ds._drop_mpas_dims(nc, CDS_NEW, log)
+    assert "t_isobaric_on_height" not in nc.variables and "t" in nc.variables and "t_isobaric_on_height" in records[-1]
+    nc.close()
+    # through the public path: nothing on that dimension in this file -> same data with and without the flag
+    args = argparse.Namespace(infile=CDS_NEW, fixed=True, track=False, trackfile=None, cdsapi=False, mpas=True)
+    a = ds.prepare_data(args, "inputs/namelist", log)
+    args.mpas = False
+    b = ds.prepare_data(args, "inputs/namelist")
+    assert all(np.array_equal(a.variables[k], b.variables[k], equal_nan=True) for k in b.variables) and any("no variable uses it" in r for r in records)

@@ -147,8 +147,66 @@ def write_sparse(path):
         h.create_dataset("c", c.shape, dtype=np.float32, chunks=c.shape)
 
 
+def write_cds_new(path, nt=6, nl=6, ny=13, nx=24):
+    """The layout the Copernicus CDS delivers since its 2024 relaunch (the reference's inputs/namelist_ERA5-copernicus-new:1-10):
+    ``valid_time`` int64 "seconds since 1970-01-01", ``pressure_level`` float64 in hPa, DESCENDING, latitude / longitude float64, a
+    scalar int64 ``number`` and a per-time variable-length STRING ``expver`` coordinate (both dropped by the reference,
+    src/utils/preprocessing.py:291-296), float32 fields with shuffle + deflate, a NaN ``_FillValue``, GRIB_* attributes and a
+    ``coordinates`` attribute.  The fields are those of fields() (same seed) rounded to float32; v carries a NaN level at step 1."""
+    lev, lat, lon, f = fields(nt, nl, ny, nx)
+    lon = -90.0 + 7.5 * np.arange(nx)          # an "area" request: -180..180 convention
+    with h5py.File(path, "w", libver=("earliest", "v110")) as h:
+        h.attrs["GRIB_centre"] = np.string_("ecmf")
+        h.attrs["Conventions"] = np.string_("CF-1.7")
+        h.attrs["institution"] = "European Centre for Medium-Range Weather Forecasts"
+        d = h.create_dataset("number", data=np.int64(0))
+        d.attrs["long_name"] = "ensemble member numerical id"
+        d.attrs["units"] = "1"
+        d.attrs["standard_name"] = "realization"
+        vt = h.create_dataset("valid_time", data=(1577836800 + 3600 * np.arange(nt)).astype(np.int64))      # 2020-01-01 00:00 UTC, hourly
+        vt.make_scale("valid_time")
+        vt.attrs["long_name"] = "time"
+        vt.attrs["standard_name"] = "time"
+        vt.attrs["units"] = "seconds since 1970-01-01"
+        vt.attrs["calendar"] = "proleptic_gregorian"
+        pl = h.create_dataset("pressure_level", data=lev[:nl].astype(np.float64))        # 1000 ... 200 (5): descending
+        pl.make_scale("pressure_level")
+        pl.attrs["long_name"] = "pressure"
+        pl.attrs["units"] = "hPa"
+        pl.attrs["positive"] = "down"
+        pl.attrs["stored_direction"] = "decreasing"
+        pl.attrs["standard_name"] = "air_pressure"
+        la = h.create_dataset("latitude", data=lat.astype(np.float64))
+        la.make_scale("latitude")
+        la.attrs["units"] = "degrees_north"
+        la.attrs["stored_direction"] = "decreasing"
+        lo = h.create_dataset("longitude", data=lon.astype(np.float64))
+        lo.make_scale("longitude")
+        lo.attrs["units"] = "degrees_east"
+        ev = h.create_dataset("expver", data=np.array(["0001"] * (nt - 2) + ["0005"] * 2, dtype=object), dtype=h5py.string_dtype())
+        ev.dims[0].attach_scale(vt)
+        for name, a in f.items():
+            a = a.astype(np.float32)
+            if name == "v":
+                a[1, 0, :, :] = np.nan
+            if name == "w":
+                a[3, 2, 4, 5] = np.nan              # an interior point: _handle_nans repairs the level
+            d = h.create_dataset(name, data=a, chunks=(1, 1, ny, nx), shuffle=True, compression="gzip", compression_opts=1,
+                                 fillvalue=np.float32(np.nan))
+            d.attrs["_FillValue"] = np.float32(np.nan)
+            d.attrs["GRIB_paramId"] = np.int64(130)
+            d.attrs["GRIB_dataType"] = "an"
+            d.attrs["GRIB_missingValue"] = np.float64(3.4028234663852886e+38)
+            d.attrs["units"] = "K"
+            d.attrs["long_name"] = "field " + name
+            d.attrs["coordinates"] = "number expver"
+            for i, dn in enumerate(("valid_time", "pressure_level", "latitude", "longitude")):
+                d.dims[i].attach_scale(h[dn])
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    write_cds_new(os.path.join(OUT, "cds_new_layout.nc"))
     write_sparse(os.path.join(OUT, "sparse_latest.h5"))
     write(os.path.join(OUT, "packed_chunked_earliest.nc"), "earliest", False, True, True, False, False)
     write(os.path.join(OUT, "packed_chunked_tracked.nc"), ("earliest", "v110"), True, True, True, True, True)
