@@ -44,7 +44,9 @@
 extern "C" {
 #endif
 
-#define LEC_ABI_VERSION 7
+/* ABI 8 (round 4): lec_reduce_args.stage (the two halves of stage 2 run apart; no 65535-step limit), lec_inflate_args.dst_bytes and
+ * lec_chunk_scatter_args.src_bytes (the destination / payload ranges of every descriptor are bounds-checked on the device). */
+#define LEC_ABI_VERSION 8
 
 /* number of fp64 values per (time, level, lat) row record written by lec_rowstats */
 #define LEC_NSTAT 32
@@ -154,11 +156,20 @@ typedef struct lec_rowstats_args {
 
 /*
  * Stage 2: (level x lat) math on the row records -> per-time scalars and per-level tables.
- * Limits: nl <= 160 levels (LEC_ERR_UNSUPPORTED beyond), t_count <= 65535 time steps per call (split longer
- * series into several calls; with drop_any_time use lec_dropmask per call, merge, then mode 2).
+ * Limits: nl <= 160 levels (LEC_ERR_UNSUPPORTED beyond); nl * t_count < 2^31 (ABI 8: the 65535-step limit of a call is gone).
+ *
+ * The call has two halves that may also be run apart (`stage`, ABI 8), for series whose row records are not held whole:
+ *   LEC_STAGE_LEVELS    rows_d -> levraw_d : the level x latitude work of the call's time steps; needs rows_d, box / lat / lev tables,
+ *                       am_d, levraw_d -- 6.8 MB of row records per 37 x 721 time step become 12 KB, so a streamed series runs
+ *                       this half chunk by chunk into ONE levraw buffer of the whole series and recycles the row records;
+ *   LEC_STAGE_VERTICAL  levraw_d -> dropmask / scalars / levels / nanflag over t_count steps of levraw records (rows_d, box_d, am_d and
+ *                       lattab2_d are not read and may be NULL; boxtab2_d is: the per-box constants c1, c2).
+ * LEC_STAGE_BOTH (0) is the whole call.  Either way every number is the same: the halves are the same kernels.
  */
 #define LEC_MAX_LEVELS 160
-#define LEC_MAX_STEPS_PER_REDUCE 65535
+#define LEC_STAGE_BOTH 0
+#define LEC_STAGE_LEVELS 1
+#define LEC_STAGE_VERTICAL 2
 typedef struct lec_reduce_args {
     const double* rows_d;       /* [t_count][nl][nyb_max][LEC_NSTAT] from lec_rowstats; 16-byte aligned */
     int32_t t_count, nl;
@@ -175,7 +186,7 @@ typedef struct lec_reduce_args {
                                    1: any-time over the time steps of this call (mask computed by the call);
                                    2: any-time with the mask in dropmask_d taken as given: the caller ran lec_dropmask on every
                                       shard / chunk of the series and merged the masks (element-wise max) */
-    int32_t reserved0;
+    int32_t stage;              /* LEC_STAGE_BOTH (0), LEC_STAGE_LEVELS, LEC_STAGE_VERTICAL (see above) */
     int32_t* dropmask_d;        /* [LEC_NLEVFUN][nl] (needed when drop_any_time): workspace zeroed by the call (mode 1), input (mode 2) */
     double* am_d;               /* workspace [t_count][nl][8]  area means (always required; left untouched when nyb_max <= 64) */
     double* levraw_d;           /* workspace [t_count][nl][LEC_NLEVRAW] */
@@ -261,7 +272,8 @@ int lec_ingest(const lec_ingest_args* args);
 int lec_reduce(const lec_reduce_args* args);
 
 /* The any-time NaN-level mask of the time steps in `args` alone -> dropmask_d (zeroed first; non-zero = drop).
- * Uses am_d / levraw_d as workspace; scalars_d, levels_d, nanflag_d are not touched and may be NULL.
+ * Uses am_d / levraw_d as workspace (stage LEC_STAGE_VERTICAL: reads levraw_d as given); scalars_d, levels_d, nanflag_d are not
+ * touched and may be NULL.
  * For series processed in shards or chunks: merge the masks, then call lec_reduce with drop_any_time = 2. */
 int lec_dropmask(const lec_reduce_args* args);
 
@@ -328,6 +340,8 @@ typedef struct lec_inflate_args {
     void* dst_d;
     int32_t* status_d;          /* [n_streams][4] */
     void* stream;
+    int64_t dst_bytes;          /* size of the dst_d allocation (ABI 8): a descriptor whose output offset is negative, not a multiple of 16, or
+                                   whose output does not end inside dst_d gets the status "size" and nothing of it is written */
 } lec_inflate_args;
 
 typedef struct lec_chunk_scatter_args {
@@ -341,6 +355,7 @@ typedef struct lec_chunk_scatter_args {
     int32_t nt, nl, ny, nx;
     void* out_d;
     void* stream;
+    int64_t src_bytes;          /* size of the src_d allocation (ABI 8): a chunk whose payload does not lie inside it is skipped */
 } lec_chunk_scatter_args;
 
 int lec_inflate(const lec_inflate_args* args);

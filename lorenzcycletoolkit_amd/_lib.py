@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # LEC_LIB: alternative build of the same ABI (kernel experiments only)
 LIB_PATH = os.environ.get("LEC_LIB") or os.path.join(_HERE, "liblec_hip.so")
 
-LEC_ABI_VERSION = 7
+LEC_ABI_VERSION = 8
 LEC_NSTAT = 32
 LEC_NLEVRAW = 40
 LEC_NSCALAR = 16
@@ -77,7 +77,7 @@ class ReduceArgs(C.Structure):
         ("t_count", C.c_int32), ("nl", C.c_int32), ("n_box", C.c_int32), ("nyb_max", C.c_int32),
         ("box_d", C.c_void_p), ("boxtab2_d", C.c_void_p), ("lattab2_d", C.c_void_p), ("levtab2_d", C.c_void_p),
         ("phi_scale", C.c_double),
-        ("drop_any_time", C.c_int32), ("reserved0", C.c_int32), ("dropmask_d", C.c_void_p),
+        ("drop_any_time", C.c_int32), ("stage", C.c_int32), ("dropmask_d", C.c_void_p),
         ("am_d", C.c_void_p), ("levraw_d", C.c_void_p), ("scalars_d", C.c_void_p), ("levels_d", C.c_void_p),
         ("nanflag_d", C.c_void_p), ("stream", C.c_void_p),
         ("scalars_stride", C.c_int64), ("levels_stride", C.c_int64),
@@ -113,7 +113,7 @@ class DiagArgs(C.Structure):
 class InflateArgs(C.Structure):
     """struct lec_inflate_args (include/lec_hip.h)."""
     _fields_ = [("src_d", C.c_void_p), ("src_bytes", C.c_int64), ("desc_d", C.c_void_p), ("n_streams", C.c_int32), ("flags", C.c_int32),
-                ("dst_d", C.c_void_p), ("status_d", C.c_void_p), ("stream", C.c_void_p)]
+                ("dst_d", C.c_void_p), ("status_d", C.c_void_p), ("stream", C.c_void_p), ("dst_bytes", C.c_int64)]
 
 
 class ChunkScatterArgs(C.Structure):
@@ -124,8 +124,10 @@ class ChunkScatterArgs(C.Structure):
                 ("t_base", C.c_int32), ("n_tmap", C.c_int32), ("n_kmap", C.c_int32), ("j0", C.c_int32),
                 ("tmap_d", C.c_void_p), ("kmap_d", C.c_void_p),
                 ("nt", C.c_int32), ("nl", C.c_int32), ("ny", C.c_int32), ("nx", C.c_int32),
-                ("out_d", C.c_void_p), ("stream", C.c_void_p)]
+                ("out_d", C.c_void_p), ("stream", C.c_void_p), ("src_bytes", C.c_int64)]
 
+
+STAGE_BOTH, STAGE_LEVELS, STAGE_VERTICAL = 0, 1, 2      # lec_reduce_args.stage
 
 _lib = None
 

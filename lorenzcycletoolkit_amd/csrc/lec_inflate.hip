@@ -16,11 +16,18 @@
 //
 // Output goes through an 8 KiB ring in LDS (the recent history LZ77 matches mostly refer to) and is flushed to HBM in 16-byte
 // pieces; a match that reaches further back than the ring reads the flushed bytes from HBM (a fence orders the wave's own earlier
-// stores, taken lazily -- only when such a match occurs).  12.6 KiB of LDS and ~70 VGPRs per wave: 12 waves per CU, 3072 streams
-// in flight.  Measured (profiles/r03_notes.md 2b): 31 GB/s of decoded data on noisy int16 fields, 93 GB/s on smooth ones; the
-// kernel is bound by the latency of its ~150 dependent instructions per round, not by memory.
+// stores, taken lazily -- only when such a match occurs).  12.6 KiB of LDS and ~90 VGPRs per wave (89 / 92 in the two
+// instantiations): 12 waves per CU, 3072 streams in flight; the 4 KiB-ring instantiation (flags bit 1) 8.5 KiB and 18 waves per CU.
+// Measured (profiles/r03_notes.md 2b, ERA5-like 361 x 720 int16 chunks, shuffle + deflate 4, >= 6000 streams in flight): 40-44 GB/s of
+// decoded data on noisy fields (ratio 1.3), 119-126 GB/s on smooth ones (ratio 1.8); the kernel is bound by instruction issue
+// (10.8 scalar + 8.1 vector instructions per decoded byte on noisy fields; half of a round is its ~3 matches), not by memory.
 //
-// Every loop is bounded by the stream's bit length / the output size; malformed input ends with a status code, never a hang.
+// Every loop is bounded by the stream's bit length / the output size, and every descriptor is checked on the device before its
+// stream is touched (source AND destination ranges against the sizes of the two allocations, ABI 8): malformed input ends with a
+// status code, never a hang or an out-of-bounds access.
+// The kernel contains no FLAT memory instruction (tests/test_build_cpu.py checks the ISA): LDS traffic is DS, HBM traffic is
+// GLOBAL.  A FLAT access that resolves to LDS is not ordered with the wave's DS operations by wave_sync() (a wavefront-scope fence
+// emits no s_waitcnt), which is how round 3's timing builds came to read stale ring bytes in the far-match form.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -198,26 +205,35 @@ __device__ int build_code(const uint8_t* lens, int n, uint16_t* table, int bits,
 struct InflateParams {
     const uint8_t* src; long long src_bytes;
     const long long* desc; int n; int flags;
-    uint8_t* dst; int* status;
+    uint8_t* dst; long long dst_bytes; int* status;
 };
 
 // HDF5's Fletcher-32 (H5_checksum_fletcher32: 16-bit big-endian words, sums folded with end-around carry) of `len` bytes, by one wave.
 // With S1 = sum w_i and S2 = sum (n - i) w_i exact in 64 bits, the folded sums are ((x - 1) mod 65535) + 1 for x > 0.
 __device__ uint32_t fletcher32_wave(const uint8_t* p, long long len, int lane) {
     const long long n = (len + 1) / 2;                           // an odd last byte counts as (byte << 8)
+    // S1 = sum w_i and S2 = sum (n - i) w_i modulo 65535, weights reduced and the partial sums folded every 65536 words per lane (terms
+    // below 2^32: no 64-bit wrap-around however large the chunk, as hdf5_lite._fletcher32 folds on the host); a sum that is a
+    // multiple of 65535 folds to 65535 unless every word was zero
     unsigned long long s1 = 0, s2 = 0;
-    for (long long i = lane; i < n; i += 64) {
+    bool nz = false;
+    long long it = 0;
+    for (long long i = lane; i < n; i += 64, ++it) {
         const uint32_t hi = p[2 * i], lo = (2 * i + 1 < len) ? p[2 * i + 1] : 0u;
         const unsigned long long w = (hi << 8) | lo;
+        nz = nz || (w != 0);
         s1 += w;
-        s2 += (unsigned long long)(n - i) * w;
+        s2 += (unsigned long long)((n - i) % 65535ll) * w;
+        if ((it & 0xffff) == 0xffff) { s1 %= 65535ull; s2 %= 65535ull; }
     }
+    nz = __ballot(nz) != 0;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
         s1 += ((unsigned long long)__shfl_xor((unsigned)(s1 >> 32), off) << 32) | __shfl_xor((unsigned)s1, off);
         s2 += ((unsigned long long)__shfl_xor((unsigned)(s2 >> 32), off) << 32) | __shfl_xor((unsigned)s2, off);
     }
-    const uint32_t f1 = s1 ? (uint32_t)((s1 - 1) % 65535ull) + 1u : 0u, f2 = s2 ? (uint32_t)((s2 - 1) % 65535ull) + 1u : 0u;
+    const uint32_t r1 = (uint32_t)(s1 % 65535ull), r2 = (uint32_t)(s2 % 65535ull);
+    const uint32_t f1 = nz ? (r1 ? r1 : 65535u) : 0u, f2 = nz ? (r2 ? r2 : 65535u) : 0u;
     return (f2 << 16) | f1;
 }
 
@@ -242,9 +258,11 @@ __global__ void __launch_bounds__(64) LEC_INFLATE_OCC lec_inflate_kernel(const I
     uint8_t* const out = P.dst + dst_off;
     {
         // bit positions and output positions are 32-bit here: a stream of up to 256 MiB, an output of up to 2 GiB (an HDF5 chunk is < 4 GiB
-        // by format, a sensible one a few MiB); and the stream must lie inside the source buffer
+        // by format, a sensible one a few MiB); the stream must lie inside the source buffer and its output, at a multiple of 16,
+        // inside the destination buffer (the flush stores 16 bytes at a time)
         const long long n = src_len < 0 ? -src_len : src_len;
-        if (n >= (1ll << 28) || dst_len < 0 || dst_len >= (1ll << 31) || src_off < 0 || src_off + n + ((P.flags & 1) ? 4 : 0) > P.src_bytes) {
+        if (n >= (1ll << 28) || dst_len < 0 || dst_len >= (1ll << 31) || src_off < 0 || src_off + n + ((P.flags & 1) ? 4 : 0) > P.src_bytes ||
+            dst_off < 0 || (dst_off & 15) || dst_off + dst_len > P.dst_bytes) {
             if (lane == 0) { P.status[4 * s + 0] = ST_SIZE; P.status[4 * s + 1] = 0; P.status[4 * s + 2] = 0; P.status[4 * s + 3] = 0; }
             return;
         }
@@ -628,11 +646,16 @@ __global__ void __launch_bounds__(64) LEC_INFLATE_OCC lec_inflate_kernel(const I
                     }
                 } else {
                     // (a source behind the ring lies more than kRing - kCap - 64 > 258 bytes back: it cannot overlap its output)
+                    // BOTH loads are unconditional and the VALUES are selected: a conditional load lets the compiler select the POINTER
+                    // (LDS or global) and read through one FLAT load -- which, when it resolves to LDS, is not ordered with the DS
+                    // writes that filled the ring a moment ago (wave_sync() emits no s_waitcnt).  The global address is clamped into
+                    // the flushed part; what the other load reads where it is not selected is in bounds and ignored.
+                    const int glast = safe_lo > 0 ? safe_lo - 1 : 0;
                     for (uint32_t k = (uint32_t)lane; k < len; k += 64u) {
                         const int sp = from + (int)k;
-                        uint8_t byte = L.ring[(uint32_t)sp & (kRing - 1)];     // (always read: a select between an LDS and a global POINTER
-                        if (sp < safe_lo) byte = out[sp];                      // makes this compiler build a flat pointer it then mis-compiles
-                        L.ring[(p + k) & (kRing - 1)] = byte;                  // when the surrounding code changes, e.g. in the timing builds)
+                        const uint8_t ring_byte = L.ring[(uint32_t)sp & (kRing - 1)];
+                        const uint8_t far_byte = __builtin_nontemporal_load(out + (sp < glast ? sp : glast));
+                        L.ring[(p + k) & (kRing - 1)] = sp < safe_lo ? far_byte : ring_byte;
                     }
                 }
                 wave_sync();
@@ -677,7 +700,7 @@ __global__ void __launch_bounds__(64) LEC_INFLATE_OCC lec_inflate_kernel(const I
 // chunks -> the contiguous raw sub-cube lec_ingest reads (un-shuffle, chunk tiling, edge chunks, level / time selection)
 // ---------------------------------------------------------------------------------------------------------------------
 struct ScatterParams {
-    const uint8_t* src; const long long* chunk; int n_chunks, es, shuffled;
+    const uint8_t* src; long long src_bytes; const long long* chunk; int n_chunks, es, shuffled;
     int ct, ck, cj, ci;
     int t_base, n_tmap; const int* tmap; int n_kmap; const int* kmap; int j0;
     int nt, nl, ny, nx;
@@ -696,6 +719,7 @@ __global__ void __launch_bounds__(256) lec_chunk_scatter_kernel(const ScatterPar
     const int ot = p.tmap[tt], ok = p.kmap[fk], oj = fj - p.j0;
     if (ot < 0 || ot >= p.nt || ok < 0 || ok >= p.nl || oj < 0 || oj >= p.ny) return;
     const long long n_elem = (long long)rows * p.ci;
+    if (ch[0] < 0 || ch[0] + n_elem * ES > p.src_bytes) return;      // a payload that does not lie inside src: skipped (the caller's rows keep what they held)
     const uint8_t* base = p.src + ch[0];
     const long long e0 = (long long)row * p.ci;
     uint8_t* orow = p.out + ((((long long)ot * p.nl + ok) * p.ny + oj) * p.nx) * ES;
@@ -746,12 +770,12 @@ const char* status_text(int code) {
 extern "C" int lec_inflate(const lec_inflate_args* a) {
     if (!a) return lec_set_error(LEC_ERR_ARG, "lec_inflate: null args");
     if (!a->src_d || !a->desc_d || !a->dst_d || !a->status_d) return lec_set_error(LEC_ERR_ARG, "lec_inflate: null pointer argument");
-    if (a->n_streams < 1 || a->src_bytes < 8) return lec_set_error(LEC_ERR_ARG, "lec_inflate: n_streams >= 1 and src_bytes >= 8 needed");
+    if (a->n_streams < 1 || a->src_bytes < 8 || a->dst_bytes < 1) return lec_set_error(LEC_ERR_ARG, "lec_inflate: n_streams >= 1, src_bytes >= 8 and dst_bytes >= 1 needed");
     if (a->flags & ~3) return lec_set_error(LEC_ERR_ARG, "lec_inflate: unknown bits in flags");
     if (((uintptr_t)a->src_d & 3u) || ((uintptr_t)a->dst_d & 15u)) return lec_set_error(LEC_ERR_ARG, "lec_inflate: src_d must be 4-byte, dst_d 16-byte aligned");
     InflateParams p;
     p.src = (const uint8_t*)a->src_d; p.src_bytes = a->src_bytes; p.desc = (const long long*)a->desc_d; p.n = a->n_streams; p.flags = a->flags;
-    p.dst = (uint8_t*)a->dst_d; p.status = a->status_d;
+    p.dst = (uint8_t*)a->dst_d; p.dst_bytes = a->dst_bytes; p.status = a->status_d;
     if (a->flags & 2) hipLaunchKernelGGL(lec_inflate_kernel<kRingShort>, dim3((unsigned)a->n_streams), dim3(64), 0, (hipStream_t)a->stream, p);
     else hipLaunchKernelGGL(lec_inflate_kernel<kRingDefault>, dim3((unsigned)a->n_streams), dim3(64), 0, (hipStream_t)a->stream, p);
     const hipError_t e = hipGetLastError();
@@ -767,11 +791,12 @@ extern "C" int lec_chunk_scatter(const lec_chunk_scatter_args* a) {
     if (a->n_chunks < 1 || a->ct < 1 || a->ck < 1 || a->cj < 1 || a->ci < 1 || a->nt < 1 || a->nl < 1 || a->ny < 1 || a->nx < 1 || a->n_tmap < 1 || a->n_kmap < 1)
         return lec_set_error(LEC_ERR_ARG, "lec_chunk_scatter: extents must be >= 1");
     if (a->elem_size != 1 && a->elem_size != 2 && a->elem_size != 4 && a->elem_size != 8) return lec_set_error(LEC_ERR_ARG, "lec_chunk_scatter: elem_size must be 1, 2, 4 or 8");
+    if (a->src_bytes < (long long)a->ct * a->ck * a->cj * a->ci * a->elem_size) return lec_set_error(LEC_ERR_ARG, "lec_chunk_scatter: src_bytes is smaller than one chunk");
     const long long rows = (long long)a->ct * a->ck * a->cj;
     const long long blocks = rows * a->n_chunks;
     if (blocks > 0x7fffffffLL) return lec_set_error(LEC_ERR_UNSUPPORTED, "lec_chunk_scatter: more than 2^31-1 chunk rows in one call");
     ScatterParams p;
-    p.src = (const uint8_t*)a->src_d; p.chunk = (const long long*)a->chunk_d; p.n_chunks = a->n_chunks; p.es = a->elem_size; p.shuffled = a->shuffled;
+    p.src = (const uint8_t*)a->src_d; p.src_bytes = a->src_bytes; p.chunk = (const long long*)a->chunk_d; p.n_chunks = a->n_chunks; p.es = a->elem_size; p.shuffled = a->shuffled;
     p.ct = a->ct; p.ck = a->ck; p.cj = a->cj; p.ci = a->ci;
     p.t_base = a->t_base; p.n_tmap = a->n_tmap; p.tmap = a->tmap_d; p.n_kmap = a->n_kmap; p.kmap = a->kmap_d; p.j0 = a->j0;
     p.nt = a->nt; p.nl = a->nl; p.ny = a->ny; p.nx = a->nx; p.out = (uint8_t*)a->out_d;

@@ -65,10 +65,11 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-// grid (nl, t_count), block 64.  Like lec_level_terms_kernel: the record loads are addressed from the kernel arguments alone (nyb_max
-// rows) and issued before the box height arrives; rows below a lower box are masked out afterwards.
+// grid (nl * t_count) -- level fastest: neighbouring workgroups are neighbouring levels of one time step --, block 64.  Like
+// lec_level_terms_kernel: the record loads are addressed from the kernel arguments alone (nyb_max rows) and issued before the box
+// height arrives; rows below a lower box are masked out afterwards.
 __global__ void __launch_bounds__(64) lec_area_means_kernel(const RedParams p) {
-    const int k = blockIdx.x, tl = blockIdx.y, lane = threadIdx.x;
+    const int tl = blockIdx.x / p.nl, k = blockIdx.x - tl * p.nl, lane = threadIdx.x;
     const int bi = (p.n_box == 1) ? 0 : tl;
     const double* rec = p.rows + (size_t)(tl * p.nl + k) * p.nyb_max * LEC_NSTAT;
     const double* lt = p.lattab2 + (size_t)bi * p.nyb_max * 8;
@@ -115,12 +116,12 @@ __device__ double baz3_repaired(const RedParams& p, const double* am_t, int tl, 
     return slope * (p.levtab2[4 * k] - xl) + yl;
 }
 
-// grid (nl, t_count), block 64.  A wave's life here is a chain of memory round trips (a few hundred arithmetic instructions between
+// grid (nl * t_count), block 64.  A wave's life here is a chain of memory round trips (a few hundred arithmetic instructions between
 // them), so the kernel is arranged to have TWO: every global load -- the level's records, the latitude table, the records of the
 // levels above and below -- is addressed from the kernel arguments alone (the staging covers nyb_max rows; the rows below a lower box
 // are zero records) and issued before anything waits for the area means or the box height.
 __global__ void __launch_bounds__(64) lec_level_terms_kernel(const RedParams p) {
-    const int k = blockIdx.x, tl = blockIdx.y, lane = threadIdx.x;
+    const int tl = blockIdx.x / p.nl, k = blockIdx.x - tl * p.nl, lane = threadIdx.x;
     const int nl = p.nl, nyb_max = p.nyb_max;
     const int bi = (p.n_box == 1) ? 0 : tl;
     const int km = k > 0 ? k - 1 : k, kp = k < nl - 1 ? k + 1 : k;
@@ -302,13 +303,13 @@ struct LaneSums {
     __device__ __forceinline__ Ref operator[](int i) const { return Ref{slot0 + (i - first) * kPartStride, in}; }
 };
 
-// grid (nl, t_count), block 64; requires nyb_max <= 64
+// grid (nl * t_count), block 64; requires nyb_max <= 64
 #ifndef LEC_SMALL_WAVES
 #define LEC_SMALL_WAVES 2       // 193 VGPRs: a cap of 168 (three waves per SIMD) spills and doubles the kernel's time
 #endif
 __global__ void __launch_bounds__(64, LEC_SMALL_WAVES) lec_level_small_kernel(const RedParams p) {
     __shared__ double part[kSmallRound * kPartStride];
-    const int k = blockIdx.x, tl = blockIdx.y, lane = threadIdx.x;
+    const int tl = blockIdx.x / p.nl, k = blockIdx.x - tl * p.nl, lane = threadIdx.x;
     const int nl = p.nl, nyb_max = p.nyb_max;
     const int bi = (p.n_box == 1) ? 0 : tl;
     const int km = k > 0 ? k - 1 : k, kp = k < nl - 1 ? k + 1 : k;
@@ -567,20 +568,24 @@ __global__ void __launch_bounds__(64) lec_vertical_kernel(const RedParams p) {
 
 static int reduce_impl(const lec_reduce_args* a, bool mask_only, const char* who) {
     if (!a) return lec_set_error(LEC_ERR_ARG, "lec_reduce: null args");
-    if (!a->rows_d || !a->box_d || !a->boxtab2_d || !a->lattab2_d || !a->levtab2_d || !a->am_d || !a->levraw_d)
+    if (a->stage < LEC_STAGE_BOTH || a->stage > LEC_STAGE_VERTICAL) return lec_set_error(LEC_ERR_ARG, "lec_reduce / lec_dropmask: stage must be 0 (both), 1 (levels) or 2 (vertical)");
+    const bool levels = a->stage != LEC_STAGE_VERTICAL, vertical = a->stage != LEC_STAGE_LEVELS;
+    if (mask_only && a->stage == LEC_STAGE_LEVELS) return lec_set_error(LEC_ERR_ARG, "lec_dropmask: stage LEC_STAGE_LEVELS forms no mask (use lec_reduce)");
+    if (!a->boxtab2_d || !a->levtab2_d || !a->levraw_d)
         return lec_set_error(LEC_ERR_ARG, "lec_reduce / lec_dropmask: null pointer argument");
-    if (!mask_only && (!a->scalars_d || !a->levels_d || !a->nanflag_d)) return lec_set_error(LEC_ERR_ARG, "lec_reduce: null output pointer");
+    if (levels && (!a->rows_d || !a->box_d || !a->lattab2_d || !a->am_d)) return lec_set_error(LEC_ERR_ARG, "lec_reduce / lec_dropmask: null pointer argument");
+    if (vertical && !mask_only && (!a->scalars_d || !a->levels_d || !a->nanflag_d)) return lec_set_error(LEC_ERR_ARG, "lec_reduce: null output pointer");
     if (a->t_count < 1 || a->nl < 2 || a->nyb_max < 2) return lec_set_error(LEC_ERR_ARG, "lec_reduce: needs t_count>=1, nl>=2, nyb_max>=2");
     if (a->nl > kMaxNl) return lec_set_error(LEC_ERR_UNSUPPORTED, "lec_reduce: more than 160 levels");
-    if (a->t_count > 65535) return lec_set_error(LEC_ERR_UNSUPPORTED, "lec_reduce: more than 65535 time steps in one call");
+    if ((long long)a->t_count * a->nl > 0x7fffffffLL) return lec_set_error(LEC_ERR_UNSUPPORTED, "lec_reduce: nl * t_count must stay below 2^31 in one call");
     if (a->n_box != 1 && a->n_box != a->t_count) return lec_set_error(LEC_ERR_ARG, "lec_reduce: n_box must be 1 or t_count");
     if (a->drop_any_time < 0 || a->drop_any_time > 2) return lec_set_error(LEC_ERR_ARG, "lec_reduce: drop_any_time must be 0, 1 or 2");
-    if ((reinterpret_cast<uintptr_t>(a->rows_d) | reinterpret_cast<uintptr_t>(a->lattab2_d)) & 15)
+    if (levels && ((reinterpret_cast<uintptr_t>(a->rows_d) | reinterpret_cast<uintptr_t>(a->lattab2_d)) & 15))
         return lec_set_error(LEC_ERR_ARG, "lec_reduce / lec_dropmask: rows_d and lattab2_d must be 16-byte aligned");
     if (a->scalars_stride < 0 || a->levels_stride < 0 || (a->scalars_stride && a->scalars_stride < LEC_NSCALAR) ||
         (a->levels_stride && a->levels_stride < (long long)LEC_NLEVTAB * a->nl))
         return lec_set_error(LEC_ERR_ARG, "lec_reduce: scalars_stride / levels_stride must be 0 (dense) or at least one record long");
-    if ((a->drop_any_time || mask_only) && !a->dropmask_d) return lec_set_error(LEC_ERR_ARG, "lec_reduce / lec_dropmask: drop_any_time needs dropmask_d");
+    if (vertical && (a->drop_any_time || mask_only) && !a->dropmask_d) return lec_set_error(LEC_ERR_ARG, "lec_reduce / lec_dropmask: drop_any_time needs dropmask_d");
     (void)who;
     RedParams p;
     p.rows = a->rows_d; p.t_count = a->t_count; p.nl = a->nl; p.n_box = a->n_box; p.nyb_max = a->nyb_max;
@@ -591,18 +596,22 @@ static int reduce_impl(const lec_reduce_args* a, bool mask_only, const char* who
     p.lstride = a->levels_stride ? a->levels_stride : (long long)LEC_NLEVTAB * a->nl;
     p.drop_any_time = (a->drop_any_time || mask_only) ? 1 : 0; p.dropmask = a->dropmask_d;
     hipStream_t st = (hipStream_t)a->stream;
-    const dim3 grid2(a->nl, a->t_count);
-    if (a->nyb_max <= kSmallRows) {
-        hipLaunchKernelGGL(lec_level_small_kernel, grid2, dim3(64), 0, st, p);       // forms its own area means; am_d is not used
-    } else {
-        hipLaunchKernelGGL(lec_area_means_kernel, grid2, dim3(64), 0, st, p);
-        hipLaunchKernelGGL(lec_level_terms_kernel, grid2, dim3(64), 0, st, p);
+    if (levels) {
+        const dim3 grid2((unsigned)a->nl * (unsigned)a->t_count);      // one workgroup per (time step, level), level fastest
+        if (a->nyb_max <= kSmallRows) {
+            hipLaunchKernelGGL(lec_level_small_kernel, grid2, dim3(64), 0, st, p);       // forms its own area means; am_d is not used
+        } else {
+            hipLaunchKernelGGL(lec_area_means_kernel, grid2, dim3(64), 0, st, p);
+            hipLaunchKernelGGL(lec_level_terms_kernel, grid2, dim3(64), 0, st, p);
+        }
     }
-    if (mask_only || a->drop_any_time == 1) {
-        if (hipMemsetAsync(p.dropmask, 0, sizeof(int) * F_COUNT * a->nl, st) != hipSuccess) return lec_set_error(LEC_ERR_LAUNCH, "lec_reduce: hipMemsetAsync failed");
-        hipLaunchKernelGGL(lec_dropmask_kernel, dim3(a->t_count), dim3(64), 0, st, p);
+    if (vertical) {
+        if (mask_only || a->drop_any_time == 1) {
+            if (hipMemsetAsync(p.dropmask, 0, sizeof(int) * F_COUNT * a->nl, st) != hipSuccess) return lec_set_error(LEC_ERR_LAUNCH, "lec_reduce: hipMemsetAsync failed");
+            hipLaunchKernelGGL(lec_dropmask_kernel, dim3(a->t_count), dim3(64), 0, st, p);
+        }
+        if (!mask_only) hipLaunchKernelGGL(lec_vertical_kernel, dim3(a->t_count), dim3(64), 0, st, p);
     }
-    if (!mask_only) hipLaunchKernelGGL(lec_vertical_kernel, dim3(a->t_count), dim3(64), 0, st, p);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return lec_set_error(LEC_ERR_LAUNCH, hipGetErrorString(e));
     return LEC_OK;

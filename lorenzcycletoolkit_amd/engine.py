@@ -98,6 +98,8 @@ class LECEngine:
     device           : torch device of the field tensors (``cuda:N`` on ROCm)
     """
 
+    MAX_STEPS_PER_LAUNCH = 32768       # time steps per lec_rowstats launch (longer calls are cut into parts by `rowstats`)
+
     def __init__(self, lat_deg, lon_deg, level_pa, device="cuda"):
         self.lib = _lib.load()
         self.device = torch.device(device)
@@ -245,6 +247,17 @@ class LECEngine:
             tcoef = self._tcoef[1]
 
         f64 = dict(dtype=torch.float64, device=tair.device)
+        if t_count > self.MAX_STEPS_PER_LAUNCH:
+            # a stage-1 launch addresses its time steps with 16-bit grid coordinates in some kernel families: longer series go out in
+            # parts (same kernels, same bits: results do not depend on how a series is cut)
+            rows = rows_out if rows_out is not None else torch.empty((t_count, nl, bt.nyb_max, _lib.LEC_NSTAT), **f64)
+            whole = PreparedBoxes(boxes, bt, dev)
+            for a in range(0, t_count, self.MAX_STEPS_PER_LAUNCH):
+                b = min(a + self.MAX_STEPS_PER_LAUNCH, t_count)
+                self.rowstats(tair, u, v, omega, geopt, whole.part(a, b) if per_step_boxes else whole, dTdt=dTdt, t_begin=t_begin + a,
+                              t_count=b - a, with_q=with_q, timing=timing, rows_out=rows[a:b], tuning=tuning, per_step_boxes=per_step_boxes,
+                              tcoef=tcoef)
+            return rows
         if rows_out is None:
             rows = torch.empty((t_count, nl, bt.nyb_max, _lib.LEC_NSTAT), **f64)
         else:       # a slice of a longer series' record buffer (chunked ingest): stage 2 runs once over all of it
@@ -295,46 +308,95 @@ class LECEngine:
             raise ValueError("boxes: give one box, or one per processed time step")
         if rows.shape != (t_count, self.level.size, bt.nyb_max, _lib.LEC_NSTAT) or rows.dtype != torch.float64 or not rows.is_contiguous():
             raise ValueError("rows must be a contiguous fp64 [t_count, nl, nyb_max, 32] tensor")
-        f64 = dict(dtype=torch.float64, device=rows.device)
-        # the two workspaces are scratch of this call only (stream-ordered: the next call on the stream may reuse them); the outputs
-        # are fresh tensors, they belong to the caller
-        # keyed by the stream too: two reduce calls of one shape on different streams must not share scratch (or the dropmask)
-        wkey = (t_count, nl, str(rows.device), int(torch.cuda.current_stream(rows.device).cuda_stream))
+        am, levraw, dropmask_ws = self._workspace(t_count, nl, rows.device)
+        res = self._stage2(_lib.STAGE_BOTH, rows, levraw, am, dropmask_ws, boxes, bt, dev, phi_scale, drop_any_time, merge_dropmask, out, nanflag_out)
+        res.rows = rows if keep_rows else None
+        return res
+
+    # -- the two halves of stage 2, for series whose row records are not held whole (ingest.lec_streamed) ---------------------------
+    def level_stage(self, rows: torch.Tensor, boxes, levraw_out: torch.Tensor, *, phi_scale: float = 1.0) -> None:
+        """rows [t_count, nl, nyb_max, 32] -> ``levraw_out`` [t_count, nl, 40] (``lec_reduce`` with stage LEC_STAGE_LEVELS): the level x
+        latitude half of stage 2 for a chunk of a series.  6.8 MB of row records per 37 x 721 time step become 12 KB, so a streamed
+        series keeps ONE levraw buffer for all its steps and recycles the chunk's row records."""
+        t_count, nl = int(rows.shape[0]), int(rows.shape[1])
+        boxes, bt, dev = self._resolve_boxes(boxes, nyb_min=int(rows.shape[2]))
+        if len(boxes) not in (1, t_count):
+            raise ValueError("boxes: give one box, or one per processed time step")
+        if rows.shape != (t_count, self.level.size, bt.nyb_max, _lib.LEC_NSTAT) or rows.dtype != torch.float64 or not rows.is_contiguous():
+            raise ValueError("rows must be a contiguous fp64 [t_count, nl, nyb_max, 32] tensor")
+        if (levraw_out.shape != (t_count, nl, _lib.LEC_NLEVRAW) or levraw_out.dtype != torch.float64 or levraw_out.device != rows.device
+                or not levraw_out.is_contiguous()):
+            raise ValueError("levraw_out must be a contiguous fp64 [t_count, nl, 40] tensor on the rows' device")
+        am = self._workspace(t_count, nl, rows.device, am_only=True)
+        self._stage2(_lib.STAGE_LEVELS, rows, levraw_out, am, None, boxes, bt, dev, phi_scale, False, None, None, None)
+
+    def vertical_stage(self, levraw: torch.Tensor, boxes, *, drop_any_time: Optional[bool] = None,
+                       merge_dropmask: Optional[Callable[[torch.Tensor], None]] = None, out: Optional[torch.Tensor] = None,
+                       nanflag_out: Optional[torch.Tensor] = None) -> LECResult:
+        """levraw [t_count, nl, 40] of a whole series (or shard) -> the packed records (``lec_reduce`` with stage LEC_STAGE_VERTICAL):
+        _handle_nans with the any-time mask over ALL the steps (``drop_any_time`` / ``merge_dropmask`` as in ``reduce``), the pressure
+        integrals and the boundary assembly.  ``boxes``: the series' box(es), for the per-box constants."""
+        t_count, nl = int(levraw.shape[0]), int(levraw.shape[1])
+        boxes, bt, dev = self._resolve_boxes(boxes)
+        if len(boxes) not in (1, t_count):
+            raise ValueError("boxes: give one box, or one per processed time step")
+        if levraw.shape != (t_count, self.level.size, _lib.LEC_NLEVRAW) or levraw.dtype != torch.float64 or not levraw.is_contiguous():
+            raise ValueError("levraw must be a contiguous fp64 [t_count, nl, 40] tensor")
+        dropmask_ws = torch.empty((_lib.LEC_NLEVFUN, nl), dtype=torch.int32, device=levraw.device)
+        return self._stage2(_lib.STAGE_VERTICAL, None, levraw, None, dropmask_ws, boxes, bt, dev, 1.0, drop_any_time, merge_dropmask, out, nanflag_out)
+
+    def _workspace(self, t_count: int, nl: int, device, am_only: bool = False):
+        # the workspaces are scratch of one call only (stream-ordered: the next call on the stream may reuse them); keyed by the
+        # stream too: two calls of one shape on different streams must not share scratch (or the dropmask)
+        f64 = dict(dtype=torch.float64, device=device)
+        wkey = (t_count, nl, str(device), int(torch.cuda.current_stream(device).cuda_stream))
         if wkey not in self._work:
             if len(self._work) > 4:
                 self._work.clear()
             self._work[wkey] = (torch.empty((t_count, nl, 8), **f64), torch.empty((t_count, nl, _lib.LEC_NLEVRAW), **f64),
-                                torch.empty((_lib.LEC_NLEVFUN, nl), dtype=torch.int32, device=rows.device))
-        am, levraw, dropmask_ws = self._work[wkey]
+                                torch.empty((_lib.LEC_NLEVFUN, nl), dtype=torch.int32, device=device))
+        return self._work[wkey][0] if am_only else self._work[wkey]
+
+    def _stage2(self, stage, rows, levraw, am, dropmask_ws, boxes, bt, dev, phi_scale, drop_any_time, merge_dropmask, out, nanflag_out) -> Optional[LECResult]:
+        t_count, nl = int(levraw.shape[0]), int(levraw.shape[1])
+        device = levraw.device
+        f64 = dict(dtype=torch.float64, device=device)
         width = self.packed_width(nl)
-        if out is None:
-            out = torch.empty((t_count, width), **f64)
-        elif (out.shape != (t_count, width) or out.dtype != torch.float64 or out.device != rows.device or out.stride(1) != 1
-              or out.stride(0) < width or out.data_ptr() % 8):
-            raise ValueError(f"out must be an fp64 [t_count, {width}] tensor on the rows' device with contiguous columns")
-        scalars = out[:, :_lib.LEC_NSCALAR]
-        levels = out[:, _lib.LEC_NSCALAR:].unflatten(1, (_lib.LEC_NLEVTAB, nl))
-        if nanflag_out is None:
-            nanflag = torch.empty((t_count,), dtype=torch.int32, device=rows.device)
-        else:
-            nanflag = nanflag_out
-            if nanflag.shape != (t_count,) or nanflag.dtype != torch.int32 or nanflag.device != rows.device or not nanflag.is_contiguous():
-                raise ValueError("nanflag_out must be a contiguous int32 [t_count] tensor on the rows' device")
+        scalars = levels = nanflag = None
+        if stage != _lib.STAGE_LEVELS:
+            if out is None:
+                out = torch.empty((t_count, width), **f64)
+            elif (out.shape != (t_count, width) or out.dtype != torch.float64 or out.device != device or out.stride(1) != 1
+                  or out.stride(0) < width or out.data_ptr() % 8):
+                raise ValueError(f"out must be an fp64 [t_count, {width}] tensor on the rows' device with contiguous columns")
+            scalars = out[:, :_lib.LEC_NSCALAR]
+            levels = out[:, _lib.LEC_NSCALAR:].unflatten(1, (_lib.LEC_NLEVTAB, nl))
+            if nanflag_out is None:
+                nanflag = torch.empty((t_count,), dtype=torch.int32, device=device)
+            else:
+                nanflag = nanflag_out
+                if nanflag.shape != (t_count,) or nanflag.dtype != torch.int32 or nanflag.device != device or not nanflag.is_contiguous():
+                    raise ValueError("nanflag_out must be a contiguous int32 [t_count] tensor on the rows' device")
         if drop_any_time is None:
             drop_any_time = len(boxes) == 1
-        dropmask = dropmask_ws if drop_any_time else None
-        stream = C.c_void_p(torch.cuda.current_stream(rows.device).cuda_stream)
-        mode = 0 if not drop_any_time else (2 if merge_dropmask is not None else 1)
+        dropmask = dropmask_ws if (drop_any_time and stage != _lib.STAGE_LEVELS) else None
+        stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        mode = 0 if dropmask is None else (2 if merge_dropmask is not None else 1)
         rd = _lib.ReduceArgs(
             rows_d=_ptr(rows), t_count=t_count, nl=nl, n_box=len(boxes), nyb_max=bt.nyb_max,
             box_d=_ptr(dev["box"]), boxtab2_d=_ptr(dev["boxtab2"]), lattab2_d=_ptr(dev["lattab2"]),
             levtab2_d=_ptr(self._levtab2), phi_scale=float(phi_scale),
-            drop_any_time=mode, reserved0=0, dropmask_d=_ptr(dropmask),
+            drop_any_time=mode, stage=stage, dropmask_d=_ptr(dropmask),
             am_d=_ptr(am), levraw_d=_ptr(levraw), scalars_d=_ptr(scalars), levels_d=_ptr(levels),
-            nanflag_d=_ptr(nanflag), stream=stream, scalars_stride=int(out.stride(0)), levels_stride=int(out.stride(0)))
-        with torch.cuda.device(rows.device):
+            nanflag_d=_ptr(nanflag), stream=stream, scalars_stride=0 if out is None else int(out.stride(0)),
+            levels_stride=0 if out is None else int(out.stride(0)))
+        with torch.cuda.device(device):
             if mode == 2:
                 _lib.check(self.lib.lec_dropmask(C.byref(rd)), "lec_dropmask")
                 merge_dropmask(dropmask)
+                if stage == _lib.STAGE_BOTH:
+                    rd.stage = _lib.STAGE_VERTICAL          # lec_dropmask has filled levraw: the level half need not run again
             _lib.check(self.lib.lec_reduce(C.byref(rd)), "lec_reduce")
-        return LECResult(scalars=scalars, levels=levels, nanflag=nanflag, rows=rows if keep_rows else None, packed=out)
+        if stage == _lib.STAGE_LEVELS:
+            return None
+        return LECResult(scalars=scalars, levels=levels, nanflag=nanflag, rows=None, packed=out)

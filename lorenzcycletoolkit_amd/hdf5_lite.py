@@ -105,7 +105,13 @@ class H5Variable:
             return None                                    # the usual pipeline order only: shuffle, deflate, fletcher32
         if 2 in ids and self._filters[ids.index(2)][1] and self._filters[ids.index(2)][1][0] != self.dtype.itemsize:
             return None
+        # what lec_inflate takes: stored sizes below 2^28 bytes, chunks below 2^31 (its bit and output positions are 32-bit); an
+        # uncompressed record variable kept as ONE huge chunk per step stays on the host reader
+        if int(np.prod(lay["chunk"], dtype=np.int64)) * self.dtype.itemsize >= (1 << 31):
+            return None
         table = self._file._chunks(self)
+        if any(size >= (1 << 28) for _addr, size, _mask in table.values()):
+            return None
         counts = [-(-s // c) for s, c in zip(self.shape, lay["chunk"])]
         if len(table) != int(np.prod(counts)):
             return None                                    # chunks that were never written read as the fill value: host path

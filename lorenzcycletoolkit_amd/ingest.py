@@ -5,8 +5,8 @@ The reference decodes the whole file with xarray, then copies it four more times
 src/utils/select_area.py:254-338, src/utils/box_data.py:297-310) before any term is computed.  Here the
 memory-mapped file bytes of a chunk of time steps go over PCIe as they are (int16-packed ERA5 data is a
 quarter of its fp64 size), ``lec_ingest`` decodes / sorts / crops / converts them in one gather pass on the
-GPU, ``lec_rowstats`` turns the chunk into row records, and ``lec_reduce`` runs once over the records of
-the whole series.  Chunks are double-buffered: the copy of chunk c+1 (copy stream) overlaps the kernels of
+GPU, ``lec_rowstats`` turns the chunk into row records, the level half of ``lec_reduce`` condenses them at once
+(12 KB per time step: the records live for one chunk), and its vertical half runs once over the whole series.  Chunks are double-buffered: the copy of chunk c+1 (copy stream) overlaps the kernels of
 chunk c (compute stream).  Results are bit-identical to the resident path (``LECEngine.compute`` on the
 host-prepared cubes): stage 1 is per row, and every chunk carries the one-step halo of T that dT/dt needs.
 
@@ -432,14 +432,15 @@ class _ChunkStager:
         with torch.cuda.device(self.device):
             ia = _lib.InflateArgs(src_d=self.comp_dev[slot].data_ptr(), src_bytes=used, desc_d=desc.data_ptr(), n_streams=n,
                                   flags=int(bool(self.info.get("fletcher32"))) | (2 if self.short_window else 0),
-                                  dst_d=self.inflated[slot].data_ptr(), status_d=self.status_dev[slot].data_ptr(), stream=stream)
+                                  dst_d=self.inflated[slot].data_ptr(), status_d=self.status_dev[slot].data_ptr(), stream=stream,
+                                  dst_bytes=self.inflated[slot].numel())
             _lib.check(lib.lec_inflate(C.byref(ia)), "lec_inflate")
             ct, ck, cj, ci = self.chunk
             sa = _lib.ChunkScatterArgs(src_d=self.inflated[slot].data_ptr(), chunk_d=recs.data_ptr(), n_chunks=n, elem_size=self.itemsize,
                                        shuffled=int(self.info["shuffle"]), ct=ct, ck=ck, cj=cj, ci=ci, t_base=t_base, n_tmap=n_tmap,
                                        n_kmap=self.shape[1], j0=self.j0, tmap_d=self.tmap_dev[slot].data_ptr(), kmap_d=self.kmap_dev.data_ptr(),
                                        nt=int(self.raw_dev[slot].shape[0]), nl=len(self.levels), ny=self.j1 - self.j0 + 1, nx=self.nx,
-                                       out_d=self.raw_dev[slot].data_ptr(), stream=stream)
+                                       out_d=self.raw_dev[slot].data_ptr(), stream=stream, src_bytes=self.inflated[slot].numel())
             _lib.check(lib.lec_chunk_scatter(C.byref(sa)), "lec_chunk_scatter")
         self.status_pin[slot][:n].copy_(self.status_dev[slot][:n], non_blocking=True)
         self.fetched[slot].record(torch.cuda.current_stream(self.device))
@@ -625,7 +626,14 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
     bt, _ = engine._box_tables(boxes)            # the row count of the records is the tallest box of the WHOLE series, on every rank
     if per_step_boxes:
         own_boxes = engine.prepare_boxes(own_boxes, nyb_min=bt.nyb_max)
-    rows = torch.empty((t1 - t0, nl, bt.nyb_max, _lib.LEC_NSTAT), dtype=torch.float64, device=dev)
+    else:
+        fixed_box = engine.prepare_boxes(boxes, nyb_min=bt.nyb_max)
+    # Row records live for one chunk only (6.8 MB per 37 x 721 time step: a month of hourly steps would be 5 GB, 30 k steps all of
+    # HBM): every chunk's records go through the level half of stage 2 at once and leave 12 KB per step in `levraw`, which is what
+    # the any-time NaN mask and the pressure integrals of the WHOLE series need at the end (energy_contents.py:190-208).  One buffer,
+    # not one per slot: stage 1 and the level stage of consecutive chunks are on the same stream.
+    rows = torch.empty((chunk_steps, nl, bt.nyb_max, _lib.LEC_NSTAT), dtype=torch.float64, device=dev)
+    levraw = torch.empty((t1 - t0, nl, _lib.LEC_NLEVRAW), dtype=torch.float64, device=dev)
     time_s = plan.time_s
     phi_scale = ds.field_scale(variable_list_df, geo_role)
 
@@ -650,11 +658,13 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
         c0, c1 = bounds[c], bounds[c + 1]
         h0, h1 = (max(c0 - 1, 0), min(c1 + 1, nt)) if with_q else (c0, c1)
         if used[slot]:
-            copied[slot][-1].synchronize()      # the pinned buffers of this slot may be overwritten now (uploads are in stream order)
+            for ev in copied[slot]:             # the pinned buffers of this slot may be overwritten now: EVERY variable's upload has landed
+                ev.synchronize()                # (they ride on different streams when deflated and plain variables mix: ADVICE r3)
             if direct:
                 spans.release(c - slots + 1)    # ... and the file spans only chunks up to c - slots used are no longer being read
         # only T carries the halo; the other fields start at their own first step (rows [c0 - h0, c1 - h0) of the slot)
         span_of = lambda r: (0, h1 - h0) if r == "Air Temperature" else (c0 - h0, c1 - h0)
+        copier_waited = False                   # has the shared copy stream waited for this slot's last decode yet?
         for n, r in enumerate(roles):
             # variable by variable: stage (thread pool), enqueue its upload, decode it -- the copy engine starts after a fifth of the
             # chunk's staging, and the next variable is staged while this one is on the link
@@ -665,8 +675,9 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
             host_s += time.perf_counter() - t_host
             up = stagers[r].streams[slot] if hasattr(stagers[r], "streams") else copier   # a deflated variable uploads and inflates on its own stream
             with torch.cuda.stream(up):
-                if used[slot] and (n == 0 or up is not copier):
+                if used[slot] and (up is not copier or not copier_waited):
                     up.wait_event(consumed[slot])       # the raw device buffers of this slot have been decoded
+                    copier_waited = copier_waited or up is copier
                 if direct:
                     t_host = time.perf_counter()
                     moved += stagers[r].upload_direct(lib, spans, slot, plan.tsel[h0 + a: h0 + b], a, c, C.c_void_p(copier.cuda_stream))
@@ -683,11 +694,14 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
                              decode[r], common, cubes[slot][keys[r]][a].data_ptr(), compute)
         consumed[slot].record(compute)
         f = {k: t[: h1 - h0] for k, t in cubes[slot].items()}
-        engine.rowstats(f["tair"], f["u"], f["v"], f["omega"], f["geopt"], own_boxes.part(c0 - t0, c1 - t0) if per_step_boxes else boxes,
+        part = own_boxes.part(c0 - t0, c1 - t0) if per_step_boxes else fixed_box
+        engine.rowstats(f["tair"], f["u"], f["v"], f["omega"], f["geopt"], part,
                         tcoef=tcoef_all[h0:h1] if with_q else None, t_begin=c0 - h0, t_count=c1 - c0, with_q=with_q,
-                        rows_out=rows[c0 - t0:c1 - t0], per_step_boxes=per_step_boxes)
+                        rows_out=rows[: c1 - c0], per_step_boxes=per_step_boxes)
+        engine.level_stage(rows[: c1 - c0], part, levraw[c0 - t0: c1 - t0], phi_scale=phi_scale)
         used[slot] = True
-    res = engine.reduce(rows, own_boxes, phi_scale=phi_scale, drop_any_time=not per_step_boxes, merge_dropmask=merge_dropmask, out=out)
+    res = engine.vertical_stage(levraw, own_boxes if per_step_boxes else fixed_box, drop_any_time=not per_step_boxes,
+                                merge_dropmask=merge_dropmask, out=out)
     on_device = [r for r in roles if isinstance(stagers[r], _ChunkStager)]
     for r in on_device:
         stagers[r].finish()                     # every chunk inflated (raises otherwise)
@@ -699,6 +713,7 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
     if stats is not None:
         stats.update(staging="registered" if direct else "staged", **(reg_stats if direct else {}))
         stats.update(inflate="device" if on_device else ("host" if any(hasattr(v.data, "chunk_streams") for v in rvars.values()) else "none"))
+        stats.update(row_record_bytes=rows.numel() * 8, levraw_bytes=levraw.numel() * 8)
         stats.update(bytes_moved=moved, host_staging_seconds=host_s, chunks=n_chunks, chunk_steps=chunk_steps, storage=str(out_dtype).replace("torch.", ""),
                      decode={keys[r]: str(d) for r, d in decode.items()}, box=tuple(int(x) for x in boxes[0]), domain=(nt, nl, ny, nx))
     return res

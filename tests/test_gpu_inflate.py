@@ -61,7 +61,7 @@ def inflate(streams, sizes, *, packed=False, plain=(), flags=0):
     dst_d = torch.full((do + 16,), 0xAA, dtype=torch.uint8, device=DEV)
     status_d = torch.full((n, 4), -1, dtype=torch.int32, device=DEV)
     a = _lib.InflateArgs(src_d=src_d.data_ptr(), src_bytes=src.size, desc_d=desc_d.data_ptr(), n_streams=n, flags=flags, dst_d=dst_d.data_ptr(),
-                         status_d=status_d.data_ptr(), stream=C.c_void_p(torch.cuda.current_stream().cuda_stream))
+                         status_d=status_d.data_ptr(), stream=C.c_void_p(torch.cuda.current_stream().cuda_stream), dst_bytes=dst_d.numel())
     _lib.check(lib.lec_inflate(C.byref(a)), "lec_inflate")
     torch.cuda.synchronize()
     out, status = dst_d.cpu().numpy(), status_d.cpu().numpy()
@@ -141,7 +141,7 @@ def test_malformed_streams_end_with_a_status():
     assert st2[0, 0] == 13 and b"adler32" in lib.lec_inflate_status_text(13) and st2[1, 0] == 0 and st2[2, 0] == 0
     # arguments
     st = torch.zeros(4, dtype=torch.int32, device=DEV)
-    a = _lib.InflateArgs(src_d=st.data_ptr(), src_bytes=16, desc_d=st.data_ptr(), n_streams=0, dst_d=st.data_ptr(), status_d=st.data_ptr())
+    a = _lib.InflateArgs(src_d=st.data_ptr(), src_bytes=16, desc_d=st.data_ptr(), n_streams=0, dst_d=st.data_ptr(), status_d=st.data_ptr(), dst_bytes=16)
     assert lib.lec_inflate(C.byref(a)) == 1 and b"n_streams" in lib.lec_last_error()
     a.n_streams, a.dst_d = 1, 0
     assert lib.lec_inflate(C.byref(a)) == 1 and b"null" in lib.lec_last_error()
@@ -181,12 +181,98 @@ def test_chunk_scatter_puts_chunks_in_place(es, shuffled):
     out = torch.full((4, 4, j1 - j0 + 1, 16), sentinel, dtype={1: torch.uint8, 2: torch.int16, 4: torch.int32, 8: torch.int64}[es], device=DEV)
     sa = _lib.ChunkScatterArgs(src_d=src.data_ptr(), chunk_d=recs_d.data_ptr(), n_chunks=len(origins), elem_size=es, shuffled=int(shuffled),
                                ct=2, ck=3, cj=5, ci=7, t_base=0, n_tmap=5, n_kmap=7, j0=j0, tmap_d=tmap_d.data_ptr(), kmap_d=kmap_d.data_ptr(),
-                               nt=4, nl=4, ny=j1 - j0 + 1, nx=16, out_d=out.data_ptr(), stream=C.c_void_p(torch.cuda.current_stream().cuda_stream))
+                               nt=4, nl=4, ny=j1 - j0 + 1, nx=16, out_d=out.data_ptr(), stream=C.c_void_p(torch.cuda.current_stream().cuda_stream),
+                               src_bytes=src.numel())
     _lib.check(lib.lec_chunk_scatter(C.byref(sa)), "lec_chunk_scatter")
     torch.cuda.synchronize()
     got = out.cpu().numpy().view(dt)
     assert (got[0] == sentinel).all()
     for r, t in enumerate(steps):
         assert np.array_equal(got[r + 1], a[t][levels][:, j0: j1 + 1]), (r, t)
+    # malformed chunk records: a payload offset that is negative or runs past src_bytes is skipped on the device -- the
+    # rows it would have filled keep what they held, the other chunks land as before, nothing outside `out` is touched
+    bad = recs_d.clone()
+    bad[0, 0] = -16
+    bad[1, 0] = src.numel() - 8
+    out2 = torch.full_like(out, sentinel)
+    sa.chunk_d, sa.out_d = bad.data_ptr(), out2.data_ptr()
+    _lib.check(lib.lec_chunk_scatter(C.byref(sa)), "lec_chunk_scatter")
+    torch.cuda.synchronize()
+    got2 = out2.cpu().numpy().view(dt)
+    differs = got2 != got
+    assert differs.any() and (got2[differs] == sentinel).all()          # only the two skipped chunks' elements are missing
+    sa.src_bytes = 8
+    assert lib.lec_chunk_scatter(C.byref(sa)) == 1 and b"src_bytes" in lib.lec_last_error()
+    sa.src_bytes = src.numel()
     sa.elem_size = 3
     assert lib.lec_chunk_scatter(C.byref(sa)) == 1 and b"elem_size" in lib.lec_last_error()
+
+
+def test_malformed_descriptors_end_with_a_status_code_not_a_write():
+    """the destination side of a descriptor is checked on the device like the source side -- an output offset that is
+    negative, not a multiple of 16, or whose output would end beyond dst_bytes gets status "size" (10); nothing of that stream is
+    written (the guard bytes around the buffer stay), and the well-formed streams of the same launch inflate as usual."""
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    data = [payload(rng, 3000, k) for k in range(6)]
+    streams = [zlib.compress(d, 6) for d in data]
+    n = len(streams)
+    src_off = np.cumsum([0] + [(len(s) + 15) & ~15 for s in streams])
+    src = np.zeros(int(src_off[-1]) + 1024, dtype=np.uint8)
+    for i, s in enumerate(streams):
+        src[src_off[i]: src_off[i] + len(s)] = np.frombuffer(s, dtype=np.uint8)
+    room = 3008
+    dst_bytes = n * room
+    guard = 4096
+    whole = torch.full((guard + dst_bytes + guard,), 0xAA, dtype=torch.uint8, device=DEV)
+    desc = np.array([(src_off[i], len(streams[i]), i * room, 3000) for i in range(n)], dtype=np.int64)
+    desc[1, 2] = -16                       # before the buffer
+    desc[2, 2] = 2 * room + 8              # not a multiple of 16
+    desc[3, 2] = dst_bytes - 1008          # would end beyond dst_bytes
+    desc[4, 2] = 1 << 40                   # far outside
+    src_d, desc_d = torch.from_numpy(src).to(DEV), torch.from_numpy(desc).to(DEV)
+    status_d = torch.full((n, 4), -1, dtype=torch.int32, device=DEV)
+    a = _lib.InflateArgs(src_d=src_d.data_ptr(), src_bytes=src.size, desc_d=desc_d.data_ptr(), n_streams=n, flags=0,
+                         dst_d=whole.data_ptr() + guard, status_d=status_d.data_ptr(), stream=C.c_void_p(torch.cuda.current_stream().cuda_stream),
+                         dst_bytes=dst_bytes)
+    _lib.check(lib.lec_inflate(C.byref(a)), "lec_inflate")
+    torch.cuda.synchronize()
+    st, out = status_d.cpu().numpy(), whole.cpu().numpy()
+    assert st[:, 0].tolist() == [0, 10, 10, 10, 10, 0] and b"size" in lib.lec_inflate_status_text(10)
+    assert (out[:guard] == 0xAA).all() and (out[guard + dst_bytes:] == 0xAA).all()
+    body = out[guard: guard + dst_bytes]
+    assert body[:3000].tobytes() == data[0] and body[5 * room: 5 * room + 3000].tobytes() == data[5]
+    assert (body[room: 5 * room] == 0xAA).all()                                  # the four refused streams wrote nothing
+    a.dst_bytes = 0
+    assert lib.lec_inflate(C.byref(a)) == 1 and b"dst_bytes" in lib.lec_last_error()
+
+
+def test_fletcher32_of_a_large_stored_chunk():
+    """The wave's Fletcher-32 folds its partial sums (unfolded 64-bit sums wrap beyond ~47 MB and would report a false
+    checksum error): a 64 MiB chunk stored as it is, with the checksum hdf5_lite computes on the host; and a corrupt byte is seen."""
+    from lorenzcycletoolkit_amd import hdf5_lite
+    lib = _lib.load()
+    rng = np.random.default_rng(9)
+    n = 64 << 20
+    data = rng.integers(0, 256, n, dtype=np.uint8)
+    data[: n // 4] = 0xFF                                                           # long runs of large words: the sums grow fastest
+    ck = hdf5_lite._fletcher32(data.tobytes())[0]
+    for flip in (False, True):
+        src = np.zeros(n + 4 + 1024, dtype=np.uint8)
+        src[:n] = data
+        src[n: n + 4] = np.frombuffer(int(ck).to_bytes(4, "little"), dtype=np.uint8)
+        if flip:
+            src[n // 2] ^= 1
+        src_d = torch.from_numpy(src).to(DEV)
+        desc_d = torch.tensor([[0, -n, 0, n]], dtype=torch.int64, device=DEV)
+        dst_d = torch.zeros(n + 16, dtype=torch.uint8, device=DEV)
+        status_d = torch.full((1, 4), -1, dtype=torch.int32, device=DEV)
+        a = _lib.InflateArgs(src_d=src_d.data_ptr(), src_bytes=src.size, desc_d=desc_d.data_ptr(), n_streams=1, flags=1, dst_d=dst_d.data_ptr(),
+                             status_d=status_d.data_ptr(), stream=C.c_void_p(torch.cuda.current_stream().cuda_stream), dst_bytes=dst_d.numel())
+        _lib.check(lib.lec_inflate(C.byref(a)), "lec_inflate")
+        torch.cuda.synchronize()
+        code = int(status_d[0, 0])
+        if flip:
+            assert code == 12
+        else:
+            assert code == 0 and torch.equal(dst_d[:n].cpu(), torch.from_numpy(data))

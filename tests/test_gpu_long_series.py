@@ -1,0 +1,178 @@
+"""Series longer than one launch or one record buffer (VERDICT r3 "missing" 3), and the streamed pipeline with deflated and plain
+variables mixed in one file.
+
+* ``lec_reduce`` has no 65535-step limit any more (ABI 8) and ``LECEngine.rowstats`` cuts a long resident series into launches itself;
+* ``lec_streamed`` keeps row records for ONE chunk: every chunk goes through the level half of stage 2 (``LEC_STAGE_LEVELS``) into a
+  12-KB-per-step buffer of the whole series, and the any-time NaN mask + the pressure integrals run over all of it at the end
+  (``LEC_STAGE_VERTICAL``) -- the reference's dropna over the whole [time, level] array (energy_contents.py:190-208)."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import pandas as pd
+import pytest
+
+torch = pytest.importorskip("torch")
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+from lorenzcycletoolkit_amd import _lib, ingest                      # noqa: E402
+from lorenzcycletoolkit_amd import dataset as ds                      # noqa: E402
+from lorenzcycletoolkit_amd.engine import LECEngine                   # noqa: E402
+
+NAMES = {"Air Temperature": "t", "Eastward Wind Component": "u", "Northward Wind Component": "v", "Omega Velocity": "w",
+         "Geopotential": "z", "Longitude": "longitude", "Latitude": "latitude", "Time": "time", "Vertical Level": "level"}
+DF = pd.DataFrame({"Variable": list(NAMES.values()), "Units": ["K", "m/s", "m/s", "Pa/s", "m**2/s**2", "", "", "", ""]}, index=list(NAMES.keys()))
+KEYS = {"t": "tair", "u": "u", "v": "v", "w": "omega", "z": "geopt"}
+
+
+def _fields(T, lev_hpa, lat, lon, seed, dtype=np.float32):
+    rng = np.random.default_rng(seed)
+    p = (lev_hpa[None, :, None, None] * 100.0) / 1e5
+    shp = (T, lev_hpa.size, lat.size, lon.size)
+    phi = np.deg2rad(lat)[None, None, :, None]
+    wob = np.sin(np.arange(T) / 37.0)[:, None, None, None]
+    return {"t": (288.0 * p ** 0.19 + 8.0 * np.cos(2 * phi) * p + wob + rng.standard_normal(shp)).astype(dtype),
+            "u": (20.0 * np.cos(phi) * (1 - p / 1.2) + 5 * rng.standard_normal(shp)).astype(dtype),
+            "v": (3.0 * rng.standard_normal(shp)).astype(dtype),
+            "w": (0.1 * rng.standard_normal(shp)).astype(dtype),
+            "z": (9.80665 * 7000.0 * np.log(1.0 / p) + 100.0 * rng.standard_normal(shp)).astype(dtype)}
+
+
+def _plan(raw, T):
+    px = ds.process_index(raw.lat, raw.lon, raw.level, raw.time, raw.level_units, raw.names, argparse.Namespace(track=False))
+    i32 = lambda x: np.ascontiguousarray(x, dtype=np.int32)
+    return ingest.IngestPlan(np.arange(T), i32(px.ik), i32(px.ij), i32(px.io), px.lat, px.lon, px.level, px.time), px
+
+
+def test_a_70000_step_series_streams_with_chunk_sized_records():
+    """70,000 steps of a 4 x 6 x 8 grid (file order: levels from the ground up in hPa, latitudes N -> S), one level of v all NaN at ONE
+    step: the streamed run (chunks of 4096 steps, row records for one chunk only) equals the resident engine run over the whole cube
+    bit for bit -- itself two stage-1 launches and one 70,000-step lec_reduce, which ABI 7 refused --, the NaN level is dropped at
+    every step, and the numbers are the oracle's."""
+    T = 70000
+    lev = np.array([1000.0, 850.0, 500.0, 200.0])
+    lat, lon = np.linspace(30.0, -20.0, 6), np.linspace(-40.0, 30.0, 8)
+    f = _fields(T, lev, lat, lon, seed=1)
+    f["v"][40000, 3] = np.nan                                    # 200 hPa = the top level, one step out of 70,000
+    f["w"][123, 1, 2, 3] = np.nan                                # an interior point elsewhere: repaired at that step only
+    time = np.datetime64("2000-01-01T00", "ns") + (np.arange(T) * 3600 * 10 ** 9).astype("timedelta64[ns]")
+    raw = ds.RawDataset({n: ds.RawVariable(a, None, None, None) for n, a in f.items()}, lat, lon, lev, time, NAMES, "hPa", "Geopotential")
+    plan, px = _plan(raw, T)
+    limits = (float(plan.lon[0]), float(plan.lon[-1]), float(plan.lat[0]), float(plan.lat[-1]))
+    stats = {}
+    res = ingest.lec_streamed(raw, plan, DF, [limits], chunk_steps=4096, stats=stats)
+    torch.cuda.synchronize()
+    assert stats["chunks"] == 1 + -(-(T - 1) // 4096)
+    assert stats["row_record_bytes"] == 4096 * 4 * 6 * 32 * 8 and stats["levraw_bytes"] == T * 4 * 40 * 8      # bounded by the chunk / 1.3 KB per step
+    # resident: the host-prepared cube, one engine call
+    cube = {KEYS[n]: torch.from_numpy(np.ascontiguousarray(a[:, px.ik][:, :, px.ij][:, :, :, px.io])).to("cuda:0") for n, a in f.items()}
+    eng = LECEngine(plan.lat, plan.lon, plan.level, device="cuda:0")
+    assert T > 2 * eng.MAX_STEPS_PER_LAUNCH and T > 65535
+    box = eng.box_from_limits(*limits)
+    ref = eng.compute(cube["tair"], cube["u"], cube["v"], cube["omega"], cube["geopt"], [box], time_s=plan.time_s)
+    torch.cuda.synchronize()
+    same = lambda a, b: bool(((a == b) | (torch.isnan(a) & torch.isnan(b))).all())
+    assert same(res.scalars, ref.scalars) and same(res.levels, ref.levels) and torch.equal(res.nanflag, ref.nanflag)
+    assert bool((res.nanflag > 0).all())                          # the level that is NaN at step 40000 is dropped at EVERY step
+    assert bool(torch.isfinite(res.scalars).all())
+    # a chunk length that does not divide the series, and a time range (what a rank of a sharded run computes) with the mask merged by hand
+    again = ingest.lec_streamed(raw, plan, DF, [limits], chunk_steps=30011)
+    assert same(again.scalars, ref.scalars) and same(again.levels, ref.levels)
+    masks = []
+    parts = [ingest.lec_streamed(raw, plan, DF, [limits], chunk_steps=8192, t_range=r, merge_dropmask=lambda m: masks.append(m.clone()))
+             for r in ((0, 35000), (35000, T))]
+    merged = torch.maximum(masks[0], masks[1])
+    assert int(masks[0].sum()) == 0 and int(masks[1].sum()) > 0  # only the second half saw the NaN level
+    parts = [ingest.lec_streamed(raw, plan, DF, [limits], chunk_steps=8192, t_range=r, merge_dropmask=lambda m: m.copy_(merged))
+             for r in ((0, 35000), (35000, T))]
+    assert same(torch.cat([p.scalars for p in parts]), ref.scalars) and same(torch.cat([p.levels for p in parts]), ref.levels)
+    # the oracle: the reference's un-factored formulas with its dropna over the whole [time, level] arrays, on a window around the
+    # NaN step (the whole series would take the oracle minutes) -- the any-time mask of the window equals the series' there
+    from oracle import lec_oracle as o
+    from tests.helpers import SCALARS, scale_err
+    a, b = 39990, 40010
+    host = {k: np.ascontiguousarray(v[a:b].double().cpu().numpy()) for k, v in cube.items()}
+    dom = o.Domain(host["tair"], host["u"], host["v"], host["omega"], host["geopt"], plan.lat, plan.lon, plan.level, plan.time_s[a:b])
+    with np.errstate(all="ignore"):
+        sc, _ = o.lec_fixed(dom, *limits)
+    got = {name: res.scalars[a + 1: b - 1, i].cpu().numpy() for i, name in enumerate(_scalar_names())}
+    for name in ("Az", "Ae", "Kz", "Ke", "Cz", "Ca", "Ck", "Ce", "BAz", "BAe", "BKz", "BKe", "Gz", "Ge"):      # interior steps: same dT/dt stencil
+        assert scale_err(got[name], np.asarray(sc[name])[1:-1]) < 1e-9, name
+
+
+def _scalar_names():
+    from lorenzcycletoolkit_amd.constants import SCALAR_TERMS
+    return list(SCALAR_TERMS)
+
+
+def test_stage_halves_and_launch_splitting_change_no_bit():
+    """``rowstats`` cut into launches of 5 steps, ``level_stage`` + ``vertical_stage`` run apart, against the plain ``compute`` -- one fixed
+    box with an any-time NaN level and per-step boxes (the moving framework), fp64 and fp32 storage: the same bits."""
+    from tests.helpers import synthetic_domain
+    for dtype in (np.float64, np.float32):
+        dom = synthetic_domain(23, 6, 40, 64, seed=5, dtype=dtype, lat0=-50, lat1=28, lon0=-120, lon1=6)
+        dom.omega[7, 0] = np.nan
+        eng = LECEngine(dom.lat, dom.lon, dom.level, device="cuda:0")
+        f = [torch.as_tensor(np.ascontiguousarray(x)).to("cuda:0") for x in (dom.tair, dom.u, dom.v, dom.omega, dom.geopt)]
+        for moving in (False, True):
+            boxes = [(3 + t % 4, 50 + t % 5, 2 + t % 3, 30 + t % 6) for t in range(23)] if moving else [(2, 60, 1, 38)]
+            ref = eng.compute(*f, boxes, time_s=dom.time_s, per_step_boxes=moving, keep_rows=True)
+            eng.MAX_STEPS_PER_LAUNCH = 5
+            try:
+                rows = eng.rowstats(*f, boxes, time_s=dom.time_s, per_step_boxes=moving)
+            finally:
+                del eng.MAX_STEPS_PER_LAUNCH
+            assert torch.equal(rows.view(torch.int64), ref.rows.view(torch.int64))
+            prep = eng.prepare_boxes(boxes, nyb_min=int(rows.shape[2]))
+            levraw = torch.empty((23, 6, _lib.LEC_NLEVRAW), dtype=torch.float64, device="cuda:0")
+            for a, b in ((0, 1), (1, 9), (9, 23)):
+                eng.level_stage(rows[a:b], prep.part(a, b) if moving else prep, levraw[a:b])
+            got = eng.vertical_stage(levraw, prep, drop_any_time=not moving)
+            torch.cuda.synchronize()
+            same = lambda x, y: bool(((x == y) | (torch.isnan(x) & torch.isnan(y))).all())
+            assert same(got.scalars, ref.scalars) and same(got.levels, ref.levels) and torch.equal(got.nanflag, ref.nanflag), (dtype, moving)
+
+
+def test_deflated_and_plain_variables_mixed_in_one_streamed_run():
+    """a file whose variables take DIFFERENT roads to the GPU -- T (the first role) and w in deflated HDF5 chunks, inflated on
+    the device on their own streams; u, v, z plain arrays, staged to pinned memory and copied on the shared copy stream -- through many
+    reuses of two and three pipeline slots.  Every slot's raw buffers must have been decoded, and every variable's upload landed,
+    before the slot is restaged, whichever stream the variable rides on: same bits as the all-plain run, and as the resident run."""
+    sys.path.insert(0, ROOT)
+    from tools.bench_ingest import DeflatedVar
+    T = 37
+    lev = np.array([1000.0, 925.0, 850.0, 700.0, 500.0, 300.0, 200.0, 100.0])
+    lat, lon = np.linspace(40.0, -40.0, 33), np.arange(0.0, 360.0, 7.5)
+    f = _fields(T, lev, lat, lon, seed=2, dtype=np.float64)
+    packed, attrs = {}, {}
+    for n, a in f.items():
+        lo, hi = float(a.min()) - 1.0, float(a.max()) + 1.0
+        attrs[n] = ((hi - lo) / 64000.0, 0.5 * (hi + lo))
+        packed[n] = np.clip(np.round((a - attrs[n][1]) / attrs[n][0]), -32000, 32000).astype("<i2")
+    packed["v"][5, 0] = -32767                                     # a level of fill values at one step: the any-time mask crosses chunks
+    time = np.datetime64("2010-01-01T00", "ns") + (np.arange(T) * 3600 * 10 ** 9).astype("timedelta64[ns]")
+    plain = {n: ds.RawVariable(packed[n], attrs[n][0], attrs[n][1], -32767.0) for n in packed}
+    mixed = dict(plain)
+    for n in ("t", "w"):
+        mixed[n] = ds.RawVariable(DeflatedVar(packed[n], (1, 2, 17, 24), 3), attrs[n][0], attrs[n][1], -32767.0)
+    limits = (-100.0, 80.0, -30.0, 35.0)
+    out = {}
+    for label, variables in (("plain", plain), ("mixed", mixed)):
+        raw = ds.RawDataset(variables, lat, lon, lev, time, NAMES, "hPa", "Geopotential")
+        plan, px = _plan(raw, T)
+        for slots in (2, 3):
+            for chunk in (1, 2, 5):
+                st = {}
+                r = ingest.lec_streamed(raw, plan, DF, [limits], chunk_steps=chunk, slots=slots, stats=st)
+                torch.cuda.synchronize()
+                assert st["inflate"] == ("device" if label == "mixed" else "none")
+                out[(label, slots, chunk)] = (r.scalars.clone(), r.levels.clone(), r.nanflag.clone())
+    ref = out[("plain", 2, 5)]
+    same = lambda x, y: bool(((x == y) | (torch.isnan(x) & torch.isnan(y))).all())
+    for key, got in out.items():
+        assert same(got[0], ref[0]) and same(got[1], ref[1]) and torch.equal(got[2], ref[2]), key
+    assert bool((ref[2] > 0).all()) and bool(torch.isfinite(ref[0]).all())

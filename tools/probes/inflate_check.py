@@ -70,7 +70,7 @@ def run(lib, streams, sizes, dev, flags=None):
     dst_d = torch.full((do + 16,), 0xAA, dtype=torch.uint8, device=dev)
     status_d = torch.full((n, 4), -1, dtype=torch.int32, device=dev)
     a = _lib.InflateArgs(src_d=src_d.data_ptr(), src_bytes=src.size, desc_d=desc_d.data_ptr(), n_streams=n, flags=FLAGS if flags is None else flags, dst_d=dst_d.data_ptr(),
-                         status_d=status_d.data_ptr(), stream=C.c_void_p(torch.cuda.current_stream().cuda_stream))
+                         status_d=status_d.data_ptr(), stream=C.c_void_p(torch.cuda.current_stream().cuda_stream), dst_bytes=dst_d.numel())
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     _lib.check(lib.lec_inflate(C.byref(a)), "lec_inflate")
