@@ -63,6 +63,8 @@ def parse_args(argv=None):
     ap.add_argument("--digest-file", type=str, default=os.path.join(ROOT, "profiles", "series_digests.json"),
                     help="per-step checksums of the packed series of one-GPU runs: what config.series_equals_n1 compares an N-GPU run with")
     ap.add_argument("--write-digest", action="store_true", help="N = 1 only: add this run's series digest to --digest-file")
+    ap.add_argument("--nonuniform-lon", action="store_true", help="stretched longitudes (a Gaussian / regridded-MPAS style axis): the kernels "
+                    "then carry per-column trapezoid weights and d/dlon coefficient tables instead of the even-spacing fast path")
     ap.add_argument("--ny", type=int, default=721)
     ap.add_argument("--nx", type=int, default=1440)
     return ap.parse_args(argv)
@@ -278,6 +280,8 @@ def run_rank(args):
     level = era5_like_levels()
     lat = np.linspace(-90.0, 90.0, args.ny)
     lon = np.linspace(-180.0, 180.0 - 360.0 / args.nx, args.nx)
+    if args.nonuniform_lon:      # strictly ascending, spacing modulated by +-30 %
+        lon = np.sort(lon + 0.3 * (360.0 / args.nx) * np.sin(np.linspace(0.0, 7.0, args.nx)))
     if args.moving:
         # the reference crops the data to the track extent +- (half box + one grid step) first
         # (select_area.py:297-313); the synthetic track wanders over 25 x 45 degrees
@@ -580,7 +584,8 @@ def run_rank(args):
             workload = (f"synthetic 0.25-degree {nl} lev x {lat.size} x {lon.size} track-extent crop, moving 15x15-degree box "
                         f"(61 x 61 points) per time step, storage {args.storage}, terms = {terms}")
         else:
-            workload = (f"synthetic ERA5-res {nl} lev x {args.ny} x {args.nx}, fixed box = whole grid, storage {args.storage}, terms = {terms}")
+            workload = (f"synthetic ERA5-res {nl} lev x {args.ny} x {args.nx}" + (" on STRETCHED longitudes" if args.nonuniform_lon else "") +
+                        f", fixed box = whole grid, storage {args.storage}, terms = {terms}")
         workload += (f"; strong scaling: global series T={T_global} sharded over {world} GPU(s), "
                      + ("shard resident in HBM" if resident else f"streamed through HBM in chunks of {chunk} steps (+ one-step T halo)")
                      if strong else f"; T={T_local} per GPU resident in HBM")
@@ -644,7 +649,8 @@ def run_rank(args):
             out["roofline"]["conversion_terms"] = conv
         # the synthetic fields are seeded per GLOBAL time step and the kernels are bitwise reproducible under sharding and chunking,
         # so the series does not depend on N: compare it with the digest a one-GPU run stored (profiles/series_digests.json)
-        dkey = (f"{'moving' if args.moving else 'fixed'}_{args.storage}_{'noq' if args.no_q else 'all'}_{nl}x{lat.size}x{lon.size}_T{T_global}")
+        dkey = (f"{'moving' if args.moving else 'fixed'}_{args.storage}_{'noq' if args.no_q else 'all'}_{nl}x{lat.size}x{lon.size}_T{T_global}"
+                + ("_stretched" if args.nonuniform_lon else ""))
         full = series if (series is not None and gat.active) else res.packed
         sums = record_checksums(full).cpu().numpy() if full.shape[0] == T_global else None
         if sums is not None:

@@ -20,8 +20,11 @@ import time
 
 import pandas as pd
 
+from lorenzcycletoolkit_amd import phases
 from lorenzcycletoolkit_amd.dataset import prepare_data
 from lorenzcycletoolkit_amd.frameworks import lec_fixed, lec_moving
+
+phases.mark("imports")          # interpreter start -> here: Python, pandas, torch and the package
 
 
 def create_arg_parser():
@@ -129,6 +132,13 @@ def main(argv=None):
         results_subdirectory_vertical_levels = os.path.join(results_subdirectory, "results_vertical_levels")
         figures_directory = os.path.join(results_subdirectory, "Figures")
     app_logger = initialize_logging(results_subdirectory, args)
+    if phases.enabled():             # (measurement runs only: brings the library load and the HIP context forward so that they show as a phase)
+        import torch
+        from lorenzcycletoolkit_amd import _lib
+        _lib.load()
+        torch.zeros(1, device=(args.shard.device if args.shard is not None else os.environ.get("LEC_DEVICE", "cuda:0")))
+        torch.cuda.synchronize()
+        phases.mark("library_and_hip_init")
     app_logger.info("Starting LEC analysis")
     app_logger.info(f"Command line arguments: {args}")
     if args.shard is not None:
@@ -139,6 +149,7 @@ def main(argv=None):
             data = prepare_streamed(args, "inputs/namelist", app_logger)
         else:
             data = prepare_data(args, "inputs/namelist", app_logger)
+        phases.mark("open_and_plan" if args.device_ingest else "open_decode_and_prepare")
         try:
             run_lec_analysis(data, args, results_subdirectory, figures_directory, results_subdirectory_vertical_levels, app_logger)
         finally:
@@ -150,6 +161,8 @@ def main(argv=None):
         app_logger.exception("LEC analysis failed")
         raise
     finally:
+        phases.mark("end")
+        phases.dump({"argv": argv})
         if args.shard is not None:
             import torch.distributed as dist
             if dist.is_initialized():

@@ -27,6 +27,19 @@
 // box-relative rows / columns), so sharding / chunking a series changes no bit.  Any box size works: rows wider than 64 columns
 // take several column chunks per level (no level window then: same arithmetic, T neighbours loaded per pass), four-row blocks
 // cover any height.
+//
+// TIME GROUPS (round 4, template parameter TG > 1; per-point dT/dt from the cube, one column chunk): a workgroup of TG waves owns the
+// same four rows of TG CONSECUTIVE time steps, one wave per step, and walks the levels in lock step.  T(t-1) and T(t+1) of a point --
+// two of the 7.5 row requests per point, and the kernel is bound by the rate at which a CU's L1 completes line fills -- are then the
+// neighbour waves' own T rows: every pass each wave publishes its four centre rows of T in LDS (in the tile that holds f, which is
+// dead between the compute layout of one pass and the load layout of the next: no extra LDS) and reads its time neighbours' instead
+// of loading them; only the group's first / last wave still loads T(t-1) / T(t+1) from memory: (6 + 8 / TG + 16) / 4 = 6.0 rows per
+// point at TG = 4 instead of 7.5.  For that the waves of a group load on COMMON grid rows and columns -- the union of the group's
+// boxes, which must fit 64 columns and the launch's row blocks (a track moves a column or a row every few steps; a group that does
+// not fit simply loads its time neighbours itself, same arithmetic) -- while everything that decides a BIT stays box-relative: the
+// position of a point in the LDS tiles (hence its summation group), the row's shift values, end points, latitude coefficients
+// and record slot.  So the records do not depend on TG, on how a series is cut into groups, shards or chunks, or on whether a
+// group shared: tested bit for bit against TG = 1 and the one-wave-per-row kernel.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -63,6 +76,10 @@ constexpr int kMinLevels = 5;                   // the T window's prologue (two 
 constexpr int kMaxLevels = 21;                  // a wave keeps its chunk's static-stability coefficients one per lane (3 per level: `levv`)
 static_assert(3 * kMaxLevels <= 64, "the level coefficients of a wave's chunk must fit one value per lane");
 constexpr int kLB = 4;               // levels whose rows are finished together (16 lanes: 4 levels x 4 rows)
+#ifndef LEC_BT_TG
+#define LEC_BT_TG 1                  // time steps per workgroup where the call allows it (tuning.block_shape overrides: 1, 2, 4)
+#endif
+constexpr int kDefaultTG = LEC_BT_TG;
 constexpr int kPS = 65;              // stride between the statistics of the partial-sum array (odd: conflict-free both ways)
 
 template <bool UNIFORM, int MODE> constexpr int n_tiles() { return (MODE == 0 ? 5 : 6) + (UNIFORM ? 0 : 1); }
@@ -105,26 +122,35 @@ __device__ __forceinline__ void finish_lane(const double (&tot)[kNA], double cT,
 // MODE 0: T, u, v, omega (Phi if present), no Q;  1: dT/dt = ta T(t-1) + tb T(t) + tc T(t+1) per point;  2: dT/dt cube.
 // WINDOW: rows fit one column chunk, so a wave walks its level chunk with T(k-1), T(k), T(k+1) sliding through registers;
 // otherwise every pass loads its own T neighbours (wide boxes; same arithmetic, same bits).
-template <typename TIN, bool UNIFORM, int MODE, bool WINDOW>
-__global__ void __launch_bounds__(64, 2) lec_boxtile_kernel(const RowParams p) {
+// TG: waves per workgroup = consecutive time steps that share their T rows through LDS (see the head of the file); 1 = none.
+__device__ __forceinline__ void lds_barrier() {           // LDS write -> workgroup barrier -> LDS read, the global loads stay in flight
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <typename TIN, bool UNIFORM, int MODE, bool WINDOW, int TG>
+__global__ void __launch_bounds__(64 * TG, 2) lec_boxtile_kernel(const RowParams p) {
+    static_assert(TG == 1 || (MODE == 1 && WINDOW), "time groups: per-point dT/dt from the cube's time neighbours, rows of one column chunk");
     constexpr bool WITH_Q = MODE != 0;
     constexpr int NT = n_tiles<UNIFORM, MODE>();
 #ifdef LEC_BT_PAD       // measurement builds: extra LDS per wave to cap the resident waves
-    __shared__ double sm[lds_doubles<UNIFORM, MODE>() + LEC_BT_PAD];
+    constexpr int kLds = lds_doubles<UNIFORM, MODE>() + LEC_BT_PAD;
 #else
-    __shared__ double sm[lds_doubles<UNIFORM, MODE>()];
+    constexpr int kLds = lds_doubles<UNIFORM, MODE>();
 #endif
+    __shared__ double sm_all[TG * kLds];
+    const int wv = TG > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;      // the wave = the time step inside the group
+    double* const sm = sm_all + wv * kLds;
     double* const part = sm;                              // [kNA][kPS]: the lanes' partial sums of a level (aliases the tiles: they are dead by then)
     double* const stash = sm + NT * kTile;                // [kLB levels][kWR rows][kNA]: row totals waiting for their finishing lane
     double* const side = stash + kLB * kWR * kNA;         // [kLB levels][kWR rows][kSide]
 
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
 
-    // block -> (time step, level chunk, row block of 4).  Every XCD (blockIdx % 8, speed only) owns a contiguous chunk of time steps
+    // block -> (time step [TG > 1: group of TG steps], level chunk, row block of 4).  Every XCD (blockIdx % 8, speed only) owns a contiguous chunk of time steps
     // and walks it in groups of tgroup steps: row block fastest (neighbouring blocks share their halo rows), then time step, then
     // level chunk, so the waves resident on an XCD are neighbours in latitude and time: the T rows at j+-1 (halo) and t+-1 are rows
     // a sibling loads as its own (L2)
-    const int n_rb = (p.nyb_max + kWR - 1) / kWR;
+    const int n_rb = p.jrows;                        // row blocks of the launch (TG > 1: room for the rows a group's boxes are apart)
     const int kchunk = p.jgroup;                     // levels per wave
     const int n_kc = (p.nl + kchunk - 1) / kchunk;
     const int xcd = blockIdx.x & 7;
@@ -132,28 +158,59 @@ __global__ void __launch_bounds__(64, 2) lec_boxtile_kernel(const RowParams p) {
     const int rbi = q0 % n_rb; q0 /= n_rb;
     const int ti = q0 % p.tgroup; q0 /= p.tgroup;
     const int kc = q0 % n_kc;
-    const int tin = (q0 / n_kc) * p.tgroup + ti;          // step inside the XCD's chunk (jchunk = time steps per XCD here)
-    const int tl = xcd * p.jchunk + tin;
-    if (tin >= p.jchunk || tl >= p.t_count) return;
+    const int tin = (q0 / n_kc) * p.tgroup + ti;          // step (TG > 1: group) inside the XCD's chunk (jchunk = steps / groups per XCD here)
+    const int grp = xcd * p.jchunk + tin;
+    if (tin >= p.jchunk || grp * TG >= p.t_count) return;                 // (the same for every wave of the workgroup)
+    // the last group of a series may be partial: its spare waves walk along as copies of the last step (barriers) and store nothing
+    const bool live = grp * TG + wv < p.t_count;
+    const int tl = live ? grp * TG + wv : p.t_count - 1;
 
     const int bi = (p.n_box == 1) ? 0 : tl;
     const int iw = p.box[4 * bi + 0], ie = p.box[4 * bi + 1], js = p.box[4 * bi + 2], jn = p.box[4 * bi + 3];
     const int nxb = ie - iw + 1, nyb = jn - js + 1;
-    const int jb0 = rbi * kWR;
     const int k0 = kc * kchunk, k1 = min(k0 + kchunk, p.nl);
-    if (jb0 >= nyb) {       // a row block that holds only padding rows of a box lower than nyb_max
-        const int nrow = min(kWR, p.nyb_max - jb0);
-        for (int k = k0; k < k1; ++k) {
-            double* rec = p.rows + ((size_t)(tl * p.nl + k) * p.nyb_max + jb0) * LEC_NSTAT;
+    // TG > 1: the group's waves load on the grid rows / columns of the UNION of their boxes, if that fits one wave-wide row and the
+    // launch's row blocks (else every wave keeps to its own box and loads its time neighbours itself).  sh / shj: where the wave's
+    // own box starts inside the union -- everything that shapes a sum or a record below is in box-relative rows / columns.
+    bool shared = false, any_act = true;
+    int i0 = iw, j0 = js, uw = nxb, ujn = nyb - 1;
+    if constexpr (TG > 1) {
+        int imin = iw, imax = ie, jmin = js, jmax = jn;
+#pragma unroll
+        for (int g = 0; g < TG; ++g) {
+            const int b = (p.n_box == 1) ? 0 : min(grp * TG + g, p.t_count - 1);
+            imin = min(imin, p.box[4 * b + 0]); imax = max(imax, p.box[4 * b + 1]);
+            jmin = min(jmin, p.box[4 * b + 2]); jmax = max(jmax, p.box[4 * b + 3]);
+        }
+        shared = (imax - imin + 1 <= kCW) && (jmax - jmin + 1 <= n_rb * kWR);
+        if (shared) { i0 = imin; j0 = jmin; uw = imax - imin + 1; ujn = jmax - jmin; }
+        any_act = false;
+#pragma unroll
+        for (int g = 0; g < TG; ++g) {                   // does the row block hold a box row of ANY step of the group?
+            const int b = (p.n_box == 1) ? 0 : min(grp * TG + g, p.t_count - 1);
+            const int f0 = rbi * kWR - (shared ? p.box[4 * b + 2] - j0 : 0);
+            any_act = any_act || (f0 + kWR > 0 && f0 < p.box[4 * b + 3] - p.box[4 * b + 2] + 1);
+        }
+    }
+    const int sh = TG > 1 ? iw - i0 : 0, shj = TG > 1 ? js - j0 : 0;
+    const int jb0 = rbi * kWR - shj;                 // box-relative row of the wave's first row (TG > 1: may be negative)
+    if (TG > 1 ? !any_act : jb0 >= nyb) {            // a row block that holds only padding rows of a box lower than nyb_max (or nothing)
+        const int jlo = max(jb0, TG > 1 ? nyb : 0), nrow = min(jb0 + kWR, p.nyb_max) - jlo;
+        for (int k = k0; k < k1 && live; ++k) {
+            double* rec = p.rows + ((size_t)(tl * p.nl + k) * p.nyb_max + jlo) * LEC_NSTAT;
             for (int e = lane; e < nrow * LEC_NSTAT; e += 64) rec[e] = 0.0;
         }
         return;
     }
+    // rows of the block at which the box ends inside it (TG > 1): their neighbour across the edge is a row of ANOTHER step's box
+    // there -- loaded for that step's sake; the one-sided stencil gives it the coefficient 0, but 0 x NaN is NaN, so it is replaced
+    // by the row itself, which is what the clamped row index of the plain kernel reads
+    const int r_lo = (TG > 1 && jb0 < 0) ? -jb0 : -1, r_hi = (TG > 1) ? nyb - 1 - jb0 : -1;
 
     const int t = p.t_begin + tl;
     const size_t plane = (size_t)p.ny * p.nx;
     const size_t cube = plane * p.nl;
-    const size_t t0off = (size_t)t * cube + (size_t)iw;
+    const size_t t0off = (size_t)t * cube + (size_t)i0;
     const TIN* __restrict__ gT = (const TIN*)p.T + t0off;
     const TIN* __restrict__ gU = (const TIN*)p.U + t0off;
     const TIN* __restrict__ gV = (const TIN*)p.V + t0off;
@@ -165,6 +222,12 @@ __global__ void __launch_bounds__(64, 2) lec_boxtile_kernel(const RowParams p) {
     const TIN* __restrict__ gD1 = (t < p.nt - 1) ? gT + cube : gT;
     double ta = 0, tb = 0, tc = 0;
     if (MODE == 1) { const double* tcf = p.tcoef + (size_t)t * 3; ta = tcf[0]; tb = tcf[1]; tc = tcf[2]; }
+    // which time neighbours come from the group's LDS (the previous / next wave's own T rows) instead of from memory
+    const bool d0_lds = TG > 1 && shared && wv > 0;
+    const bool d1_lds = TG > 1 && shared && wv < TG - 1 && grp * TG + wv + 1 < p.t_count;
+    TIN* const xch = reinterpret_cast<TIN*>(sm + 5 * kTile);                      // own centre rows of T, [4][64] (the f tile, dead between passes)
+    const TIN* const xlo = reinterpret_cast<const TIN*>(sm - (TG > 1 ? kLds : 0) + 5 * kTile);     // (only read when d0_lds / d1_lds)
+    const TIN* const xhi = reinterpret_cast<const TIN*>(sm + (TG > 1 ? kLds : 0) + 5 * kTile);
     // Row / level coefficients are wave-uniform, but inside the pass loop (which stores row records) the compiler would fetch them
     // with VECTOR loads followed by s_waitcnt vmcnt(0) -- draining the prefetched rows every time.  So they are loaded once, here,
     // spread over the lanes, and picked with v_readlane:
@@ -172,7 +235,7 @@ __global__ void __launch_bounds__(64, 2) lec_boxtile_kernel(const RowParams p) {
     //   coefficient j of level k0 + kk -- so a wave walks at most kMaxLevels = 21 levels (launch_tiles enforces it)
     double latv = 0.0, levv = 0.0;
     if (WITH_Q) {
-        const int jrow = min(jb0 + ((lane >> 2) & 3), nyb - 1);
+        const int jrow = min(max(jb0 + ((lane >> 2) & 3), 0), nyb - 1);
         latv = p.lattab[((size_t)bi * p.nyb_max + jrow) * 4 + (lane & 3)];
         levv = p.levtab[(size_t)min(k0 + lane / 3, p.nl - 1) * 3 + lane % 3];
     }
@@ -192,7 +255,12 @@ __global__ void __launch_bounds__(64, 2) lec_boxtile_kernel(const RowParams p) {
     // element offsets (inside a level plane) of the wave's rows: rows -1 .. 4 relative to its first, clamped into the box
     unsigned roff[kWR + 2];
 #pragma unroll
-    for (int i = 0; i < kWR + 2; ++i) roff[i] = (unsigned)__builtin_amdgcn_readfirstlane((js + min(max(jb0 + i - 1, 0), nyb - 1)) * p.nx);
+    for (int i = 0; i < kWR + 2; ++i) {
+        int row = js + min(max(jb0 + i - 1, 0), nyb - 1);
+        // a sharing group: the four centre rows are the union's rows whether or not this step's box holds them (a neighbour's may)
+        if (TG > 1 && shared && i >= 1 && i <= kWR) row = j0 + min(rbi * kWR + i - 1, ujn);
+        roff[i] = (unsigned)__builtin_amdgcn_readfirstlane(row * p.nx);
+    }
 
     // ---- registers of the load layout.  T window: Tn = level k+1 (rows -1 .. 4), Tc = level k, Tm = level k-1 (rows 0 .. 3);
     // En / Ec: T at the columns just outside the chunk (lanes 0..31: c0 - 1, lanes 32..63: c0 + 64) of the centre rows at k+1 / k
@@ -226,11 +294,11 @@ __global__ void __launch_bounds__(64, 2) lec_boxtile_kernel(const RowParams p) {
     // loads of the pass (level k, column chunk at c0).  `fresh`: the whole T window (no predecessor pass to inherit it from)
     auto issue_loads = [&](const int k, const int c0, const bool fresh) {
         if (LEC_BT_ABLATE & 2) return;
-        const unsigned col = (unsigned)min(c0 + lane, nxb - 1);
+        const unsigned col = (unsigned)min(c0 + lane, uw - 1);
         const unsigned ecol = (unsigned)min(max(lane < 32 ? c0 - 1 : c0 + kCW, 0), nxb - 1);
         const size_t lk = lev(k);
         if (!UNIFORM) {
-            const int ec = min(c0 + lane, nxb - 1);
+            const int ec = min(max(c0 + lane - sh, 0), nxb - 1);
             rWl = wl[ec];
             if (WITH_Q) { rG[0] = gl[3 * ec]; rG[1] = gl[3 * ec + 1]; rG[2] = gl[3 * ec + 2]; }
         }
@@ -259,8 +327,8 @@ __global__ void __launch_bounds__(64, 2) lec_boxtile_kernel(const RowParams p) {
                 const size_t o = lk + roff[i + 1];
                 if (WITH_Q || has_p) sP[0][i] = ldnt(gP + o, col);
                 if (WITH_Q) {
-                    sD0[0][i] = ld(gD0 + o, col);
-                    if (MODE == 1) sD1[0][i] = ld(gD1 + o, col);
+                    if (!d0_lds) sD0[0][i] = ld(gD0 + o, col);
+                    if (MODE == 1 && !d1_lds) sD1[0][i] = ld(gD1 + o, col);
                 }
             }
         }
@@ -270,7 +338,7 @@ __global__ void __launch_bounds__(64, 2) lec_boxtile_kernel(const RowParams p) {
         constexpr int SET = decltype(set_tag)::value;
         if (LEC_BT_ABLATE & 2) return;
         const int kn = ps / ncc, c0 = (ps - kn * ncc) * kCW;
-        const unsigned col = (unsigned)min(c0 + lane, nxb - 1);
+        const unsigned col = (unsigned)min(c0 + lane, uw - 1);
         const size_t lk = lev(k0 + kn);
 #pragma unroll
         for (int i = 0; i < kWR; ++i) {
@@ -281,11 +349,16 @@ __global__ void __launch_bounds__(64, 2) lec_boxtile_kernel(const RowParams p) {
             if (DEEP_ALL) {
                 if (WITH_Q || has_p) sP[SET][i] = ldnt(gP + o, col);
                 if (WITH_Q) {
-                    sD0[SET][i] = ld(gD0 + o, col);
-                    if (MODE == 1) sD1[SET][i] = ld(gD1 + o, col);
+                    if (!d0_lds) sD0[SET][i] = ld(gD0 + o, col);
+                    if (MODE == 1 && !d1_lds) sD1[SET][i] = ld(gD1 + o, col);
                 }
             }
         }
+    };
+    // the wave's centre rows of T at the level the NEXT pass works on -> its exchange tile (TG > 1)
+    auto publish = [&]() {
+#pragma unroll
+        for (int i = 0; i < kWR; ++i) xch[i * kCW + lane] = Tc[i + 1];
     };
 
     // ---- compute-layout roles: lane -> (row ci of the wave's four, column group cg of sixteen)
@@ -298,8 +371,19 @@ __global__ void __launch_bounds__(64, 2) lec_boxtile_kernel(const RowParams p) {
     issue_loads(k0, 0, true);
     issue_stream(std::integral_constant<int, 0>{}, 0);
     if (npass > 1) issue_stream(std::integral_constant<int, 1>{}, 1);
+    if (TG > 1 && shared) { publish(); lds_barrier(); }       // (`shared` and the pass count are the same for every wave of the workgroup)
     auto pass = [&](auto set_tag, const int ps) {
         constexpr int SET = decltype(set_tag)::value;
+        if (TG > 1 && shared) {
+            // the time neighbours' rows of this level, published by the previous / next wave at the end of their last pass; the second
+            // barrier lets every wave finish reading before anyone's load layout overwrites the tile with f
+#pragma unroll
+            for (int i = 0; i < kWR; ++i) {
+                if (d0_lds) sD0[DEEP_ALL ? SET : 0][i] = xlo[i * kCW + lane];
+                if (d1_lds) sD1[DEEP_ALL ? SET : 0][i] = xhi[i * kCW + lane];
+            }
+            lds_barrier();
+        }
         const TIN (&rU)[kWR] = sU[SET]; const TIN (&rV)[kWR] = sV[SET]; const TIN (&rW)[kWR] = sW[SET]; const TIN (&rP)[kWR] = sP[DEEP_ALL ? SET : 0];
         const TIN (&rD0)[kWR] = sD0[DEEP_ALL ? SET : 0]; const TIN (&rD1)[kWR] = sD1[DEEP_ALL ? SET : 0];
         const int kk = ps / ncc, cc = ps - kk * ncc, k = k0 + kk, c0 = cc * kCW;
@@ -308,10 +392,10 @@ __global__ void __launch_bounds__(64, 2) lec_boxtile_kernel(const RowParams p) {
         // ================= load layout: one point per lane, the wave's four rows =================
         {
 #pragma clang fp contract(off)
-            const int e = c0 + lane;
-            const bool inside = e < nxb, first = e == 0, last = e == nxb - 1;
+            const int e = c0 + lane - sh;                                          // box-relative column
+            const bool inside = (unsigned)e < (unsigned)nxb, first = e == 0, last = e == nxb - 1;
             const bool zero = UNIFORM ? (!inside || first || last) : !inside;     // contributes nothing to the sums taken in LDS
-            const int llast = nxb - 1 - c0;                                        // lane of the row's last point (if in this chunk)
+            const int llast = nxb - 1 - c0 + sh;                                   // lane of the row's last point (if in this chunk)
             const bool has_last = llast >= 0 && llast < kCW;
             double al = 0, be = 0, gm = 0;
             if (WITH_Q) { al = lane_value(levv, 3 * kk); be = lane_value(levv, 3 * kk + 1); gm = lane_value(levv, 3 * kk + 2); }
@@ -321,9 +405,9 @@ __global__ void __launch_bounds__(64, 2) lec_boxtile_kernel(const RowParams p) {
             for (int i = 0; i < kWR; ++i) {
                 const double T = (double)Tc[i + 1], U = (double)rU[i], V = (double)rV[i], W = (double)rW[i];
                 const double P = (WITH_Q || has_p) ? (has_p ? (double)rP[i] : 0.0) : 0.0;
-                if (cc == 0) {                                 // the row's first box element is lane 0 of the first chunk
-                    cT[i] = lane_value(T, 0); cU[i] = lane_value(U, 0); cV[i] = lane_value(V, 0); cW[i] = lane_value(W, 0);
-                    cP[i] = lane_value(P, 0);
+                if (cc == 0) {                                 // the row's first box element is lane 0 (TG > 1: sh) of the first chunk
+                    cT[i] = lane_value(T, sh); cU[i] = lane_value(U, sh); cV[i] = lane_value(V, sh); cW[i] = lane_value(W, sh);
+                    cP[i] = lane_value(P, sh);
                 }
                 double f = 0.0;
                 if (WITH_Q && !(LEC_BT_ABLATE & 16)) {
@@ -335,15 +419,19 @@ __global__ void __launch_bounds__(64, 2) lec_boxtile_kernel(const RowParams p) {
                         const double dd = ((last ? T : Tr) - (first ? T : Tl)) * ((first || last) ? 2.0 : 1.0);
                         adv = (U * ((0.5 * inv_hdeg) * idx)) * dd;
                     } else {
-                        adv = U * fma(g2, Tr, fma(g1, T, g0 * Tl)) * idx;
+                        // (TG > 1: the lanes beside the box's ends hold real grid points there -- possibly NaN -- where the plain kernel's
+                        // clamped loads repeat the end point; the end coefficients are 0, but 0 x NaN is NaN)
+                        const double Tl_ = (TG > 1 && first) ? T : Tl, Tr_ = (TG > 1 && last) ? T : Tr;
+                        adv = U * fma(g2, Tr_, fma(g1, T, g0 * Tl_)) * idx;
                     }
-                    const double sP_ = stencil3(ga_, (double)Tc[i], gc_, (double)Tc[i + 2], gb_, T);
+                    const double Tjm = (TG > 1 && i == r_lo) ? T : (double)Tc[i], Tjp = (TG > 1 && i == r_hi) ? T : (double)Tc[i + 2];
+                    const double sP_ = stencil3(ga_, Tjm, gc_, Tjp, gb_, T);
                     const double sS = stencil3(al, (double)Tm[i], gm, (double)Tn[i + 1], be, T);
                     const double dTdt = (MODE == 1) ? stencil3(ta, (double)rD0[i], tc, (double)rD1[i], tb, T) : (double)rD0[i];
                     f = fma(-W, sS, fma(V, sP_, dTdt + adv));
                 }
                 const double a = T - cT[i], b = U - cU[i], c = V - cV[i], d = W - cW[i], ee = P - cP[i];
-                const int dst = i * kS4 + pos4(lane);
+                const int dst = i * kS4 + pos4(TG > 1 ? ((lane - sh) & (kCW - 1)) : lane);
                 sm[0 * kTile + dst] = zero ? 0.0 : a;
                 sm[1 * kTile + dst] = zero ? 0.0 : b;
                 sm[2 * kTile + dst] = zero ? 0.0 : c;
@@ -353,7 +441,7 @@ __global__ void __launch_bounds__(64, 2) lec_boxtile_kernel(const RowParams p) {
                 if (!UNIFORM) sm[(NT - 1) * kTile + dst] = wgt;
                 // the row's side values for its finishing lane
                 double* sr = sd + i * kSide;
-                if (cc == 0 && lane == 0) { sr[0] = cT[i]; sr[1] = cU[i]; sr[2] = cV[i]; sr[3] = cW[i]; sr[4] = cP[i]; sr[5] = f; }
+                if (cc == 0 && lane == sh) { sr[0] = cT[i]; sr[1] = cU[i]; sr[2] = cV[i]; sr[3] = cW[i]; sr[4] = cP[i]; sr[5] = f; }
                 if (has_last && lane == llast) {
                     sr[6] = a; sr[7] = b; sr[8] = c; sr[9] = d; sr[10] = ee; sr[11] = f;
                     sr[12] = T; sr[13] = U; sr[14] = V;
@@ -410,7 +498,7 @@ __global__ void __launch_bounds__(64, 2) lec_boxtile_kernel(const RowParams p) {
 #pragma clang fp contract(off)
             const int lv = lane >> 2, r = lane & 3;
             const int jb = jb0 + r;
-            if (lv <= slot && jb < p.nyb_max) {
+            if (lv <= slot && jb >= 0 && jb < p.nyb_max && live) {
                 const int kout = k - slot + lv;
                 dbl2_t* __restrict__ out = reinterpret_cast<dbl2_t*>(p.rows + ((size_t)(tl * p.nl + kout) * p.nyb_max + jb) * LEC_NSTAT);
                 // (few values live at a time: the epilogue runs while two passes' loads are in flight in registers)
@@ -446,6 +534,8 @@ __global__ void __launch_bounds__(64, 2) lec_boxtile_kernel(const RowParams p) {
             }
             row_sync<64>();
         }
+        // the f tile is dead until the next load layout: the centre rows of the next level (the window has slid) for the neighbours
+        if (TG > 1 && shared && ps + 1 < npass) { publish(); lds_barrier(); }
     };
     for (int ps = 0; ps < npass; ps += 2) {
         pass(std::integral_constant<int, 0>{}, ps);
@@ -454,16 +544,22 @@ __global__ void __launch_bounds__(64, 2) lec_boxtile_kernel(const RowParams p) {
 }
 
 template <typename TIN>
-int launch_tiles(RowParams p, bool uniform, int mode, hipStream_t st) {
-    const long long n_rb = (p.nyb_max + kWR - 1) / kWR;
-    p.jchunk = (p.t_count + 7) / 8;                       // time steps per XCD
-    // levels per wave: as many as still leave kTargetWaves one-wave workgroups (four rounds of the 2048 the chip holds at two per SIMD)
+int launch_tiles(RowParams p, bool uniform, int mode, int tg, hipStream_t st) {
+    const bool window = mode != 0 && p.nxb_max <= kCW;    // same arithmetic either way: only where the T neighbours come from differs
+    // time groups: TG consecutive steps per workgroup share T(t +- 1) through LDS (per-point dT/dt from the cube, one column chunk)
+    if (tg == 0) tg = kDefaultTG;
+    if (!(mode == 1 && window) || p.t_count < 2) tg = 1;
+    const long long n_rb = tg > 1 ? (p.nyb_max + 3 + kWR - 1) / kWR : (p.nyb_max + kWR - 1) / kWR;     // (room for boxes up to 3 rows apart)
+    p.jrows = (int)n_rb;
+    const long long n_units = (p.t_count + tg - 1) / tg;  // workgroups along time
+    p.jchunk = (int)((n_units + 7) / 8);                  // ... per XCD
+    // levels per wave: as many as still leave kTargetWaves waves (four rounds of the 2048 the chip holds at two per SIMD)
     // -- long level walks read best (profiles/r02_notes.md: 4 rows x 37 levels 6 % ahead of 4 x 10), short launches need the waves
     if (kLevelsFixed > 0) p.jgroup = kLevelsFixed;
     if (p.jgroup > kMaxLevels) return LEC_ERR_ARG;       // never clamped: the caller asked for something the kernel cannot do
     if (p.jgroup < 1) {
         constexpr long long kTargetWaves = 8192;
-        const long long per_chunk = 8LL * p.jchunk * n_rb;
+        const long long per_chunk = 8LL * p.jchunk * n_rb * tg;
         const long long want = (kTargetWaves + per_chunk - 1) / per_chunk;
         const long long most = (p.nl + kMinLevels - 1) / kMinLevels, least = (p.nl + kMaxLevels - 1) / kMaxLevels;
         const long long n_kc0 = want < least ? least : (want > most ? most : want);
@@ -471,18 +567,20 @@ int launch_tiles(RowParams p, bool uniform, int mode, hipStream_t st) {
     }
     if (p.jgroup > p.nl) p.jgroup = p.nl;
     const long long n_kc = (p.nl + p.jgroup - 1) / p.jgroup;
-    if (p.tgroup < 1) p.tgroup = 8;
+    if (p.tgroup < 1) p.tgroup = 8;                       // time steps per tile group ...
+    p.tgroup = (p.tgroup + tg - 1) / tg;                  // ... in workgroups
     if (p.tgroup > p.jchunk) p.tgroup = p.jchunk;
     const long long tgroups = (p.jchunk + p.tgroup - 1) / p.tgroup;
     const long long nblocks = 8LL * tgroups * p.tgroup * n_rb * n_kc;
     if (nblocks > 0x7fffffffLL) return LEC_ERR_UNSUPPORTED;
     if ((unsigned long long)p.ny * (unsigned long long)p.nx > 0xffffffffULL) return LEC_ERR_UNSUPPORTED;     // 32-bit offsets inside a plane
-    dim3 grid((unsigned)nblocks), block(64);
-    const bool window = mode != 0 && p.nxb_max <= kCW;    // same arithmetic either way: only where the T neighbours come from differs
-#define LEC_TILE(U, M, W) hipLaunchKernelGGL((lec_boxtile_kernel<TIN, U, M, W>), grid, block, 0, st, p)
-#define LEC_TILE_W(U, M) do { if (window) LEC_TILE(U, M, true); else LEC_TILE(U, M, false); } while (0)
-    if (uniform) { if (mode == 0) LEC_TILE(true, 0, false); else if (mode == 1) LEC_TILE_W(true, 1); else LEC_TILE_W(true, 2); }
-    else { if (mode == 0) LEC_TILE(false, 0, false); else if (mode == 1) LEC_TILE_W(false, 1); else LEC_TILE_W(false, 2); }
+    dim3 grid((unsigned)nblocks), block(64 * tg);
+#define LEC_TILE(U, M, W, G) hipLaunchKernelGGL((lec_boxtile_kernel<TIN, U, M, W, G>), grid, block, 0, st, p)
+#define LEC_TILE_W(U, M) do { if (window) LEC_TILE(U, M, true, 1); else LEC_TILE(U, M, false, 1); } while (0)
+#define LEC_TILE_G(U) do { if (tg == 4) LEC_TILE(U, 1, true, 4); else if (tg == 2) LEC_TILE(U, 1, true, 2); else LEC_TILE_W(U, 1); } while (0)
+    if (uniform) { if (mode == 0) LEC_TILE(true, 0, false, 1); else if (mode == 1) LEC_TILE_G(true); else LEC_TILE_W(true, 2); }
+    else { if (mode == 0) LEC_TILE(false, 0, false, 1); else if (mode == 1) LEC_TILE_G(false); else LEC_TILE_W(false, 2); }
+#undef LEC_TILE_G
 #undef LEC_TILE_W
 #undef LEC_TILE
     return LEC_OK;
@@ -491,7 +589,9 @@ int launch_tiles(RowParams p, bool uniform, int mode, hipStream_t st) {
 }  // namespace
 
 // mode: 0 no Q, 1 dT/dt from the cube's time neighbours per point, 2 dT/dt cube; p.tgroup: time steps per tile group, p.jgroup: levels
-// per wave (< 1: chosen here; more than 21: LEC_ERR_ARG)
-int lec_launch_boxtile(const lec::RowParams& p, int dtype, bool uniform, int mode, hipStream_t st) {
-    return dtype == LEC_F64 ? launch_tiles<double>(p, uniform, mode, st) : launch_tiles<float>(p, uniform, mode, st);
+// per wave (< 1: chosen here; more than 21: LEC_ERR_ARG); tg: time steps per workgroup (0 = default, 1, 2 or 4; mode 1 with rows of one
+// column chunk only -- other calls run one wave per workgroup)
+int lec_launch_boxtile(const lec::RowParams& p, int dtype, bool uniform, int mode, int tg, hipStream_t st) {
+    if (tg != 0 && tg != 1 && tg != 2 && tg != 4) return LEC_ERR_ARG;
+    return dtype == LEC_F64 ? launch_tiles<double>(p, uniform, mode, tg, st) : launch_tiles<float>(p, uniform, mode, tg, st);
 }

@@ -303,7 +303,7 @@ int launch_vec(const RowParams& p, bool uniform, int mode, int nblocks, hipStrea
 
 int lec_launch_rowsweep(const lec::RowParams& p, int dtype, bool aligned, bool aligned8, bool uniform, int mode, int f32_vec, hipStream_t st);
 int lec_launch_rowblock(lec::RowParams p, int dtype, bool aligned, bool aligned8, bool uniform, int bt, int bk, int bj, hipStream_t st);
-int lec_launch_boxtile(const lec::RowParams& p, int dtype, bool uniform, int mode, hipStream_t st);
+int lec_launch_boxtile(const lec::RowParams& p, int dtype, bool uniform, int mode, int tg, hipStream_t st);
 int lec_launch_qtime(const lec::RowParams& p, hipStream_t st);
 
 extern "C" int lec_max_row(int dtype, int aligned, int kernel) {
@@ -339,7 +339,11 @@ extern "C" int lec_rowstats(const lec_rowstats_args* a) {
     if (tu.f32_vec != 0 && tu.f32_vec != 2) return lec_set_error(LEC_ERR_ARG, "lec_rowstats: tuning.f32_vec must be 0 or 2");
     if (tu.reserved[0] || tu.reserved[1]) return lec_set_error(LEC_ERR_ARG, "lec_rowstats: tuning.reserved must be 0");
     int bt = 2, bk = 1, bj = 2;
-    if (tu.block_shape) {
+    const bool tile_call = tu.kernel == LEC_KERNEL_BOX_TILE || (tu.kernel == LEC_KERNEL_AUTO && a->box_per_step);
+    if (tile_call) {         // the box-tile kernel reads block_shape as the time steps per workgroup (0 = default)
+        if (tu.block_shape != 0 && tu.block_shape != 1 && tu.block_shape != 2 && tu.block_shape != 4)
+            return lec_set_error(LEC_ERR_ARG, "lec_rowstats: tuning.block_shape of a box-tile call (time steps per workgroup) must be 0, 1, 2 or 4");
+    } else if (tu.block_shape) {
         bt = tu.block_shape / 100; bk = (tu.block_shape / 10) % 10; bj = tu.block_shape % 10;
         if (tu.block_shape < 0 || bt < 1 || bt > 2 || bk < 1 || bk > 2 || bj < 1 || bj > 2 || bt * bk * bj < 2)
             return lec_set_error(LEC_ERR_ARG, "lec_rowstats: tuning.block_shape must be 100 bt + 10 bk + bj with bt, bk, bj in {1, 2} and at least two waves");
@@ -415,7 +419,7 @@ extern "C" int lec_rowstats(const lec_rowstats_args* a) {
         RowParams pt = p;
         pt.tgroup = tu.tile_t;                              // time steps per tile group; 0 = the kernel's default (8)
         pt.jgroup = tu.tile_j;                              // levels per wave; 0 = chosen from the launch size
-        rc = lec_launch_boxtile(pt, a->dtype, uni, wq, st);
+        rc = lec_launch_boxtile(pt, a->dtype, uni, wq, tu.block_shape, st);
     } else {
         // Single-sweep row kernels.  All terms with dT/dt from the cube on one fixed box (the headline configuration, mode 3): a
         // row reads T(t+1) only and the time-derivative parts of [Q], [Q'T'] are completed from the records afterwards

@@ -21,6 +21,7 @@ import pandas as pd
 import torch
 
 from . import dataset as ds
+from . import phases
 from .constants import LEVEL_TERMS
 from .engine import LECEngine, LECResult
 from .tables import budgets_and_residuals
@@ -274,6 +275,7 @@ def lec_fixed(data: ds.LECDataset, variable_list_df: pd.DataFrame, results_subdi
     except Exception:
         app_logger.exception("An exception occurred while creating BoxData object")
         raise
+    phases.mark("ingest_compute_gather")
     if box_obj.result is None:              # time-sharded run: rank 0 holds the gathered series and writes every file
         return None
     if int(box_obj.nanflag.sum()):
@@ -293,6 +295,7 @@ def lec_fixed(data: ds.LECDataset, variable_list_df: pd.DataFrame, results_subdi
         results_filename = os.path.basename(args.infile).split(".nc")[0] + "_fixed_results"
     results_file = Path(results_subdirectory, f"{results_filename}.csv")
     df.to_csv(results_file)
+    phases.mark("csv_writes")
     app_logger.info(f"Results saved to {results_file}")
     if getattr(args, "plots", False):
         app_logger.warning("-p/--plots: plotting is out of scope of the MI355X engine; the CSVs feed the reference's plot scripts unchanged")
@@ -342,11 +345,13 @@ def lec_moving(data: ds.LECDataset, variable_list_df: pd.DataFrame, dTdt, result
     box_obj = BoxData(data, variable_list_df, args=args, results_subdirectory=results_subdirectory,
                       results_subdirectory_vertical_levels=results_subdirectory_vertical_levels, dTdt=dTdt,
                       boxes_limits=boxes)
+    phases.mark("ingest_compute_gather")
     # 850-hPa diagnostics of every box (lec_moving_framework.py:650-709); a time-sharded rank does its own steps, rank 0 gets them all
     from .diagnostics import track_diagnostics
     form = getattr(args, "vorticity_form", None) or "metpy_no_crs"
     positions = track_diagnostics(data, variable_list_df, limits, track, use_track_zeta=bool(getattr(args, "zeta", False)),
                                   device=_device(args), shard=shard, formulation=form)
+    phases.mark("track_diagnostics")
     if box_obj.result is None:              # time-sharded run: rank 0 holds the gathered series and writes every file
         return None
     terms = _compute_all(box_obj, "moving", app_logger)
@@ -369,4 +374,5 @@ def lec_moving(data: ds.LECDataset, variable_list_df: pd.DataFrame, dTdt, result
     out_track = pd.DataFrame([{**l, **p} for l, p in zip(limits, positions)])
     out_track = out_track.rename(columns={"datestr": "time", "central_lat": "Lat", "central_lon": "Lon"})
     out_track.to_csv(os.path.join(results_subdirectory, f"{infile_name}_{method}_trackfile"), index=False, sep=";")
+    phases.mark("csv_writes")
     return results_file, df
