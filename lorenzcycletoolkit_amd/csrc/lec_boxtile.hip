@@ -75,7 +75,16 @@ constexpr int kLevelsFixed = LEC_BT_LEVELS;     // > 0: levels per wave fixed at
 constexpr int kMinLevels = 5;                   // the T window's prologue (two extra level loads) is paid once per chunk of levels
 constexpr int kMaxLevels = 21;                  // a wave keeps its chunk's static-stability coefficients one per lane (3 per level: `levv`)
 static_assert(3 * kMaxLevels <= 64, "the level coefficients of a wave's chunk must fit one value per lane");
-constexpr int kLB = 4;               // levels whose rows are finished together (16 lanes: 4 levels x 4 rows)
+// measurement builds of the time groups (tools/build_variant.sh): LEC_BT_XABL bit 1 = no workgroup barriers (wrong results), bit 2 =
+// the time neighbours still come from memory (publish + barriers kept: the cost of the lock step alone); LEC_BT_XDB = 1: the
+// exchange double-buffered in LDS of its own (one barrier per pass; paid for by finishing rows two levels at a time instead of four)
+#ifndef LEC_BT_XABL
+#define LEC_BT_XABL 0
+#endif
+#ifndef LEC_BT_XDB
+#define LEC_BT_XDB 0
+#endif
+constexpr int kLB = LEC_BT_XDB ? 2 : 4;      // levels whose rows are finished together (16 lanes: 4 levels x 4 rows)
 #ifndef LEC_BT_TG
 #define LEC_BT_TG 1                  // time steps per workgroup where the call allows it (tuning.block_shape overrides: 1, 2, 4)
 #endif
@@ -83,7 +92,7 @@ constexpr int kDefaultTG = LEC_BT_TG;
 constexpr int kPS = 65;              // stride between the statistics of the partial-sum array (odd: conflict-free both ways)
 
 template <bool UNIFORM, int MODE> constexpr int n_tiles() { return (MODE == 0 ? 5 : 6) + (UNIFORM ? 0 : 1); }
-template <bool UNIFORM, int MODE> constexpr int lds_doubles() { return n_tiles<UNIFORM, MODE>() * kTile + kLB * kWR * (kNA + kSide); }
+template <bool UNIFORM, int MODE> constexpr int lds_doubles() { return n_tiles<UNIFORM, MODE>() * kTile + kLB * kWR * (kNA + kSide) + (LEC_BT_XDB ? 2 * kWR * kCW : 0); }
 static_assert(kNA * kPS <= 5 * kTile, "the partial sums must fit the (dead) tiles they alias");
 
 __device__ __forceinline__ int pos4(int c) { return c + (c >> 2); }     // LDS column of tile column c (one pad per 4 columns)
@@ -124,7 +133,8 @@ __device__ __forceinline__ void finish_lane(const double (&tot)[kNA], double cT,
 // otherwise every pass loads its own T neighbours (wide boxes; same arithmetic, same bits).
 // TG: waves per workgroup = consecutive time steps that share their T rows through LDS (see the head of the file); 1 = none.
 __device__ __forceinline__ void lds_barrier() {           // LDS write -> workgroup barrier -> LDS read, the global loads stay in flight
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (LEC_BT_XABL & 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 template <typename TIN, bool UNIFORM, int MODE, bool WINDOW, int TG>
@@ -223,11 +233,27 @@ __global__ void __launch_bounds__(64 * TG, 2) lec_boxtile_kernel(const RowParams
     double ta = 0, tb = 0, tc = 0;
     if (MODE == 1) { const double* tcf = p.tcoef + (size_t)t * 3; ta = tcf[0]; tb = tcf[1]; tc = tcf[2]; }
     // which time neighbours come from the group's LDS (the previous / next wave's own T rows) instead of from memory
-    const bool d0_lds = TG > 1 && shared && wv > 0;
-    const bool d1_lds = TG > 1 && shared && wv < TG - 1 && grp * TG + wv + 1 < p.t_count;
-    TIN* const xch = reinterpret_cast<TIN*>(sm + 5 * kTile);                      // own centre rows of T, [4][64] (the f tile, dead between passes)
-    const TIN* const xlo = reinterpret_cast<const TIN*>(sm - (TG > 1 ? kLds : 0) + 5 * kTile);     // (only read when d0_lds / d1_lds)
-    const TIN* const xhi = reinterpret_cast<const TIN*>(sm + (TG > 1 ? kLds : 0) + 5 * kTile);
+    const bool d0_lds = TG > 1 && shared && wv > 0 && !(LEC_BT_XABL & 2);
+    const bool d1_lds = TG > 1 && shared && wv < TG - 1 && grp * TG + wv + 1 < p.t_count && !(LEC_BT_XABL & 2);
+    constexpr int kXoff = LEC_BT_XDB ? (NT * kTile + kLB * kWR * (kNA + kSide)) : 5 * kTile;
+    TIN* const xch = reinterpret_cast<TIN*>(sm + kXoff);                          // own centre rows of T, [4][64] (the f tile, dead between passes)
+    const TIN* const xlo = reinterpret_cast<const TIN*>(sm - (d0_lds ? kLds : 0) + kXoff);     // the previous / next wave's tile (the wave's own
+    const TIN* const xhi = reinterpret_cast<const TIN*>(sm + (d1_lds ? kLds : 0) + kXoff);     // where it has no such neighbour: read and dropped)
+    // TG > 1: the time neighbours' rows are fetched with BUFFER loads through a descriptor per wave whose size is 0 where the rows
+    // come from LDS -- every lane is then out of range: the load returns zeros and touches no memory.  So the instruction stream
+    // is the same for every wave of the group (no branch around a load: the compiler's s_waitcnt bookkeeping stays exact; with
+    // wave-uniform branches around them it drained the prefetched rows with vmcnt(0) at every join and the kernel lost 20 %).
+    typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+    __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<TIN*>(TG > 1 ? gD0 : gT), (short)0, d0_lds ? 0 : 0x7fffffff, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<TIN*>(TG > 1 ? gD1 : gT), (short)0, d1_lds ? 0 : 0x7fffffff, 0x00020000);
+    auto ldb = [](__amdgpu_buffer_rsrc_t r, size_t o, unsigned col) -> TIN {
+        if constexpr (sizeof(TIN) == 8) {
+            const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)(col * 8u), (int)(unsigned)(o * 8u), 0);
+            return (TIN)__hiloint2double((int)v.y, (int)v.x);
+        } else {
+            return (TIN)__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)(col * 4u), (int)(unsigned)(o * 4u), 0));
+        }
+    };
     // Row / level coefficients are wave-uniform, but inside the pass loop (which stores row records) the compiler would fetch them
     // with VECTOR loads followed by s_waitcnt vmcnt(0) -- draining the prefetched rows every time.  So they are loaded once, here,
     // spread over the lanes, and picked with v_readlane:
@@ -327,8 +353,13 @@ __global__ void __launch_bounds__(64 * TG, 2) lec_boxtile_kernel(const RowParams
                 const size_t o = lk + roff[i + 1];
                 if (WITH_Q || has_p) sP[0][i] = ldnt(gP + o, col);
                 if (WITH_Q) {
-                    if (!d0_lds) sD0[0][i] = ld(gD0 + o, col);
-                    if (MODE == 1 && !d1_lds) sD1[0][i] = ld(gD1 + o, col);
+                    if constexpr (TG > 1) {
+                        sD0[0][i] = ldb(rs0, o, col);
+                        sD1[0][i] = ldb(rs1, o, col);
+                    } else {
+                        sD0[0][i] = ld(gD0 + o, col);
+                        if (MODE == 1) sD1[0][i] = ld(gD1 + o, col);
+                    }
                 }
             }
         }
@@ -349,16 +380,21 @@ __global__ void __launch_bounds__(64 * TG, 2) lec_boxtile_kernel(const RowParams
             if (DEEP_ALL) {
                 if (WITH_Q || has_p) sP[SET][i] = ldnt(gP + o, col);
                 if (WITH_Q) {
-                    if (!d0_lds) sD0[SET][i] = ld(gD0 + o, col);
-                    if (MODE == 1 && !d1_lds) sD1[SET][i] = ld(gD1 + o, col);
+                    if constexpr (TG > 1) {
+                        sD0[SET][i] = ldb(rs0, o, col);
+                        sD1[SET][i] = ldb(rs1, o, col);
+                    } else {
+                        sD0[SET][i] = ld(gD0 + o, col);
+                        if (MODE == 1) sD1[SET][i] = ld(gD1 + o, col);
+                    }
                 }
             }
         }
     };
     // the wave's centre rows of T at the level the NEXT pass works on -> its exchange tile (TG > 1)
-    auto publish = [&]() {
+    auto publish = [&](const int buf) {
 #pragma unroll
-        for (int i = 0; i < kWR; ++i) xch[i * kCW + lane] = Tc[i + 1];
+        for (int i = 0; i < kWR; ++i) xch[(LEC_BT_XDB ? buf * kWR * kCW * (int)(sizeof(double) / sizeof(TIN)) : 0) + i * kCW + lane] = Tc[i + 1];
     };
 
     // ---- compute-layout roles: lane -> (row ci of the wave's four, column group cg of sixteen)
@@ -371,18 +407,22 @@ __global__ void __launch_bounds__(64 * TG, 2) lec_boxtile_kernel(const RowParams
     issue_loads(k0, 0, true);
     issue_stream(std::integral_constant<int, 0>{}, 0);
     if (npass > 1) issue_stream(std::integral_constant<int, 1>{}, 1);
-    if (TG > 1 && shared) { publish(); lds_barrier(); }       // (`shared` and the pass count are the same for every wave of the workgroup)
+    if (TG > 1) { publish(0); lds_barrier(); }                // (every wave of the workgroup makes the same number of passes)
     auto pass = [&](auto set_tag, const int ps) {
         constexpr int SET = decltype(set_tag)::value;
-        if (TG > 1 && shared) {
-            // the time neighbours' rows of this level, published by the previous / next wave at the end of their last pass; the second
-            // barrier lets every wave finish reading before anyone's load layout overwrites the tile with f
+        if (TG > 1) {
+            // the time neighbours' rows of this level, published by the previous / next wave at the end of their last pass: selected
+            // over what the (empty) buffer load returned -- no branch (groups that do not share, and the group's two end waves, read
+            // their own tile and keep the loaded rows); the second barrier lets every wave finish reading before anyone's load layout
+            // overwrites the tile with f
+            const int xb = LEC_BT_XDB ? (ps & 1) * kWR * kCW * (int)(sizeof(double) / sizeof(TIN)) : 0;
 #pragma unroll
             for (int i = 0; i < kWR; ++i) {
-                if (d0_lds) sD0[DEEP_ALL ? SET : 0][i] = xlo[i * kCW + lane];
-                if (d1_lds) sD1[DEEP_ALL ? SET : 0][i] = xhi[i * kCW + lane];
+                const TIN x0 = xlo[xb + i * kCW + lane], x1 = xhi[xb + i * kCW + lane];
+                sD0[DEEP_ALL ? SET : 0][i] = d0_lds ? x0 : sD0[DEEP_ALL ? SET : 0][i];
+                sD1[DEEP_ALL ? SET : 0][i] = d1_lds ? x1 : sD1[DEEP_ALL ? SET : 0][i];
             }
-            lds_barrier();
+            if (!LEC_BT_XDB) lds_barrier();
         }
         const TIN (&rU)[kWR] = sU[SET]; const TIN (&rV)[kWR] = sV[SET]; const TIN (&rW)[kWR] = sW[SET]; const TIN (&rP)[kWR] = sP[DEEP_ALL ? SET : 0];
         const TIN (&rD0)[kWR] = sD0[DEEP_ALL ? SET : 0]; const TIN (&rD1)[kWR] = sD1[DEEP_ALL ? SET : 0];
@@ -535,7 +575,7 @@ __global__ void __launch_bounds__(64 * TG, 2) lec_boxtile_kernel(const RowParams
             row_sync<64>();
         }
         // the f tile is dead until the next load layout: the centre rows of the next level (the window has slid) for the neighbours
-        if (TG > 1 && shared && ps + 1 < npass) { publish(); lds_barrier(); }
+        if (TG > 1 && ps + 1 < npass) { publish((ps + 1) & 1); lds_barrier(); }
     };
     for (int ps = 0; ps < npass; ps += 2) {
         pass(std::integral_constant<int, 0>{}, ps);
