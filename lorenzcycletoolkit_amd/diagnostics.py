@@ -201,25 +201,30 @@ _POSITION_KEYS = ["min_max_zeta_850_lat", "min_max_zeta_850_lon", "min_max_zeta_
 
 
 def track_diagnostics(data, variable_list_df, limits_per_step, track=None, use_track_zeta=False, device="cuda:0", shard=None,
-                      formulation="metpy_no_crs"):
+                      formulation="metpy_no_crs", slices=None):
     """All time steps: u, v, geopotential height at 85000 Pa -> list of position dicts.  ``shard`` (parallel.ShardContext): every
     rank evaluates its own time steps (each is independent), one gather of nine numbers per step brings them to rank 0; the other
-    ranks get None."""
+    ranks get None.  ``slices``: {"u", "v", "geopt"} device tensors [own steps, lat, lon] at 85000 Pa that the streamed pass kept
+    (``lec_streamed(keep_level=...)``): the file is then not read a second time."""
     import torch
     n_steps = len(limits_per_step)
     t0, t1 = (0, n_steps) if shard is None else shard.ranges(n_steps)[:2]
     k850 = int(np.flatnonzero(data.level == 85000.0)[0])
     name = lambda role: str(variable_list_df.loc[role]["Variable"])
-    if hasattr(data, "level_slice"):          # streamed data set: three level slices decoded from the mapped file
+    if slices is not None:
+        key = {"Eastward Wind Component": "u", "Northward Wind Component": "v", "Geopotential": "geopt", "Geopotential Height": "geopt"}
+        get = lambda role: slices[key[role]]
+    elif hasattr(data, "level_slice"):        # streamed data set: three level slices decoded from the mapped file
         get = lambda role: data.level_slice(role, 85000.0, (t0, t1))
     else:
         h0 = (getattr(data, "t_held", None) or (0, n_steps))[0]          # the variables start at step h0 of the time axis
         get = lambda role: data.variables[name(role)][t0 - h0: t1 - h0, k850]
     u, v = get("Eastward Wind Component"), get("Northward Wind Component")
+    f64 = lambda a: a.to(torch.float64) if isinstance(a, torch.Tensor) else a.astype(np.float64)
     if "Geopotential Height" in variable_list_df.index:
-        hgt = get("Geopotential Height").astype(np.float64)
+        hgt = f64(get("Geopotential Height"))
     else:
-        hgt = get("Geopotential").astype(np.float64) / G       # -> gpm
+        hgt = f64(get("Geopotential")) / G                     # -> gpm
     val, pos = device_extrema(u, v, hgt, data.lat, data.lon, limits_per_step[t0:t1], device=device, formulation=formulation)
     out = []
     for t in range(t0, t1):

@@ -97,9 +97,14 @@ class BoxData:
             if dTdt is not None:
                 raise NotImplementedError("the device ingest differentiates T in time itself; do not pass a dTdt cube")
             self.ingest_stats = {}
+            # the moving framework's 850-hPa diagnostics take their three slices from the cubes this pass decodes (no second read of the
+            # file); only where the namelist's units leave the values as they are in the file, so that both paths see the same numbers
+            plain_units = all(ds.field_scale(variable_list_df, r) == 1.0 for r in ("Eastward Wind Component", "Northward Wind Component"))
+            keep = 85000.0 if (boxes_limits is not None and plain_units and 85000.0 in data.level) else None
             self.result: LECResult = lec_streamed(data.raw, data.plan, variable_list_df, limits, per_step_boxes=boxes_limits is not None,
                                                   device=dev, chunk_steps=data.chunk_steps, stats=self.ingest_stats, inflate=data.inflate,
-                                                  t_range=None if shard is None else (t0, t1), merge_dropmask=merge, out=out)
+                                                  t_range=None if shard is None else (t0, t1), merge_dropmask=merge, out=out, keep_level=keep)
+            self.level_slices = self.ingest_stats.pop("level_slices", None)
         else:
             self.result = self._compute_resident(data, variable_list_df, dev, dTdt, merge, out)
         if shard is not None:
@@ -350,7 +355,7 @@ def lec_moving(data: ds.LECDataset, variable_list_df: pd.DataFrame, dTdt, result
     from .diagnostics import track_diagnostics
     form = getattr(args, "vorticity_form", None) or "metpy_no_crs"
     positions = track_diagnostics(data, variable_list_df, limits, track, use_track_zeta=bool(getattr(args, "zeta", False)),
-                                  device=_device(args), shard=shard, formulation=form)
+                                  device=_device(args), shard=shard, formulation=form, slices=getattr(box_obj, "level_slices", None))
     phases.mark("track_diagnostics")
     if box_obj.result is None:              # time-sharded run: rank 0 holds the gathered series and writes every file
         return None

@@ -287,8 +287,13 @@ class _ChunkStager:
     ``stage`` / ``upload`` have ``_Stager``'s signatures; the status words of every launch are fetched asynchronously and checked by
     ``check`` (before a slot is reused and at the end of the run): a corrupt chunk raises ``hdf5_lite.Hdf5Error`` naming it."""
 
-    def __init__(self, var: ds.RawVariable, info: dict, steps: int, device, levels: np.ndarray, j0: int, j1: int, slots: int = 2):
+    def __init__(self, var: ds.RawVariable, info: dict, steps: int, device, levels: np.ndarray, j0: int, j1: int, slots: int = 2,
+                 spans: Optional["RegisteredSpans"] = None):
+        """``spans``: the run's RegisteredSpans -- the compressed chunks are then copied to the GPU straight from the mapped FILE's pages
+        (registered with the HIP runtime run by run, released two chunks later): no pinned staging buffers (pinning fresh memory
+        costs ~0.12 s per GB: 1.5 s for the 12 GB a 96-step ERA5 batch wants) and no host copy."""
         self.var, self.info = var, info
+        self.spans, self.use, self.runs = spans, 0, [None] * slots
         self.levels = [int(k) for k in levels]
         self.j0, self.j1 = int(j0), int(j1)
         shape = tuple(int(x) for x in var.data.shape)
@@ -321,7 +326,7 @@ class _ChunkStager:
         self.device = dev
         carrier = {1: torch.int8, 2: torch.int16, 4: torch.int32, 8: torch.int64}[self.itemsize]
         self.raw_dev = [torch.empty((steps, self.step_elems), dtype=carrier, device=dev) for _ in range(slots)]
-        self.comp_pin = [torch.empty(worst, dtype=torch.uint8, pin_memory=True) for _ in range(slots)]
+        self.comp_pin = [None if spans is not None else torch.empty(worst, dtype=torch.uint8, pin_memory=True) for _ in range(slots)]
         self.comp_dev = [torch.empty(worst, dtype=torch.uint8, device=dev) for _ in range(slots)]
         self.inflated = [torch.empty(self.max_chunks[0] * self.slot16 + 16, dtype=torch.uint8, device=dev) for _ in range(slots)]
         # per chunk: the lec_inflate descriptor (4 int64) and the lec_chunk_scatter record (5 int64), one upload
@@ -385,15 +390,19 @@ class _ChunkStager:
         view = self.view
         tail = 4 if self.info.get("fletcher32") else 0           # the checksum bytes after each stream travel with it
         src_off, run_lo, run_len, base, need = chunk_copy_plan(addr, size, tail)
-        if need + 2048 > self.comp_pin[slot].numel():           # larger than the sampled time-chunks (or many gaps): grow this slot's buffers
+        if need + 2048 > self.comp_dev[slot].numel():           # larger than the sampled time-chunks (or many gaps): grow this slot's buffers
             grown = int(1.25 * need) + (4 << 20)                # (its last launch has completed: check() above)
-            self.comp_pin[slot] = torch.empty(grown, dtype=torch.uint8, pin_memory=True)
+            if self.spans is None:
+                self.comp_pin[slot] = torch.empty(grown, dtype=torch.uint8, pin_memory=True)
             self.comp_dev[slot] = torch.empty(grown, dtype=torch.uint8, device=self.device)
-        comp = self.comp_pin[slot].numpy()
         used = need
         piece = 8 << 20
-        jobs = [(comp[d + a: d + min(a + piece, ln)], view[lo + a: lo + min(a + piece, ln)])
-                for lo, ln, d in zip(run_lo.tolist(), run_len.tolist(), base.tolist()) for a in range(0, ln, piece)]
+        self.runs[slot] = (run_lo.tolist(), run_len.tolist(), base.tolist())       # direct mode: upload() copies them from the file's pages
+        jobs = []
+        if self.spans is None:
+            comp = self.comp_pin[slot].numpy()
+            jobs = [(comp[d + a: d + min(a + piece, ln)], view[lo + a: lo + min(a + piece, ln)])
+                    for lo, ln, d in zip(run_lo.tolist(), run_len.tolist(), base.tolist()) for a in range(0, ln, piece)]
         meta = self.meta_pin[slot].numpy()
         desc, recs = meta[: 4 * n].reshape(n, 4), meta[4 * n: 9 * n].reshape(n, 5)
         slots16 = np.arange(n, dtype=np.int64) * self.slot16
@@ -401,7 +410,7 @@ class _ChunkStager:
         recs[:, 0], recs[:, 1:] = slots16, origins
         if len(jobs) == 1:
             np.copyto(*jobs[0])
-        else:
+        elif jobs:
             list(_pool().map(lambda j: np.copyto(*j), jobs))
         at_byte = used
         t_base = tcs[0] * ct
@@ -425,7 +434,15 @@ class _ChunkStager:
         lib = _lib.load()
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         used = nbytes + 1024
-        self.comp_dev[slot][:used].copy_(self.comp_pin[slot][:used], non_blocking=True)
+        if self.spans is None:
+            self.comp_dev[slot][:used].copy_(self.comp_pin[slot][:used], non_blocking=True)
+        else:
+            file0, dst0 = int(self.view.ctypes.data), self.comp_dev[slot].data_ptr()
+            for lo, ln, d in zip(*self.runs[slot]):
+                self.spans.ensure(file0 + lo, file0 + lo + ln, self.use)
+                for a, e in self.spans.pieces(file0 + lo, file0 + lo + ln):
+                    _lib.check(lib.lec_copy_rows_async(C.c_void_p(dst0 + d + (a - file0 - lo)), e - a, C.c_void_p(a), e - a, e - a, 1, stream),
+                               "lec_copy_rows_async")
         self.meta_dev[slot][: 9 * n].copy_(self.meta_pin[slot][: 9 * n], non_blocking=True)
         self.tmap_dev[slot][:n_tmap].copy_(self.tmap_pin[slot][:n_tmap], non_blocking=True)
         desc, recs = self.meta_dev[slot][: 4 * n], self.meta_dev[slot][4 * n: 9 * n]
@@ -468,14 +485,14 @@ class _ChunkStager:
             self.check(slot)
 
 
-def _make_stager(var: ds.RawVariable, steps: int, device, levels, j0: int, j1: int, slots: int, pinned: bool, inflate: str):
+def _make_stager(var: ds.RawVariable, steps: int, device, levels, j0: int, j1: int, slots: int, pinned: bool, inflate: str, spans=None):
     """``inflate``: "device" -- deflated NetCDF-4 variables are inflated on the GPU (error if the variable is not one);
     "host" -- the pure-Python reader's thread pool inflates them; "auto" (default): device where the variable allows it."""
     if inflate not in ("auto", "host", "device"):
         raise ValueError("inflate must be 'auto', 'host' or 'device'")
     info = var.data.chunk_streams() if (inflate != "host" and hasattr(var.data, "chunk_streams")) else None
     if info is not None:
-        return _ChunkStager(var, info, steps, device, levels, j0, j1, slots)
+        return _ChunkStager(var, info, steps, device, levels, j0, j1, slots, spans=spans)
     if inflate == "device":
         raise ValueError("inflate='device' needs a fully written, deflated (optionally shuffled / checksummed) chunked NetCDF-4 variable")
     return _Stager(var, steps, device, levels, j0, j1, slots, pinned=pinned)
@@ -536,7 +553,7 @@ def device_cube(var: ds.RawVariable, plan: IngestPlan, device="cuda:0", unit: fl
 def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_limits, *, per_step_boxes: bool = False,
                  device="cuda:0", chunk_steps: Optional[int] = None, with_q: bool = True, stats: Optional[dict] = None,
                  t_range=None, merge_dropmask=None, out=None, staging: str = "auto", inflate: str = "auto",
-                 slots: Optional[int] = None) -> LECResult:
+                 slots: Optional[int] = None, keep_level: Optional[float] = None) -> LECResult:
     """All LEC terms for the whole series, streamed from the memory-mapped file.
 
     ``boxes_limits``: one (west, east, south, north) in degrees (fixed framework, as inputs/box_limits) or one per time step
@@ -548,6 +565,8 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
     mapped memory and the runtime accepts the first span, else staged (lazily inflated NetCDF-4 variables, hosts that refuse).
     ``inflate``: where deflated NetCDF-4 chunks are inflated -- "device" (``lec_inflate``: the link carries the compressed bytes),
     "host" (the reader's thread pool), "auto" = device wherever the variable allows it (``_make_stager``).
+    ``keep_level`` (Pa): the decoded u, v and geopotential slices of that level are kept on the device for the processed steps (the
+    moving framework's 850-hPa diagnostics: no second pass over the file) -- ``stats["level_slices"]`` = {"u", "v", "geopt"} [steps, lat, lon].
     ``t_range`` = (t0, t1): a rank's share of a time-sharded run -- only those steps (and their one-step T halo) are staged, copied
     and computed, so N ranks move 1/N of the bytes each, over N host links; ``merge_dropmask`` / ``out``: see ``LECEngine.reduce``.
     """
@@ -608,8 +627,6 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
     for r in roles:
         probe[r].var, probe[r].j0, probe[r].j1 = rvars[r], j0, j1
     direct = staging != "staged" and all(probe[r].direct_ok() for r in roles)
-    if staging == "registered" and not direct:
-        raise ValueError("staging='registered' needs every variable as plain (mapped) memory; lazily inflated NetCDF-4 variables are staged")
     spans = RegisteredSpans(lib) if direct else None
     if direct and staging == "auto":            # does this host's runtime register this memory at all?  (one page of the first variable)
         try:
@@ -618,7 +635,25 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
             spans.release(0)
         except _lib.LecLibraryError:
             direct, spans = False, None
-    stagers = {r: _make_stager(rvars[r], span, dev, file_levels, j0, j1, slots, not direct, inflate) for r in roles}
+    # deflated variables: their compressed chunks go out straight from the file's own pages too (one RegisteredSpans for the run)
+    chunked = [r for r in roles if inflate != "host" and getattr(rvars[r].data, "chunk_streams", lambda: None)() is not None]
+    chunk_direct = bool(chunked) and staging != "staged"
+    if chunk_direct and spans is None:
+        try:
+            spans = RegisteredSpans(lib)
+            m0 = int(np.frombuffer(rvars[chunked[0]].data.chunk_streams()["map"], dtype=np.uint8).ctypes.data)
+            spans.ensure(m0, m0 + 1, -1)
+            spans.release(0)
+        except (_lib.LecLibraryError, ValueError, TypeError):
+            chunk_direct, spans = False, None
+    if staging == "registered" and not direct and not (chunk_direct and len(chunked) == len(roles)):
+        raise ValueError("staging='registered' needs every variable as plain (mapped) memory or as device-inflated chunks; variables that are "
+                         "inflated on the host are staged")
+    if not direct and not chunk_direct and chunked:
+        # pinned staging buffers are paid for per byte (pinning): a short series should reuse its slots, not size them for one use each
+        chunk_steps = max(1, min(chunk_steps, max(8, -(-(t1 - t0) // (2 * slots)))))
+        span = chunk_steps + 2
+    stagers = {r: _make_stager(rvars[r], span, dev, file_levels, j0, j1, slots, not direct, inflate, spans if chunk_direct else None) for r in roles}
     cubes = [{keys[r]: torch.empty((span, nl, ny, nx), dtype=out_dtype, device=dev) for r in roles} for _ in range(slots)]
     up = lambda a: torch.as_tensor(a, dtype=torch.int32).to(dev)
     maps = (up(np.searchsorted(file_levels, plan.kmap)), up(plan.jmap - j0), up(plan.imap))   # maps into the staged sub-cube
@@ -632,6 +667,10 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
     # HBM): every chunk's records go through the level half of stage 2 at once and leave 12 KB per step in `levraw`, which is what
     # the any-time NaN mask and the pressure integrals of the WHOLE series need at the end (energy_contents.py:190-208).  One buffer,
     # not one per slot: stage 1 and the level stage of consecutive chunks are on the same stream.
+    keep, k_keep = None, None
+    if keep_level is not None:
+        k_keep = int(np.flatnonzero(plan.level == float(keep_level))[0])
+        keep = {k: torch.empty((t1 - t0, ny, nx), dtype=out_dtype, device=dev) for k in ("u", "v", "geopt")}
     rows = torch.empty((chunk_steps, nl, bt.nyb_max, _lib.LEC_NSTAT), dtype=torch.float64, device=dev)
     levraw = torch.empty((t1 - t0, nl, _lib.LEC_NLEVRAW), dtype=torch.float64, device=dev)
     time_s = plan.time_s
@@ -660,7 +699,7 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
         if used[slot]:
             for ev in copied[slot]:             # the pinned buffers of this slot may be overwritten now: EVERY variable's upload has landed
                 ev.synchronize()                # (they ride on different streams when deflated and plain variables mix: ADVICE r3)
-            if direct:
+            if spans is not None:
                 spans.release(c - slots + 1)    # ... and the file spans only chunks up to c - slots used are no longer being read
         # only T carries the halo; the other fields start at their own first step (rows [c0 - h0, c1 - h0) of the slot)
         span_of = lambda r: (0, h1 - h0) if r == "Air Temperature" else (c0 - h0, c1 - h0)
@@ -674,6 +713,7 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
                 stagers[r].stage(slot, plan.tsel[h0 + a: h0 + b], a)
             host_s += time.perf_counter() - t_host
             up = stagers[r].streams[slot] if hasattr(stagers[r], "streams") else copier   # a deflated variable uploads and inflates on its own stream
+            stagers[r].use = c
             with torch.cuda.stream(up):
                 if used[slot] and (up is not copier or not copier_waited):
                     up.wait_event(consumed[slot])       # the raw device buffers of this slot have been decoded
@@ -694,6 +734,9 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
                              decode[r], common, cubes[slot][keys[r]][a].data_ptr(), compute)
         consumed[slot].record(compute)
         f = {k: t[: h1 - h0] for k, t in cubes[slot].items()}
+        if keep is not None:                    # (u, v, geopotential start at their own first step: rows [c0 - h0, c1 - h0) of the slot)
+            for k in keep:
+                keep[k][c0 - t0: c1 - t0].copy_(cubes[slot][k][c0 - h0: c1 - h0, k_keep])
         part = own_boxes.part(c0 - t0, c1 - t0) if per_step_boxes else fixed_box
         engine.rowstats(f["tair"], f["u"], f["v"], f["omega"], f["geopt"], part,
                         tcoef=tcoef_all[h0:h1] if with_q else None, t_begin=c0 - h0, t_count=c1 - c0, with_q=with_q,
@@ -706,12 +749,14 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
     for r in on_device:
         stagers[r].finish()                     # every chunk inflated (raises otherwise)
         moved += stagers[r].compressed_bytes
-    if direct:
-        copier.synchronize()                    # every copy has read its span
+    if spans is not None:
+        copier.synchronize()                    # every copy has read its span (the deflated variables' streams: finish() above)
         reg_stats = dict(registered_bytes=spans.registered_bytes, register_calls=spans.calls)
         spans.close()
     if stats is not None:
-        stats.update(staging="registered" if direct else "staged", **(reg_stats if direct else {}))
+        stats.update(staging="registered" if (direct or chunk_direct) else "staged", **(reg_stats if spans is not None else {}))
+        if keep is not None:
+            stats["level_slices"] = keep
         stats.update(inflate="device" if on_device else ("host" if any(hasattr(v.data, "chunk_streams") for v in rvars.values()) else "none"))
         stats.update(row_record_bytes=rows.numel() * 8, levraw_bytes=levraw.numel() * 8)
         stats.update(bytes_moved=moved, host_staging_seconds=host_s, chunks=n_chunks, chunk_steps=chunk_steps, storage=str(out_dtype).replace("torch.", ""),
