@@ -246,6 +246,9 @@ def _log_ingest(box_obj, app_logger):
     if st:
         app_logger.info("Device ingest: %.1f MB over the link in %d chunk(s) of %d step(s), staging %s, inflate %s, storage %s" % (
             st["bytes_moved"] / 1e6, st["chunks"], st["chunk_steps"], st["staging"], st.get("inflate", "none"), st["storage"]))
+        if "seconds" in st:
+            app_logger.info("Device ingest seconds: " + ", ".join(f"{k} {v:.3f}" for k, v in st["seconds"].items()) +
+                            (f"; {st['register_calls']} registrations, {st['registered_bytes'] / 1e9:.2f} GB" if "register_calls" in st else ""))
 
 
 def _compute_all(box_obj, method, app_logger):

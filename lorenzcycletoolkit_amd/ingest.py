@@ -115,6 +115,7 @@ class RegisteredSpans:
         self.blocks = []                # [start, end, last_use], sorted, disjoint
         self.registered_bytes = 0
         self.calls = 0
+        self.seconds = 0.0
 
     def ensure(self, lo: int, hi: int, use: int) -> None:
         lo, hi = lo & ~(_PAGE - 1), (hi + _PAGE - 1) & ~(_PAGE - 1)
@@ -128,10 +129,12 @@ class RegisteredSpans:
             at = max(at, b[1])
         if at < hi:
             new.append([at, hi, use])
+        t_reg = time.perf_counter()
         for b in new:
             _lib.check(self.lib.lec_host_register(C.c_void_p(b[0]), b[1] - b[0]), "lec_host_register")
             self.registered_bytes += b[1] - b[0]
             self.calls += 1
+        self.seconds += time.perf_counter() - t_reg
         if new:
             self.blocks = sorted(self.blocks + new)
 
@@ -438,8 +441,21 @@ class _ChunkStager:
             self.comp_dev[slot][:used].copy_(self.comp_pin[slot][:used], non_blocking=True)
         else:
             file0, dst0 = int(self.view.ctypes.data), self.comp_dev[slot].data_ptr()
+            # registrations cost ~1 ms each: a latitude band out of a global file is thousands of 0.5-MB runs with the other bands'
+            # chunks between them -- runs less than 4 MiB apart are registered as one span (the bytes between are pinned, not copied)
+            order = sorted(range(len(self.runs[slot][0])), key=lambda q: self.runs[slot][0][q])
+            glo = ghi = None
+            for q in order:
+                lo, hi = file0 + self.runs[slot][0][q], file0 + self.runs[slot][0][q] + self.runs[slot][1][q]
+                if glo is not None and lo - ghi <= (4 << 20):
+                    ghi = max(ghi, hi)
+                    continue
+                if glo is not None:
+                    self.spans.ensure(glo, ghi, self.use)
+                glo, ghi = lo, hi
+            if glo is not None:
+                self.spans.ensure(glo, ghi, self.use)
             for lo, ln, d in zip(*self.runs[slot]):
-                self.spans.ensure(file0 + lo, file0 + lo + ln, self.use)
                 for a, e in self.spans.pieces(file0 + lo, file0 + lo + ln):
                     _lib.check(lib.lec_copy_rows_async(C.c_void_p(dst0 + d + (a - file0 - lo)), e - a, C.c_void_p(a), e - a, e - a, 1, stream),
                                "lec_copy_rows_async")
@@ -574,6 +590,7 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
     dev = torch.device(device)
     if dev.type != "cuda":
         raise _lib.LecLibraryError("the device ingest needs a GPU: there is no CPU path")
+    t_enter = time.perf_counter()
     engine = LECEngine(plan.lat, plan.lon, plan.level, device=dev)
     nt, nl, ny, nx = len(plan.tsel), plan.level.size, plan.lat.size, plan.lon.size
     boxes = [engine.box_from_limits(*lim) for lim in boxes_limits]
@@ -676,6 +693,7 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
     time_s = plan.time_s
     phi_scale = ds.field_scale(variable_list_df, geo_role)
 
+    t_setup = time.perf_counter()               # (tables, staging / device buffers allocated)
     compute = torch.cuda.current_stream(dev)
     copier = torch.cuda.Stream(device=dev)
     copied = [[torch.cuda.Event() for _ in roles] for _ in range(slots)]      # the variable's upload of the slot has landed
@@ -743,6 +761,7 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
                         rows_out=rows[: c1 - c0], per_step_boxes=per_step_boxes)
         engine.level_stage(rows[: c1 - c0], part, levraw[c0 - t0: c1 - t0], phi_scale=phi_scale)
         used[slot] = True
+    t_loop = time.perf_counter()                # (every chunk enqueued)
     res = engine.vertical_stage(levraw, own_boxes if per_step_boxes else fixed_box, drop_any_time=not per_step_boxes,
                                 merge_dropmask=merge_dropmask, out=out)
     on_device = [r for r in roles if isinstance(stagers[r], _ChunkStager)]
@@ -759,6 +778,9 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
             stats["level_slices"] = keep
         stats.update(inflate="device" if on_device else ("host" if any(hasattr(v.data, "chunk_streams") for v in rvars.values()) else "none"))
         stats.update(row_record_bytes=rows.numel() * 8, levraw_bytes=levraw.numel() * 8)
+        torch.cuda.synchronize(dev)
+        stats.update(seconds=dict(setup=t_setup - t_enter, chunk_loop_host=t_loop - t_setup, drain=time.perf_counter() - t_loop,
+                                  registering=(spans.seconds if spans is not None else 0.0)))
         stats.update(bytes_moved=moved, host_staging_seconds=host_s, chunks=n_chunks, chunk_steps=chunk_steps, storage=str(out_dtype).replace("torch.", ""),
                      decode={keys[r]: str(d) for r, d in decode.items()}, box=tuple(int(x) for x in boxes[0]), domain=(nt, nl, ny, nx))
     return res

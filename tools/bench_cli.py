@@ -53,7 +53,7 @@ def run_case(workdir, argv, label, env_extra=None, timeout=1500):
         out["phases_frac"] = {k: v / (t1 - t0) for k, v in phases.items()}
     except Exception as e:       # noqa: BLE001
         out["phases_error"] = repr(e)
-    logs = [ln for ln in (r.stdout + r.stderr).splitlines() if "framework ran in" in ln or "Device ingest:" in ln]
+    logs = [ln for ln in (r.stdout + r.stderr).splitlines() if "framework ran in" in ln or "Device ingest" in ln]
     out["log"] = [ln.split(" - ", 3)[-1] for ln in logs]
     n_csv = sum(len(f) for _, _, f in os.walk(os.path.join(workdir, "LEC_Results")))
     out["files_written"] = n_csv
