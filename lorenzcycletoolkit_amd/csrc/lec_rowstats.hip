@@ -385,7 +385,9 @@ extern "C" int lec_rowstats(const lec_rowstats_args* a) {
     const bool block_ok = fixed_time_stencil && a->geopt_d && a->t_count >= 2;
     if (kernel == LEC_KERNEL_AUTO) {
         if (a->box_per_step) kernel = LEC_KERNEL_BOX_TILE;
-        else if (block_ok && a->dtype == LEC_F64 && tu.order == LEC_ORDER_AUTO) kernel = LEC_KERNEL_ROW_BLOCK;
+        // (stretched longitudes: the row-block instantiation carries per-column weight / gradient tables on top of its block state and
+        // spills 28-44 B; one wave per row is 5 % ahead there -- 22.4-23.3 vs 23.7-25.1 ms per 64 steps, profiles/r04_notes.md section 7)
+        else if (block_ok && a->dtype == LEC_F64 && tu.order == LEC_ORDER_AUTO && uni) kernel = LEC_KERNEL_ROW_BLOCK;
         else kernel = LEC_KERNEL_ROW_SWEEP;
     }
     if (kernel == LEC_KERNEL_ROW_BLOCK && !block_ok) kernel = LEC_KERNEL_ROW_SWEEP;       // a one-step shard of a row-block series: same bits

@@ -75,6 +75,34 @@ def prepare_streamed(args, varlist: str = "inputs/namelist", app_logger=None, ch
     return StreamedDataset(raw, make_plan(raw, args, app_logger), chunk_steps, getattr(args, "inflate", None) or "auto")
 
 
+def prefers_device_ingest(args, varlist: str = "inputs/namelist") -> bool:
+    """--ingest auto: True for a chunked NetCDF-4 file with at least one DEFLATED field variable, every field variable of which the
+    device can take as it lies in the file (``H5Variable.chunk_streams``: fully written, filters within shuffle / deflate /
+    fletcher32) -- there the host path inflates on the host's threads, ten times slower than the GPU does (profiles/r04_notes.md
+    section 6).  Anything else (classic NetCDF, uncompressed or partly written files, other axis orders, a framework the streamed
+    path does not serve) keeps the host preparation.  Never raises: a file that cannot be judged is left to the host path's messages."""
+    if not (getattr(args, "fixed", False) or getattr(args, "track", False)) or getattr(args, "cdsapi", False):
+        return False
+    try:
+        with open(args.infile, "rb") as fh:
+            if fh.read(8) != b"\x89HDF\r\n\x1a\n":
+                return False
+        raw = ds.open_raw(args.infile, ds.read_namelist(varlist), mpas=bool(getattr(args, "mpas", False)))
+    except Exception:       # noqa: BLE001
+        return False
+    try:
+        deflated = False
+        for v in raw.variables.values():
+            if not hasattr(v.data, "chunk_streams") or v.data.chunk_streams() is None:
+                return False
+            deflated = deflated or any(fid == 1 for fid, _cd in getattr(v.data, "_filters", []))
+        return deflated
+    except Exception:       # noqa: BLE001
+        return False
+    finally:
+        raw.close()
+
+
 def _src_code(dtype: np.dtype) -> int:
     if dtype.kind == "i" and dtype.itemsize in (1, 2, 4):
         return {1: _lib.LEC_I8, 2: _lib.LEC_I16, 4: _lib.LEC_I32}[dtype.itemsize]

@@ -207,8 +207,9 @@ def test_deflated_netcdf4_file_through_the_cli(workdir):
     for flag, name in (("-f", "fixed"), ("-t", "track")):
         results = workdir / "LEC_Results" / f"packed_chunked_tracked_{name}"
         _fresh(results)
-        _run([src, "-r", flag])
+        _run([src, "-r", flag, "--ingest", "host"])
         one = _tree(results)
+        assert "being inflated on the host" in open(results / "log.packed_chunked_tracked").read()
         df = pd.read_csv(results / f"packed_chunked_tracked_{name}_results.csv", index_col=0)
         assert len(df) == (5 if name == "fixed" else 4) and np.isfinite(df[["Az", "Ae", "Kz", "Ke"]].values).all()
         _fresh(results)
@@ -222,6 +223,11 @@ def test_deflated_netcdf4_file_through_the_cli(workdir):
         _fresh(results)
         _run([src, "-r", flag, "--device-ingest", "--gpus", "2"])
         _same_tree(one, _tree(results), f"{name}: --device-ingest on 2 ranks")
+        _fresh(results)
+        _run([src, "-r", flag])                                    # --ingest auto (the default): a deflated file goes to the device by itself
+        _same_tree(one, _tree(results), f"{name}: default ingest")
+        log = open(results / "log.packed_chunked_tracked").read()
+        assert "whose chunks the GPU can inflate" in log and "inflate device" in log
 
 
 def test_cds_new_layout_through_the_cli(workdir):
@@ -238,7 +244,7 @@ def test_cds_new_layout_through_the_cli(workdir):
     for flag, name in (("-f", "fixed"), ("-t", "track")):
         results = workdir / "LEC_Results" / f"cds_new_layout_{name}"
         _fresh(results)
-        _run([src, "-r", flag])
+        _run([src, "-r", flag, "--ingest", "host"])
         one = _tree(results)
         df = pd.read_csv(results / f"cds_new_layout_{name}_results.csv", index_col=0)
         assert len(df) == (6 if name == "fixed" else 5) and np.isfinite(df[["Az", "Ae", "Kz", "Ke", "Cz", "Ca", "Ck", "Ce"]].values).all()
@@ -254,8 +260,12 @@ def test_cds_new_layout_through_the_cli(workdir):
         _run([src, "-r", flag, "--device-ingest", "--gpus", "2"])
         _same_tree(one, _tree(results), f"{name}: --device-ingest on 2 ranks")
         _fresh(results)
-        _run([src, "-r", flag, "--gpus", "2", "-m"])              # --mpas: nothing on `standard_height` here, same files
+        _run([src, "-r", flag, "--gpus", "2", "-m", "--ingest", "host"])      # --mpas: nothing on `standard_height` here, same files
         _same_tree(one, _tree(results), f"{name}: resident on 2 ranks with --mpas")
+        _fresh(results)
+        _run([src, "-r", flag])                                    # the default: --ingest auto takes the device for this file
+        _same_tree(one, _tree(results), f"{name}: default ingest")
+        assert "inflate device" in open(results / "log.cds_new_layout").read()
     from oracle import cf_decode as cf
     from oracle import lec_oracle as o
     from tests.helpers import as_f64

@@ -92,8 +92,8 @@ def main():
         shutil.copy(os.path.join(golden, "inputs", "track_testdata_NCEP-R2"), os.path.join(wd, "inputs", "track"))
         cat, tst = os.path.join(golden, "Catarina_NCEP-R2.nc"), os.path.join(golden, "testdata_NCEP-R2.nc")
         for rep in ("first", "second"):
-            for label, argv in (("catarina_fixed_resident", [cat, "-r", "-f"]), ("catarina_fixed_device_ingest", [cat, "-r", "-f", "--device-ingest"]),
-                                ("testdata_track_resident", [tst, "-r", "-t"]), ("testdata_track_device_ingest", [tst, "-r", "-t", "--device-ingest"])):
+            for label, argv in (("catarina_fixed_resident", [cat, "-r", "-f", "--ingest", "host"]), ("catarina_fixed_device_ingest", [cat, "-r", "-f", "--device-ingest"]),
+                                ("testdata_track_resident", [tst, "-r", "-t", "--ingest", "host"]), ("testdata_track_device_ingest", [tst, "-r", "-t", "--device-ingest"])):
                 results["cases"].append(run_case(wd, argv, f"{label}:{rep}"))
                 print(json.dumps(results["cases"][-1])[:400], flush=True)
                 save()
@@ -139,7 +139,9 @@ def main():
                                 save()
                         # the host-prepared path on the regional box (inflates the band's chunks on 16 host threads), warm cache
                         open(os.path.join(wd, "inputs", "box_limits"), "w").write(plans[0][1])
-                        results["cases"].append(run_case(wd, [big, "-r", "-f"], "big:regional_box_fixed:resident_host_prepared:warm", timeout=900))
+                        results["cases"].append(run_case(wd, [big, "-r", "-f", "--ingest", "host"], "big:regional_box_fixed:resident_host_prepared:warm", timeout=900))
+                        print(json.dumps(results["cases"][-1])[:600], flush=True)
+                        results["cases"].append(run_case(wd, [big, "-r", "-f"], "big:regional_box_fixed:default_flags:warm", timeout=900))
                         print(json.dumps(results["cases"][-1])[:600], flush=True)
                         save()
                 finally:
