@@ -292,3 +292,24 @@ def test_mpas_flag_drops_the_standard_height_variables(cds_workdir):
     args.mpas = False
     b = ds.prepare_data(args, "inputs/namelist")
     assert all(np.array_equal(a.variables[k], b.variables[k], equal_nan=True) for k in b.variables) and any("no variable uses it" in r for r in records)
+
+
+def test_ingest_auto_takes_the_device_for_deflated_files_only(workdir, golden_dir):
+    """`--ingest auto` (the command line's default): the streamed device path for a chunked NetCDF-4 file with deflated field variables
+    the GPU can inflate as they lie in the file; the host preparation for everything else -- classic NetCDF, contiguous or chunked-
+    but-uncompressed HDF5, a framework the streamed path does not serve, a file that cannot be opened."""
+    ns = lambda path, **kw: argparse.Namespace(infile=path, fixed=True, track=False, trackfile=None, cdsapi=False, mpas=False, **kw)
+    want = {"packed_chunked_earliest.nc": True, "packed_chunked_tracked.nc": True, "packed_unlimited_latest.nc": True,
+            "packed_interleaved_v18.nc": True, "float_chunked_latest.nc": True,
+            "float_contiguous_latest.nc": False, "float_chunked_plain_latest.nc": False, "packed_shuffle_only_v18.nc": False}
+    for name, expect in want.items():
+        assert ingest.prefers_device_ingest(ns(os.path.join(FIX, name)), "inputs/namelist") is expect, name
+    assert ingest.prefers_device_ingest(ns(os.path.join(golden_dir, "Catarina_NCEP-R2.nc")), "inputs/namelist") is False      # classic NetCDF
+    assert ingest.prefers_device_ingest(ns(str(workdir / "missing.nc")), "inputs/namelist") is False
+    a = ns(os.path.join(FIX, "packed_chunked_earliest.nc"))
+    a.fixed = False                                              # -c / neither framework: the streamed path serves -f and -t only
+    assert ingest.prefers_device_ingest(a, "inputs/namelist") is False
+    import lorenzcycletoolkit as cli
+    args = cli.create_arg_parser().parse_args(["x.nc", "-r", "-f"])
+    assert args.ingest == "auto" and args.device_ingest is False
+    assert cli.create_arg_parser().parse_args(["x.nc", "-r", "-f", "--ingest", "host"]).ingest == "host"
