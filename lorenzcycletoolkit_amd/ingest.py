@@ -428,9 +428,11 @@ class _ChunkStager:
             self.comp_dev[slot] = torch.empty(grown, dtype=torch.uint8, device=self.device)
         used = need
         piece = 8 << 20
-        self.runs[slot] = (run_lo.tolist(), run_len.tolist(), base.tolist())       # direct mode: upload() copies them from the file's pages
+        self.runs[slot] = (run_lo.tolist(), run_len.tolist(), base.tolist()) if self.spans is not None else None    # direct mode: upload() copies them
         jobs = []
         if self.spans is None:
+            if self.comp_pin[slot] is None or self.comp_pin[slot].numel() < self.comp_dev[slot].numel():      # (a run that fell back from direct copies)
+                self.comp_pin[slot] = torch.empty(self.comp_dev[slot].numel(), dtype=torch.uint8, pin_memory=True)
             comp = self.comp_pin[slot].numpy()
             jobs = [(comp[d + a: d + min(a + piece, ln)], view[lo + a: lo + min(a + piece, ln)])
                     for lo, ln, d in zip(run_lo.tolist(), run_len.tolist(), base.tolist()) for a in range(0, ln, piece)]
@@ -456,6 +458,28 @@ class _ChunkStager:
         self.staged[slot] = (n, at_byte, t_base, n_tmap, origins)
         self.compressed_bytes += at_byte
 
+    def _copy_from_file(self, lib, slot: int, stream) -> None:
+        """The slot's runs of compressed chunks, file pages -> device, no host copy."""
+        file0, dst0 = int(self.view.ctypes.data), self.comp_dev[slot].data_ptr()
+        # registrations cost ~1 ms each: a latitude band out of a global file is thousands of 0.5-MB runs with the other bands'
+        # chunks between them -- runs less than 4 MiB apart are registered as one span (the bytes between are pinned, not copied)
+        order = sorted(range(len(self.runs[slot][0])), key=lambda q: self.runs[slot][0][q])
+        glo = ghi = None
+        for q in order:
+            lo, hi = file0 + self.runs[slot][0][q], file0 + self.runs[slot][0][q] + self.runs[slot][1][q]
+            if glo is not None and lo - ghi <= (4 << 20):
+                ghi = max(ghi, hi)
+                continue
+            if glo is not None:
+                self.spans.ensure(glo, ghi, self.use)
+            glo, ghi = lo, hi
+        if glo is not None:
+            self.spans.ensure(glo, ghi, self.use)
+        for lo, ln, d in zip(*self.runs[slot]):
+            for a, e in self.spans.pieces(file0 + lo, file0 + lo + ln):
+                _lib.check(lib.lec_copy_rows_async(C.c_void_p(dst0 + d + (a - file0 - lo)), e - a, C.c_void_p(a), e - a, e - a, 1, stream),
+                           "lec_copy_rows_async")
+
     def upload(self, slot: int, a: int, b: int):
         """Enqueued on the current stream: compressed bytes + descriptors to the device, inflate, scatter into rows [a, b)."""
         st = self.staged[slot]
@@ -465,28 +489,22 @@ class _ChunkStager:
         lib = _lib.load()
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         used = nbytes + 1024
+        if self.spans is not None:
+            try:
+                self._copy_from_file(lib, slot, stream)
+            except _lib.LecLibraryError:
+                # the runtime refused a registration in mid-run (a locked-memory limit, say): this variable goes on through pinned
+                # staging buffers -- the spans registered so far stay with the run's RegisteredSpans and are released by it
+                self.spans = None
         if self.spans is None:
+            if self.comp_pin[slot] is None or self.comp_pin[slot].numel() < self.comp_dev[slot].numel():
+                self.comp_pin[slot] = torch.empty(self.comp_dev[slot].numel(), dtype=torch.uint8, pin_memory=True)
+            if self.runs[slot] is not None:              # staged for a direct copy: do the host copy now
+                comp, view, piece = self.comp_pin[slot].numpy(), self.view, 8 << 20
+                jobs = [(comp[d + q: d + min(q + piece, ln)], view[lo + q: lo + min(q + piece, ln)])
+                        for lo, ln, d in zip(*self.runs[slot]) for q in range(0, ln, piece)]
+                list(_pool().map(lambda j: np.copyto(*j), jobs))
             self.comp_dev[slot][:used].copy_(self.comp_pin[slot][:used], non_blocking=True)
-        else:
-            file0, dst0 = int(self.view.ctypes.data), self.comp_dev[slot].data_ptr()
-            # registrations cost ~1 ms each: a latitude band out of a global file is thousands of 0.5-MB runs with the other bands'
-            # chunks between them -- runs less than 4 MiB apart are registered as one span (the bytes between are pinned, not copied)
-            order = sorted(range(len(self.runs[slot][0])), key=lambda q: self.runs[slot][0][q])
-            glo = ghi = None
-            for q in order:
-                lo, hi = file0 + self.runs[slot][0][q], file0 + self.runs[slot][0][q] + self.runs[slot][1][q]
-                if glo is not None and lo - ghi <= (4 << 20):
-                    ghi = max(ghi, hi)
-                    continue
-                if glo is not None:
-                    self.spans.ensure(glo, ghi, self.use)
-                glo, ghi = lo, hi
-            if glo is not None:
-                self.spans.ensure(glo, ghi, self.use)
-            for lo, ln, d in zip(*self.runs[slot]):
-                for a, e in self.spans.pieces(file0 + lo, file0 + lo + ln):
-                    _lib.check(lib.lec_copy_rows_async(C.c_void_p(dst0 + d + (a - file0 - lo)), e - a, C.c_void_p(a), e - a, e - a, 1, stream),
-                               "lec_copy_rows_async")
         self.meta_dev[slot][: 9 * n].copy_(self.meta_pin[slot][: 9 * n], non_blocking=True)
         self.tmap_dev[slot][:n_tmap].copy_(self.tmap_pin[slot][:n_tmap], non_blocking=True)
         desc, recs = self.meta_dev[slot][: 4 * n], self.meta_dev[slot][4 * n: 9 * n]

@@ -398,3 +398,37 @@ def test_inflate_and_slot_arguments_are_validated(workdir, golden_dir):
     b = ingest.lec_streamed(raw, plan, df, limits, slots=4, chunk_steps=3)
     assert torch.equal(a.scalars, b.scalars) and torch.equal(a.levels, b.levels)
     raw.close()
+
+
+def test_registration_refused_in_mid_run_falls_back_to_pinned_staging(workdir, monkeypatch):
+    """The compressed chunks of a deflated NetCDF-4 file go to the GPU straight from the registered file pages; when the runtime refuses
+    a registration in mid-run (a locked-memory limit), the variable goes on through pinned staging buffers: same bits, no error."""
+    from lorenzcycletoolkit_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    (workdir / "inputs" / "namelist").write_text(
+        ";Variable;Units\nAir Temperature;t;K\nGeopotential;z;m**2/s**2\nOmega Velocity;w;Pa/s\n"
+        "Eastward Wind Component;u;m/s\nNorthward Wind Component;v;m/s\nLongitude;longitude\nLatitude;latitude\n"
+        "Time;time\nVertical Level;level\n")
+    (workdir / "inputs" / "box_limits").write_text("min_lon;-60\nmax_lon;30\nmin_lat;-40\nmax_lat;30\n")
+    args = argparse.Namespace(fixed=True, track=False, trackfile=None)
+    df = ds.read_namelist("inputs/namelist")
+    raw = ds.open_raw(os.path.join(root, "tests", "golden", "hdf5", "packed_interleaved_v18.nc"), df)
+    plan = ingest.make_plan(raw, args)
+    lim = [(-60.0, 30.0, -40.0, 30.0)]
+    st = {}
+    ref = ingest.lec_streamed(raw, plan, df, lim, chunk_steps=1, stats=st)
+    assert st["staging"] == "registered" and st["inflate"] == "device" and st["register_calls"] >= 1
+    staged = ingest.lec_streamed(raw, plan, df, lim, chunk_steps=1, staging="staged")
+    real, calls = ingest.RegisteredSpans.ensure, [0]
+
+    def flaky(self, lo, hi, use):
+        calls[0] += 1
+        if calls[0] > 4:
+            raise _lib.LecLibraryError("lec_host_register failed (code 3): out of locked memory (simulated)")
+        return real(self, lo, hi, use)
+    monkeypatch.setattr(ingest.RegisteredSpans, "ensure", flaky)
+    got = ingest.lec_streamed(raw, plan, df, lim, chunk_steps=1)
+    assert calls[0] > 4
+    for r in (staged, got):
+        assert torch.equal(r.scalars, ref.scalars) and torch.equal(r.levels, ref.levels) and torch.equal(r.nanflag, ref.nanflag)
+    raw.close()
