@@ -429,6 +429,7 @@ def test_registration_refused_in_mid_run_falls_back_to_pinned_staging(workdir, m
     monkeypatch.setattr(ingest.RegisteredSpans, "ensure", flaky)
     got = ingest.lec_streamed(raw, plan, df, lim, chunk_steps=1)
     assert calls[0] > 4
+    same = lambda a, b: bool(((a == b) | (torch.isnan(a) & torch.isnan(b))).all())      # (a dropped level is a NaN column of the tables)
     for r in (staged, got):
-        assert torch.equal(r.scalars, ref.scalars) and torch.equal(r.levels, ref.levels) and torch.equal(r.nanflag, ref.nanflag)
+        assert same(r.scalars, ref.scalars) and same(r.levels, ref.levels) and torch.equal(r.nanflag, ref.nanflag)
     raw.close()
