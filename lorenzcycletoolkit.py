@@ -52,7 +52,8 @@ def create_arg_parser():
     parser.add_argument("--ingest", choices=["auto", "host", "device"], default="auto", help="where the data are prepared: 'host' decodes, sorts "
                         "and crops with NumPy and uploads the cubes; 'device' streams the file's bytes and does it on the GPU; 'auto' (default) "
                         "takes the device for deflated NetCDF-4 files whose chunks the GPU can inflate (the host inflates them ten times "
-                        "slower) and the host otherwise -- the output files are the same, byte for byte")
+                        "slower) and for any file of 1 GiB or more that the streamed path can read, the host otherwise -- the output files "
+                        "are the same, byte for byte")
     parser.add_argument("--inflate", choices=["auto", "host", "device"], default="auto", help="with --device-ingest and a chunked NetCDF-4 file: where "
                         "the (deflated) chunks are inflated -- on the GPU (lec_inflate; the default wherever the variables allow it) or on the host's threads")
     parser.add_argument("--vorticity-form", choices=["metpy_no_crs", "spherical"], default="metpy_no_crs", help="with -t: formulation of the 850-hPa "
@@ -154,8 +155,8 @@ def main(argv=None):
             from lorenzcycletoolkit_amd.ingest import prefers_device_ingest
             args.device_ingest = prefers_device_ingest(args, "inputs/namelist")
             if args.device_ingest:
-                app_logger.info("The input is a deflated NetCDF-4 file whose chunks the GPU can inflate: streaming it (--ingest device); "
-                                "--ingest host prepares the data on the host instead (same results)")
+                app_logger.info("The input is a deflated NetCDF-4 file whose chunks the GPU can inflate, or a large file: streaming it to the "
+                                "GPU (--ingest device); --ingest host prepares the data on the host instead (same results)")
         if args.device_ingest:
             from lorenzcycletoolkit_amd.ingest import prepare_streamed
             data = prepare_streamed(args, "inputs/namelist", app_logger)

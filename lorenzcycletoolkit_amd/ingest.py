@@ -75,22 +75,33 @@ def prepare_streamed(args, varlist: str = "inputs/namelist", app_logger=None, ch
     return StreamedDataset(raw, make_plan(raw, args, app_logger), chunk_steps, getattr(args, "inflate", None) or "auto")
 
 
+AUTO_DEVICE_BYTES = 1 << 30      # --ingest auto: files from this size on are streamed to the device whatever their container
+
+
 def prefers_device_ingest(args, varlist: str = "inputs/namelist") -> bool:
-    """--ingest auto: True for a chunked NetCDF-4 file with at least one DEFLATED field variable, every field variable of which the
-    device can take as it lies in the file (``H5Variable.chunk_streams``: fully written, filters within shuffle / deflate /
-    fletcher32) -- there the host path inflates on the host's threads, ten times slower than the GPU does (profiles/r04_notes.md
-    section 6).  Anything else (classic NetCDF, uncompressed or partly written files, other axis orders, a framework the streamed
-    path does not serve) keeps the host preparation.  Never raises: a file that cannot be judged is left to the host path's messages."""
+    """--ingest auto.  True (stream the file's bytes and prepare them on the GPU) for
+      * a chunked NetCDF-4 file with at least one DEFLATED field variable, every field variable of which the device can take as it
+        lies in the file (``H5Variable.chunk_streams``: fully written, filters within shuffle / deflate / fletcher32): the host path
+        inflates on the host's threads, ten times slower than the GPU does (profiles/r04_notes.md section 6);
+      * any file of ``AUTO_DEVICE_BYTES`` (1 GiB) or more that the streamed path can read (variables in (time, level, lat, lon) order,
+        int8 / int16 / int32 / float32 / float64): the host preparation decodes, sorts and crops the whole data set with NumPy before a
+        byte reaches the GPU, the device ingest moves the file's bytes at the link's rate.
+    False (prepare on the host) for everything else: small files, other axis orders, a framework the streamed path does not serve.
+    Never raises: a file that cannot be judged is left to the host path's messages.  Either way the output files are the same."""
     if not (getattr(args, "fixed", False) or getattr(args, "track", False)) or getattr(args, "cdsapi", False):
         return False
     try:
         with open(args.infile, "rb") as fh:
-            if fh.read(8) != b"\x89HDF\r\n\x1a\n":
-                return False
+            hdf5 = fh.read(8) == b"\x89HDF\r\n\x1a\n"
+        big = os.path.getsize(args.infile) >= AUTO_DEVICE_BYTES
+        if not (hdf5 or big):
+            return False
         raw = ds.open_raw(args.infile, ds.read_namelist(varlist), mpas=bool(getattr(args, "mpas", False)))
     except Exception:       # noqa: BLE001
         return False
     try:
+        if big:
+            return True
         deflated = False
         for v in raw.variables.values():
             if not hasattr(v.data, "chunk_streams") or v.data.chunk_streams() is None:

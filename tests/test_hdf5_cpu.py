@@ -306,6 +306,13 @@ def test_ingest_auto_takes_the_device_for_deflated_files_only(workdir, golden_di
         assert ingest.prefers_device_ingest(ns(os.path.join(FIX, name)), "inputs/namelist") is expect, name
     assert ingest.prefers_device_ingest(ns(os.path.join(golden_dir, "Catarina_NCEP-R2.nc")), "inputs/namelist") is False      # classic NetCDF
     assert ingest.prefers_device_ingest(ns(str(workdir / "missing.nc")), "inputs/namelist") is False
+    # any readable file from AUTO_DEVICE_BYTES on, whatever its container
+    big = ns(os.path.join(golden_dir, "Catarina_NCEP-R2.nc"))
+    import unittest.mock as mock
+    with mock.patch.object(ingest, "AUTO_DEVICE_BYTES", 1000):
+        assert ingest.prefers_device_ingest(big, os.path.join(golden_dir, "inputs", "namelist_NCEP-R2")) is True
+        assert ingest.prefers_device_ingest(big, "inputs/namelist") is False          # (this namelist names other variables: left to the host path's messages)
+        assert ingest.prefers_device_ingest(ns(os.path.join(FIX, "float_contiguous_latest.nc")), "inputs/namelist") is True
     a = ns(os.path.join(FIX, "packed_chunked_earliest.nc"))
     a.fixed = False                                              # -c / neither framework: the streamed path serves -f and -t only
     assert ingest.prefers_device_ingest(a, "inputs/namelist") is False

@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--big-dir", default=os.environ.get("TMPDIR", "/tmp"))
     ap.add_argument("--skip-big", action="store_true")
     ap.add_argument("--layout", default="era5_int16")
+    ap.add_argument("--classic-steps", type=int, default=24, help="also time an uncompressed CLASSIC NetCDF file of this many ERA5-size steps (0 = skip)")
     a = ap.parse_args()
     results = {"host": {"cpus": os.cpu_count()}, "cases": []}
     golden = os.path.join(ROOT, "tests", "golden")
@@ -147,6 +148,30 @@ def main():
                 finally:
                     if os.path.exists(big):
                         os.remove(big)
+    if not a.skip_big and a.classic_steps > 0:
+        big = os.path.join(a.big_dir, f"era5_classic_T{a.classic_steps}.nc")
+        t0 = time.time()
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_big_classic.py"), "--out", big, "--timesteps", str(a.classic_steps)],
+                           capture_output=True, text=True)
+        results["classic_file"] = {"path": big, "write_s": time.time() - t0, "note": r.stdout.strip()[-400:], "returncode": r.returncode, "stderr": r.stderr[-400:]}
+        print(results["classic_file"], flush=True)
+        save()
+        if r.returncode == 0:
+            try:
+                with tempfile.TemporaryDirectory() as wd:
+                    os.makedirs(os.path.join(wd, "inputs"))
+                    open(os.path.join(wd, "inputs", "namelist"), "w").write(NAMELIST_ERA5)
+                    open(os.path.join(wd, "inputs", "box_limits"), "w").write("min_lon;-80\nmax_lon;-20\nmin_lat;-60\nmax_lat;-10\n")
+                    for label, extra in (("default_flags", []), ("ingest_host", ["--ingest", "host"])):
+                        for cache in ("cold", "warm"):
+                            if cache == "cold":
+                                drop_cache(big)
+                            results["cases"].append(run_case(wd, [big, "-r", "-f"] + extra, f"classic:regional_box_fixed:{label}:{cache}", timeout=900))
+                            print(json.dumps(results["cases"][-1])[:600], flush=True)
+                            save()
+            finally:
+                if os.path.exists(big):
+                    os.remove(big)
     save()
     print("written", a.out)
 
