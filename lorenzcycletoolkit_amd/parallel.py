@@ -424,6 +424,8 @@ def ranks_and_devices(device, group=None) -> dict:
             ident["uuid"] = str(uuid)
     idents = [None] * dist.get_world_size(group)
     dist.all_gather_object(idents, ident, group=group)
-    keys = [(d["host"], d.get("uuid") or d["pci"] or d["device_index"]) for d in idents]
+    # two ranks drive one GPU only if EVERYTHING that names it agrees (a runtime that reports the same UUID for every card must not
+    # make distinct device indices / bus ids look like one GPU)
+    keys = [(d["host"], d["device_index"], d["pci"], d.get("uuid")) for d in idents]
     return {"ranks_seen": int(one.item()), "world_size": dist.get_world_size(group), "backend": backend, "devices": idents,
             "devices_distinct": len(set(keys)) == len(keys)}
