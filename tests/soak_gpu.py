@@ -90,6 +90,11 @@ def one_case(rng, case, with_oracle):
         err = rows_close(r, auto)
         if not err <= 2e-11:
             fails.append(f"{what}: {fam} differs from the default family by {err:.3e}")
+    if moving:      # time groups of the box-tile kernel (waves of consecutive steps share T through LDS on the union of their boxes): no bit may move
+        for tg in (2, 4):
+            r = eng.compute(*f, boxes, tuning={"kernel": "box_tile", "block_shape": tg}, **kw)
+            if not (same_bits(r.rows[..., :28], auto.rows[..., :28]) and same_bits(r.scalars, auto.scalars)):
+                fails.append(f"{what}: box_tile with time groups of {tg} is not bit-identical to the default")
     # shards of the series: bit-identical
     if nt >= 3:
         a, b = 1, nt - 1
