@@ -192,7 +192,14 @@ __global__ void __launch_bounds__(64 * TG, 2) lec_boxtile_kernel(const RowParams
             imin = min(imin, p.box[4 * b + 0]); imax = max(imax, p.box[4 * b + 1]);
             jmin = min(jmin, p.box[4 * b + 2]); jmax = max(jmax, p.box[4 * b + 3]);
         }
+        // the row blocks of a sharing group start at the union's first row: every step's records -- nyb_max rows, the padding rows of a
+        // lower box included (they are written as zeros, stage 2 relies on it) -- must still lie inside the launch's blocks
         shared = (imax - imin + 1 <= kCW) && (jmax - jmin + 1 <= n_rb * kWR);
+#pragma unroll
+        for (int g = 0; g < TG; ++g) {
+            const int b = (p.n_box == 1) ? 0 : min(grp * TG + g, p.t_count - 1);
+            shared = shared && (p.box[4 * b + 2] - jmin + p.nyb_max <= n_rb * kWR);
+        }
         if (shared) { i0 = imin; j0 = jmin; uw = imax - imin + 1; ujn = jmax - jmin; }
         any_act = false;
 #pragma unroll

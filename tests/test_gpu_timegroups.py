@@ -55,6 +55,10 @@ def test_records_do_not_depend_on_the_time_group(dtype, nonuniform):
         "two-row, three-column boxes": _track(nt, nx, ny, 3, 2, rng),
         "boxes of changing size": [(4 + t % 3, 40 + 2 * (t % 11), 3 + t % 2, 30 + 3 * (t % 7)) for t in range(nt)],
         "64 columns wide, 64 rows high": [(20 + (t % 2), 83 + (t % 2), 10, 73) for t in range(nt)],
+        # (found by the soak: a LOW box that starts far below the top of its group's union -- its padding rows, which stage 2 reads
+        # as zeros, must still lie inside the launch's row blocks, else the group may not share)
+        "a low box far down the union": [(7, 13, 41, 53) if t % 2 == 0 else (3, 9, 45, 46) for t in range(nt)],
+        "boxes of very different heights": [[(13, 30, 8, 42), (0, 30, 6, 56), (16, 30, 6, 23), (4, 17, 23, 40)][t % 4] for t in range(nt)],
     }
     for what, boxes in cases.items():
         f = [torch.as_tensor(np.ascontiguousarray(x)).to(DEV) for x in (dom.tair, dom.u, dom.v, dom.omega, dom.geopt)]
