@@ -30,6 +30,7 @@ from lorenzcycletoolkit_amd.frameworks import BoxData  # noqa: E402
 from tests import soak_ingest as si  # noqa: E402
 
 CONDA = "/opt/conda/bin/python3.9"
+SEEN = {"checked": 0, "moving": 0, "streamed_runs": 0, "device_inflate": 0, "registered": 0, "staged": 0, "host_inflate": 0, "skipped_small": 0}
 
 
 def same(x, y):
@@ -46,7 +47,9 @@ def check(rng, case, classic, nc4, limits, what, layout):
     try:
         host = ds.slice_domain(ds.process_data(ds.open_dataset(classic, df), args, df), args, df)
         if host.lat.size < 3 or host.lon.size < 3 or host.level.size < 2:
+            SEEN["skipped_small"] += 1
             return []
+        SEEN["checked"] += 1
         moving = case % 3 == 0 and 85000.0 in host.level and len(host.time) >= 2
         if moving:
             nt = len(host.time)
@@ -76,6 +79,11 @@ def check(rng, case, classic, nc4, limits, what, layout):
             st = ingest.lec_streamed(raw, plan, df, boxes, per_step_boxes=moving, chunk_steps=chunk, staging=staging, inflate=inflate, slots=slots,
                                      stats=stats, keep_level=keep)
             torch.cuda.synchronize()
+            SEEN["streamed_runs"] += 1
+            SEEN["moving"] += int(moving)
+            SEEN["device_inflate"] += int(stats["inflate"] == "device")
+            SEEN["host_inflate"] += int(stats["inflate"] == "host")
+            SEEN[stats["staging"]] += 1
             how = f"chunk {chunk} staging {staging}->{stats['staging']} inflate {inflate}->{stats['inflate']} slots {slots}"
             if not (same(st.scalars, ref.scalars) and same(st.levels, ref.levels) and torch.equal(st.nanflag, ref.nanflag)):
                 fails.append(f"{what}: streamed ({how}) differs from the classic file's resident run")
@@ -135,7 +143,7 @@ def main():
         os.chdir(ROOT)
     for ln in fails[:30]:
         print("FAIL", ln[:1200])
-    print(f"deflated soak: {a.cases} cases, seed {a.seed}: {len(fails)} failures")
+    print(f"deflated soak: {a.cases} cases, seed {a.seed}: {len(fails)} failures; exercised: {SEEN}")
     sys.exit(1 if fails else 0)
 
 

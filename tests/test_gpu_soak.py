@@ -65,3 +65,17 @@ def test_soak_slice_repeatability():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "soak_repeat.py"), "--seconds", "12"], capture_output=True, text=True,
                        timeout=600, cwd=ROOT)
     assert r.returncode == 0 and "repeatability soak: 0 failures" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/conda/bin/python3.9"), reason="the NetCDF-4 writer of this soak needs the image's conda interpreter (h5py)")
+def test_soak_slice_streamed_netcdf4_layouts():
+    """40 random files, each as classic NetCDF and rewritten as NetCDF-4 in a random layout (chunk shapes, shuffle, deflate, fletcher32,
+    contiguous / uncompressed variables mixed in): the NetCDF-4 file through the host preparation and through `lec_streamed` (device or
+    host inflate, chunks from the registered file pages or pinned staging, 2-3 slots, random chunk lengths, time ranges, tracks with the
+    850-hPa slices kept from the pass) gives the bits of the classic file's resident run."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "soak_deflated.py"), "--cases", "40", "--seed", "20260404"], capture_output=True,
+                       text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0 and "seed 20260404: 0 failures" in r.stdout, (r.stdout[-3000:], r.stderr[-1500:])
+    assert "'device_inflate': 0" not in r.stdout and "'registered': 0" not in r.stdout          # the device paths were really exercised
