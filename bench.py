@@ -261,7 +261,13 @@ def run_rank(args):
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist          # --force-dist: the N > 1 code path (process group, collectives) with ONE rank
+    stdout_fd = None
     if use_dist:
+        # RCCL and gloo print their banners ("RCCL version : ...", "[Gloo] Rank 0 is connected to ...") on STDOUT: the contract is ONE
+        # JSON line there, so everything the libraries write goes to stderr until the line itself is printed
+        sys.stdout.flush()
+        stdout_fd = os.dup(1)
+        os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if world == 1:
             os.environ.setdefault("MASTER_PORT", str(_free_port()))
@@ -688,7 +694,12 @@ def run_rank(args):
         kind = "none" if args.no_cpu_baseline else args.cpu_baseline
         if world == 1 and kind != "none" and resident and with_q and not args.moving:
             out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(kind, eng, held, lat, lon, level, time_s, device)
+        if stdout_fd is not None:
+            sys.stdout.flush()
+            os.dup2(stdout_fd, 1)
         print(json.dumps(out, ensure_ascii=False), flush=True)
+        if stdout_fd is not None:
+            os.dup2(2, 1)
     if use_dist:
         barrier()
         dist.destroy_process_group()

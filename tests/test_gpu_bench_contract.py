@@ -59,6 +59,7 @@ def test_bench_starts_its_own_ranks_and_counts_them():
     assert r.returncode == 0, r.stderr[-2000:]
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
+    assert [ln for ln in r.stdout.splitlines() if ln.strip()] == lines          # stdout holds the JSON line and nothing else (library banners: stderr)
     assert d["n_gpus"] == 2 and d["config"]["world_size"] == 2 and d["config"]["timesteps_global"] == 6 and d["scaling"] == "weak"
     assert d["config"]["backend"] == "gloo" and d["config"]["results_finite"] is True and d["config"]["gathered_series_ok"] is True
     # the run verifies itself: ranks connected, every rank's block of the gathered series, per-rank clocks and segments
@@ -79,6 +80,7 @@ def test_bench_runs_the_rccl_code_path_with_one_rank():
     r, lines = _bench(["--force-dist", "--timesteps", "3", "--cpu-baseline", "none"] + SMALL)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads(lines[0])
+    assert [ln for ln in r.stdout.splitlines() if ln.strip()] == lines          # RCCL's version banner went to stderr
     assert d["n_gpus"] == 1 and d["config"]["backend"] == "nccl" and d["config"]["results_finite"] is True and d["config"]["gathered_series_ok"] is True
     assert "mask_all_reduce" in d["config"]["segments_ms"] and "gather.collective" in d["config"]["segments_ms"]
     c = d["config"]
