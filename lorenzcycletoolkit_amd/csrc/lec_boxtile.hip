@@ -40,6 +40,9 @@
 // position of a point in the LDS tiles (hence its summation group), the row's shift values, end points, latitude coefficients
 // and record slot.  So the records do not depend on TG, on how a series is cut into groups, shards or chunks, or on whether a
 // group shared: tested bit for bit against TG = 1 and the one-wave-per-row kernel.
+// MEASURED (round 4, profiles/r04_notes.md section 2b): the L1 -> L2 line requests fall by 12 % (TG = 2) and 17 % (TG = 4) as designed,
+// and the kernel is 3 % / 8 % SLOWER -- the time neighbours were L2 hits all along, the fabric moves the same bytes, and the lock step
+// costs the waves their independence.  TG = 1 is what ships (kDefaultTG); TG = 2 / 4 stay selectable (tuning.block_shape) and tested.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
