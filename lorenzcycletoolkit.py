@@ -149,17 +149,18 @@ def main(argv=None):
     if args.shard is not None:
         app_logger.info(f"Time-sharded run: {args.shard.world} ranks (backend {args.shard.backend}), one GPU each; rank 0 writes the results")
     try:
+        opened = None
         if args.ingest == "device":
             args.device_ingest = True
         elif args.ingest == "auto" and not args.device_ingest:
             from lorenzcycletoolkit_amd.ingest import prefers_device_ingest
-            args.device_ingest = prefers_device_ingest(args, "inputs/namelist")
+            args.device_ingest, opened = prefers_device_ingest(args, "inputs/namelist", keep_open=True)
             if args.device_ingest:
                 app_logger.info("The input is a deflated NetCDF-4 file whose chunks the GPU can inflate, or a large file: streaming it to the "
                                 "GPU (--ingest device); --ingest host prepares the data on the host instead (same results)")
         if args.device_ingest:
             from lorenzcycletoolkit_amd.ingest import prepare_streamed
-            data = prepare_streamed(args, "inputs/namelist", app_logger)
+            data = prepare_streamed(args, "inputs/namelist", app_logger, raw=opened)
         else:
             data = prepare_data(args, "inputs/namelist", app_logger)
         phases.mark("open_and_plan" if args.device_ingest else "open_decode_and_prepare")

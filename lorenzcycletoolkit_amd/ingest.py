@@ -63,22 +63,24 @@ class StreamedDataset:
     names = property(lambda self: self.raw.names)
 
 
-def prepare_streamed(args, varlist: str = "inputs/namelist", app_logger=None, chunk_steps: Optional[int] = None) -> StreamedDataset:
+def prepare_streamed(args, varlist: str = "inputs/namelist", app_logger=None, chunk_steps: Optional[int] = None, raw=None) -> StreamedDataset:
     """prepare_data (preprocessing.py:374-413) for the device ingest: validates the file against the namelist and builds
-    the index maps; no field data is read here."""
+    the index maps; no field data is read here.  ``raw``: the file already opened (``prefers_device_ingest(..., keep_open=True)``: the
+    chunk index of a long NetCDF-4 series is then parsed once, not twice)."""
     if getattr(args, "cdsapi", False):
         raise NotImplementedError("--cdsapi downloads need network access and are out of scope")
     if not (getattr(args, "fixed", False) or getattr(args, "track", False)):
         raise NotImplementedError("the device ingest serves the fixed (-f) and the track (-t) frameworks")
     df = ds.read_namelist(varlist, app_logger)
-    raw = ds.open_raw(args.infile, df, mpas=bool(getattr(args, "mpas", False)), app_logger=app_logger)
+    if raw is None:
+        raw = ds.open_raw(args.infile, df, mpas=bool(getattr(args, "mpas", False)), app_logger=app_logger)
     return StreamedDataset(raw, make_plan(raw, args, app_logger), chunk_steps, getattr(args, "inflate", None) or "auto")
 
 
 AUTO_DEVICE_BYTES = 1 << 30      # --ingest auto: files from this size on are streamed to the device whatever their container
 
 
-def prefers_device_ingest(args, varlist: str = "inputs/namelist") -> bool:
+def prefers_device_ingest(args, varlist: str = "inputs/namelist", keep_open: bool = False):
     """--ingest auto.  True (stream the file's bytes and prepare them on the GPU) for
       * a chunked NetCDF-4 file with at least one DEFLATED field variable, every field variable of which the device can take as it
         lies in the file (``H5Variable.chunk_streams``: fully written, filters within shuffle / deflate / fletcher32): the host path
@@ -87,31 +89,39 @@ def prefers_device_ingest(args, varlist: str = "inputs/namelist") -> bool:
         int8 / int16 / int32 / float32 / float64): the host preparation decodes, sorts and crops the whole data set with NumPy before a
         byte reaches the GPU, the device ingest moves the file's bytes at the link's rate.
     False (prepare on the host) for everything else: small files, other axis orders, a framework the streamed path does not serve.
-    Never raises: a file that cannot be judged is left to the host path's messages.  Either way the output files are the same."""
+    Never raises: a file that cannot be judged is left to the host path's messages.  Either way the output files are the same.
+    ``keep_open``: return (decision, the opened RawDataset or None) -- on True the caller hands the data set to ``prepare_streamed``."""
+    verdict, raw = _prefers_device_ingest(args, varlist)
+    if keep_open and verdict:
+        return True, raw
+    if raw is not None:
+        raw.close()
+    return (verdict, None) if keep_open else verdict
+
+
+def _prefers_device_ingest(args, varlist):
     if not (getattr(args, "fixed", False) or getattr(args, "track", False)) or getattr(args, "cdsapi", False):
-        return False
+        return False, None
     try:
         with open(args.infile, "rb") as fh:
             hdf5 = fh.read(8) == b"\x89HDF\r\n\x1a\n"
         big = os.path.getsize(args.infile) >= AUTO_DEVICE_BYTES
         if not (hdf5 or big):
-            return False
+            return False, None
         raw = ds.open_raw(args.infile, ds.read_namelist(varlist), mpas=bool(getattr(args, "mpas", False)))
     except Exception:       # noqa: BLE001
-        return False
+        return False, None
     try:
         if big:
-            return True
+            return True, raw
         deflated = False
         for v in raw.variables.values():
             if not hasattr(v.data, "chunk_streams") or v.data.chunk_streams() is None:
-                return False
+                return False, raw
             deflated = deflated or any(fid == 1 for fid, _cd in getattr(v.data, "_filters", []))
-        return deflated
+        return deflated, raw
     except Exception:       # noqa: BLE001
-        return False
-    finally:
-        raw.close()
+        return False, raw
 
 
 def _src_code(dtype: np.dtype) -> int:
