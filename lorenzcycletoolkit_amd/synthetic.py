@@ -53,10 +53,30 @@ def synthetic_cube(nt: int, level_pa, lat_deg, lon_deg, device, dtype=torch.floa
     }
     amp = {"tair": 1.0, "u": 5.0, "v": 3.0, "omega": 0.1, "geopt": 100.0}
     out = {k: torch.empty((nt, nl, ny, nx), dtype=dtype, device=dev) for k in base}
+    # Few dispatches: per step and field only the draw itself (the generator is re-seeded per GLOBAL step, and a draw's numbers
+    # depend on its size, so the draws stay one per step and field); the scaling and the smooth part are applied to a group of steps
+    # at once (two launches per group and field instead of three per step and field -- a T = 512 moving cube was ~10,000 launches,
+    # which a counter pass of rocprofv3 serialises and instruments one by one: profiles/r05_notes.md section 2).  The arithmetic is
+    # the same two roundings as before, fl(fl(amp * N) + base), then the storage dtype: the cubes are bit-identical to round 4's.
+    names = ("tair", "u", "v", "omega", "geopt")
+    group = max(1, min(nt, (1 << 30) // (8 * nl * ny * nx)))         # steps whose draws of ONE field fit 1 GiB
+    drawn = {k: torch.empty((group, nl, ny, nx), **f64) for k in (names if group > 1 else names[:1])}
     gen = torch.Generator(device=dev)
-    for t in range(nt):
-        gen.manual_seed(seed + t0_global + t)
-        for k in ("tair", "u", "v", "omega", "geopt"):
-            noise = torch.randn((nl, ny, nx), generator=gen, **f64)
-            out[k][t] = (base[k] + amp[k] * noise).to(dtype)
+    for g0 in range(0, nt, group):
+        g1 = min(nt, g0 + group)
+        for t in range(g0, g1):               # per step: the five draws in the order T, u, v, omega, Phi from that step's seed
+            gen.manual_seed(seed + t0_global + t)
+            for k in names:
+                if group == 1:                # a full-size grid: one step at a time through one buffer
+                    n = drawn[names[0]][0]
+                    torch.randn((nl, ny, nx), generator=gen, out=n)
+                    n.mul_(amp[k])
+                    torch.add(base[k], n, out=out[k][t])
+                else:
+                    torch.randn((nl, ny, nx), generator=gen, out=drawn[k][t - g0])
+        if group > 1:
+            for k in names:
+                d = drawn[k][:g1 - g0]
+                d.mul_(amp[k])
+                torch.add(base[k], d, out=out[k][g0:g1])
     return out

@@ -92,6 +92,46 @@ def compare(engine_scalars, engine_levels, ref_scalars, ref_levels, tol, what=""
     return worst
 
 
+# ---------------------------------------------------------------------------------------------
+# The reference's committed Reg1 sample tables (tests/golden/Reg1_{fixed,track}/*_lv_ISBL3.csv) against testdata_NCEP-R2.nc
+# ---------------------------------------------------------------------------------------------
+# testdata_NCEP-R2.nc is a 5-step, 5-level (600...1000 hPa) subset of the file those samples were computed from.  Its five
+# levels are CONTIGUOUS in the 17-level original and 1000 hPa is the bottom of both, so np.gradient over level gives the same
+# numbers at 700, 850, 925 and 1000 hPa (600 hPa is an interior level there and an edge here); np.gradient over time gives the
+# same numbers at steps 1-4 (step 5 is an interior step there and the last one here).  Which cells of which table the subset
+# reproduces therefore depends on what the term differentiates:
+#   Kz Ke Ce Cz        no d/dp, no sigma, no d/dt         -> every column, every row
+#   Az Ae Ca Ck        sigma / d(T*)/dp / d[u]/dp         -> 700-1000 hPa
+#   Ge Gz              + dT/dt inside Q                   -> 700-1000 hPa, rows 1-4 (the track tables hold 2 rows anyway)
+# sign: the committed Cz / Ca tables were written by a revision with the opposite sign (tests/golden/README.md).
+REG1_BOX = (-60, -30, -42.5, -17.5)      # tests/golden/inputs/box_limits_Reg1
+REG1_TERMS = {   # term: (skip the 600-hPa column, usable rows of the fixed table, sign)
+    "Kz": (False, 5, 1), "Ke": (False, 5, 1), "Ce": (False, 5, 1), "Cz": (False, 5, -1),
+    "Az": (True, 5, 1), "Ae": (True, 5, 1), "Ca": (True, 5, -1), "Ck": (True, 5, 1),
+    "Ge": (True, 4, 1), "Gz": (True, 4, 1),
+}
+
+
+def reg1_table(golden_dir, kind, term):
+    """(reference cells, level slice into the 5-level axis of testdata, number of rows, sign) for `kind` in fixed / track."""
+    import os
+    import pandas as pd
+    skip600, rows_fixed, sign = REG1_TERMS[term]
+    hpa = [600.0, 700.0, 850.0, 925.0, 1000.0][1 if skip600 else 0:]
+    df = pd.read_csv(os.path.join(golden_dir, f"Reg1_{kind}", f"{term}_lv_ISBL3.csv"), index_col=0)
+    cols = [str(h) if kind == "fixed" else str(h * 100.0) for h in hpa]        # hPa headers (old fixed sample) / Pa (track)
+    r = df[cols].values
+    rows = min(rows_fixed, len(r)) if kind == "fixed" else len(r)                # the track tables hold 3 (Ge, Gz: 2) rows
+    return r[:rows], slice(1 if skip600 else 0, None), rows, sign
+
+
+def reg1_track_limits(golden_dir):
+    import os
+    import pandas as pd
+    tr = pd.read_csv(os.path.join(golden_dir, "inputs", "track_testdata_NCEP-R2"), sep=";")
+    return tr, [(lo - 7.5, lo + 7.5, la - 7.5, la + 7.5) for la, lo in zip(tr.Lat, tr.Lon)]
+
+
 def write_packed_era5_style(path, nt=7, fill=True, offset=True):
     """ERA5-style file: int16 with scale_factor / add_offset / _FillValue, lon 0..357.5, lat N -> S, levels in hPa
     from the surface up including 5 hPa (dropped by the >= 10 hPa filter).  ``fill`` / ``offset``: leave out the fill value

@@ -151,6 +151,34 @@ def test_device_ingest_flag_writes_identical_csvs(workdir, golden_dir):
     assert len(a) == 36 and np.isfinite(a.values).all()
 
 
+@pytest.mark.parametrize("ingest", ["host", "device"])
+@pytest.mark.parametrize("kind", ["fixed", "track"])
+def test_reg1_sample_tables_pin_the_engine(workdir, golden_dir, kind, ingest):
+    """The HIP path against the reference's OWN numbers on a second data set, both frameworks, both ways of preparing the data:
+    the level tables the CLI writes for testdata_NCEP-R2.nc against every cell of the committed Reg1 sample tables that the 5-level /
+    5-step subset reproduces (tests/helpers.py REG1_TERMS) -- sigma, the Q stencil (the moving framework's with the dT/dt it forms
+    over the track's times), Ca's two gradients, Ck.  The reference computed in float32, the engine computes in fp64 from the same
+    float32 file: tolerance policy (ii) of SURVEY appendix D.  The track sample's Ck predates the current second piece
+    (tests/golden/README.md; accounted for on the CPU in tests/test_oracle_golden.py) and is left out."""
+    from tests.helpers import REG1_TERMS, reg1_table
+    shutil.copy(os.path.join(golden_dir, "inputs", "box_limits_Reg1"), workdir / "inputs" / "box_limits")
+    shutil.copy(os.path.join(golden_dir, "inputs", "track_testdata_NCEP-R2"), workdir / "inputs" / "track")
+    infile = os.path.join(golden_dir, "testdata_NCEP-R2.nc")
+    _main([infile, "-r", "-f" if kind == "fixed" else "-t", "--ingest", ingest])
+    lvdir = workdir / "LEC_Results" / f"testdata_NCEP-R2_{kind}" / "results_vertical_levels"
+    worst = {}
+    for term in REG1_TERMS:
+        if kind == "track" and term == "Ck":
+            continue
+        r, lev, rows, sign = reg1_table(golden_dir, kind, term)
+        got = pd.read_csv(lvdir / f"{term}_lv_ISBL3.csv", index_col=0)
+        assert [float(c) for c in got.columns] == [60000.0, 70000.0, 85000.0, 92500.0, 100000.0]
+        a = sign * got.values[:rows, lev]
+        assert np.all(np.abs(a - r) <= 2e-4 * np.abs(r) + 1e-4 * np.max(np.abs(r))), term
+        worst[term] = float(np.max(np.abs(a - r)) / np.max(np.abs(r)))
+    print(kind, ingest, worst)
+
+
 def _write_era5_style(path, nt=6):
     """What the reference's missing samples/testdata_ERA5.nc looks like to the toolkit: namelist_ERA5 names (T, Z, W, U, V; time,
     level, latitude, longitude), hourly from 2005-08-09, int16-packed, latitudes N -> S, levels in millibars incl. 850 hPa."""
