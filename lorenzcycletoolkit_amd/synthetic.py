@@ -56,7 +56,8 @@ def synthetic_cube(nt: int, level_pa, lat_deg, lon_deg, device, dtype=torch.floa
     # Few dispatches: per step and field only the draw itself (the generator is re-seeded per GLOBAL step, and a draw's numbers
     # depend on its size, so the draws stay one per step and field); the scaling and the smooth part are applied to a group of steps
     # at once (two launches per group and field instead of three per step and field -- a T = 512 moving cube was ~10,000 launches,
-    # which a counter pass of rocprofv3 serialises and instruments one by one: profiles/r05_notes.md section 2).  The arithmetic is
+    # and rocprofv3's counter collection does not survive a backlog of that many unsynchronised instrumented launches -- stuck at
+    # 10,000, a segmentation fault in its launch path at 17,000: profiles/r05_notes.md section 2).  The arithmetic is
     # the same two roundings as before, fl(fl(amp * N) + base), then the storage dtype: the cubes are bit-identical to round 4's.
     names = ("tair", "u", "v", "omega", "geopt")
     group = max(1, min(nt, (1 << 30) // (8 * nl * ny * nx)))         # steps whose draws of ONE field fit 1 GiB
@@ -79,4 +80,6 @@ def synthetic_cube(nt: int, level_pa, lat_deg, lon_deg, device, dtype=torch.floa
                 d = drawn[k][:g1 - g0]
                 d.mul_(amp[k])
                 torch.add(base[k], d, out=out[k][g0:g1])
+        if dev.type == "cuda":                # no deep backlog of launches (the buffers are reused; and see the note above)
+            torch.cuda.synchronize(dev)
     return out

@@ -10,7 +10,11 @@ i=0
 for SET in "${ARR[@]}"; do
   [ -z "$SET" ] && continue
   i=$((i+1))
-  timeout -k 5 100 rocprofv3 --pmc $SET --output-format csv -d $OUT/p$i -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-baseline none "$@" > $OUT/b$i.json 2> $OUT/e$i.log || echo "pass $i failed or timed out: $SET"
+  timeout -k 5 100 rocprofv3 --pmc $SET --kernel-include-regex lec_ --output-format csv -d $OUT/p$i -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-baseline none "$@" > $OUT/b$i.json 2> $OUT/e$i.log
+  rc=$?
+  if [ $rc -ne 0 ]; then     # say WHICH: 124 / 137 = killed at the limit, anything else = the run itself failed; no further GPU step after it
+    echo "pass $i rc=$rc ($([ $rc -eq 124 -o $rc -eq 137 ] && echo killed at its time limit || echo failed)): $SET"; tail -3 $OUT/e$i.log; break
+  fi
 done
 python3 - <<PY
 import csv, glob, collections

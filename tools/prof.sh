@@ -13,7 +13,7 @@ IFS=';' read -ra ARR <<< "$SETS"
 for SET in "${ARR[@]}"; do
   [ -z "$SET" ] && continue
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --pmc $SET --output-format csv -d $OUT/pmc_$i -- python3 $REPO/bench.py --cpu-baseline none --steps 2 --warmup 1 "$@" > $OUT/bench_pmc_$i.json 2> $OUT/pmc_$i.err || { echo "pmc pass $i failed"; tail -5 $OUT/pmc_$i.err; exit 1; }
+  timeout -k 10 300 rocprofv3 --pmc $SET --kernel-include-regex lec_ --output-format csv -d $OUT/pmc_$i -- python3 $REPO/bench.py --cpu-baseline none --steps 2 --warmup 1 "$@" > $OUT/bench_pmc_$i.json 2> $OUT/pmc_$i.err || { echo "pmc pass $i failed"; tail -5 $OUT/pmc_$i.err; exit 1; }
 done
 python3 - <<PY
 import csv, glob, collections, json
