@@ -84,6 +84,10 @@ if pm:
     t_per_launch = bp["config"]["timesteps_per_gpu"]
     out.update(fetch_size_kib_per_call=fetch_kib, hbm_read_bytes_per_call_corrected=read_bytes, algorithmic_bytes_per_call=alg,
                traffic_over_algorithmic=read_bytes / alg, timesteps_per_call=t_per_launch)
+    # the embedded line was printed BEFORE this counter pass existed: its stored-traffic fields described the previous round's pass
+    # (VERDICT r4 "weak" 9: a line saying traffic_stale next to a fresh top-level csrc_sha); they now describe this file's own pass
+    bench["roofline"].update(traffic=read_bytes, traffic_source="the FETCH_SIZE pass summarised in this file", traffic_stale=False,
+                             traffic_csrc_sha=bp.get("config", {}).get("csrc_sha"))
     if key != "-":
         p = os.path.join(dst, "pmc_summary.json")
         summ = json.load(open(p)) if os.path.exists(p) else {}
