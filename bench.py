@@ -175,7 +175,9 @@ def cpu_baseline_and_parity(kind, eng, held, lat, lon, level, time_s, device):
     cos 90 deg there); the engine runs the same sub-cube and every one of the 16 terms and 21 level tables is compared
     (`parity`).  The oracle's wall time on exactly that call is the one-thread CPU baseline (`cpu_baseline`, kind "port").
     kind "full": nt = 3 at the benchmark's size, two repetitions (the first also yields the parity), plus a best-effort all-cores figure;
-    kind "quick" (tests): nt = 2, one repetition."""
+    kind "quick" (tests): nt = 2, one repetition;
+    kind "single" (what "full" becomes on rank 0 of an N > 1 run, the peers waiting in the closing barrier): nt = 3, one repetition, no
+    all-cores figure -- the other ranks' processes occupy cores and the N = 1 line of the same scaling run carries it."""
     import multiprocessing as mp
     import torch
     from oracle import lec_oracle as o
@@ -185,7 +187,7 @@ def cpu_baseline_and_parity(kind, eng, held, lat, lon, level, time_s, device):
     except AttributeError:
         usable = ncpu
     h0, h1, f = held
-    nt = min(3 if kind == "full" else 2, h1 - h0)
+    nt = min(3 if kind in ("full", "single") else 2, h1 - h0)
     ny, nx = lat.size, lon.size
     south, north = (lat[1], lat[-2]) if abs(lat[0]) >= 90.0 - 1e-9 else (lat[0], lat[-1])
     limits = (lon[0], lon[-1], south, north)
@@ -595,6 +597,20 @@ def run_rank(args):
         workload += (f"; strong scaling: global series T={T_global} sharded over {world} GPU(s), "
                      + ("shard resident in HBM" if resident else f"streamed through HBM in chunks of {chunk} steps (+ one-step T halo)")
                      if strong else f"; T={T_local} per GPU resident in HBM")
+        # which configuration of BASELINE.json this line is (configs are numbered from 1 as the prompt's "configs[1]" numbers from 0: 3 = T=64 on
+        # one GPU, 4 = T=2048 sharded over 2/4/8 GPUs, 5 = moving box, T=4096 on 8 GPUs)
+        full_grid = (args.ny, args.nx) == (721, 1440) and not args.nonuniform_lon and args.storage == "f64" and not args.no_q
+        if args.moving:
+            bcfg = {"id": 5, "exact": bool(T_global == 4096 and world == 8 and args.storage == "f64" and not args.no_q),
+                    "note": f"moving box, T={T_global} on {world} GPU(s); BASELINE config 5 is T=4096 on 8 GPUs (--gpus 8 --moving --timesteps-global 4096)"}
+        elif not full_grid:
+            bcfg = {"id": None, "exact": False, "note": "a variant of the headline workload (grid, storage or term set differ): not a BASELINE configuration"}
+        elif world == 1 and not strong:
+            bcfg = {"id": 3, "exact": bool(T_global == 64), "note": f"T={T_global} resident on one GPU; BASELINE config 3 is T=64"}
+        else:
+            bcfg = {"id": 4, "exact": bool(T_global == 2048 and world in (2, 4, 8)),
+                    "note": (f"T={T_global} time-sharded over {world} GPU(s)" + (" (strong scaling)" if strong else f" (weak scaling: T={T_local} per GPU)")
+                             + "; BASELINE config 4 is T=2048 over 2/4/8 GPUs (--timesteps-global 2048)")}
         out = {
             "metric": ("LEC timesteps/sec (all terms), moving 61x61x37 box per time step" if args.moving else
                        "LEC timesteps/sec (all energy+conversion+boundary+generation terms) at 37x721x1440"),
@@ -605,7 +621,7 @@ def run_rank(args):
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {
-                "workload": workload,
+                "workload": workload, "baseline_config": bcfg,
                 "timesteps_per_gpu": T_local, "timesteps_global": T_global, "world_size": world,
                 "backend": (dist.get_backend() if use_dist else "none"),
                 "parallelism": f"time-sharded x{world}, no data-path collective; RCCL all_reduce of the NaN-level mask (fixed box) + one gather of the "
@@ -691,9 +707,17 @@ def run_rank(args):
                 n1 = None
             out["config"]["speedup_vs_n1"] = None if not n1 else out["value"] / n1
             out["config"]["n1_value"] = n1
+        # The CPU leg runs AFTER the timed region and the verification collectives, on rank 0 only; at N > 1 the peers wait for it in the
+        # closing barrier (17 s for "single"; the process group's timeout is 10 min for RCCL, 30 for gloo).  north_star: the N-GPU
+        # throughput "next to the reference CPU path timed on the node's own host cores in the same run" (the reference clocks its whole
+        # call: lorenzcycletoolkit.py:173,180,199).  `parity` at N > 1 is rank 0's shard: its first steps against the oracle.
         kind = "none" if args.no_cpu_baseline else args.cpu_baseline
-        if world == 1 and kind != "none" and resident and with_q and not args.moving:
-            out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(kind, eng, held, lat, lon, level, time_s, device)
+        if kind != "none" and resident and with_q and not args.moving:
+            leg = kind if world == 1 or kind == "quick" else "single"
+            out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(leg, eng, held, lat, lon, level, time_s, device)
+            if world > 1:
+                out["cpu_baseline"]["ranks_waiting_in_the_closing_barrier"] = world - 1
+                out["parity"]["shard"] = f"rank 0 of {world}: global time steps {t0}..{t1 - 1}"
         if stdout_fd is not None:
             sys.stdout.flush()
             os.dup2(stdout_fd, 1)

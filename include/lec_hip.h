@@ -46,7 +46,8 @@ extern "C" {
 
 /* ABI 8 (round 4): lec_reduce_args.stage (the two halves of stage 2 run apart; no 65535-step limit), lec_inflate_args.dst_bytes and
  * lec_chunk_scatter_args.src_bytes (the destination / payload ranges of every descriptor are bounds-checked on the device). */
-#define LEC_ABI_VERSION 8
+#define LEC_ABI_VERSION 9
+/* ABI 9 (round 5): lec_format_csv_rows (host): a per-level table as the text pandas writes for it, one call per table. */
 
 /* number of fp64 values per (time, level, lat) row record written by lec_rowstats */
 #define LEC_NSTAT 32
@@ -156,7 +157,8 @@ typedef struct lec_rowstats_args {
 
 /*
  * Stage 2: (level x lat) math on the row records -> per-time scalars and per-level tables.
- * Limits: nl <= 160 levels (LEC_ERR_UNSUPPORTED beyond); nl * t_count < 2^31 (ABI 8: the 65535-step limit of a call is gone).
+ * Limits: nl <= 160 levels (LEC_ERR_UNSUPPORTED beyond); nl * t_count < 2^26 per call (the launch is nl * t_count workgroups of 64
+ * threads and HIP takes fewer than 2^32 threads per launch; LEC_ERR_UNSUPPORTED beyond: 1.8 million steps of 37 levels).
  *
  * The call has two halves that may also be run apart (`stage`, ABI 8), for series whose row records are not held whole:
  *   LEC_STAGE_LEVELS    rows_d -> levraw_d : the level x latitude work of the call's time steps; needs rows_d, box / lat / lev tables,
@@ -361,6 +363,19 @@ typedef struct lec_chunk_scatter_args {
 int lec_inflate(const lec_inflate_args* args);
 const char* lec_inflate_status_text(int code);
 int lec_chunk_scatter(const lec_chunk_scatter_args* args);
+
+/*
+ * The text of a per-level table (HOST memory in, host memory out; no device work).  Replaces the per-cell formatting inside
+ * `_save_vertical_levels` (src/analysis/conversion_terms.py:287-308 and its copies in energy_contents.py,
+ * generation_and_dissipation_terms.py: DataFrame.to_csv(mode="a", header=None)) for the 21 tables of a series: `rows` lines, each
+ * `labels + r * label_len` (label_len bytes: the time stamp as the reference prints it), then for each of the `cols` values of the row
+ * (`row_stride` doubles from one row to the next) a ',' and the value as Python's repr(float) -- shortest round-trip digits,
+ * positional for 1e-4 <= |x| < 1e16 with at least ".0", else d[.ddd]e[+-]XX --, NaN as an empty field (pandas' na_rep), and '\n'.
+ * Byte for byte what pandas writes for float64 columns.  `out` must hold rows * (label_len + 27 * cols + 1) bytes.
+ * Returns the number of bytes written, or -1 (text via lec_last_error()).
+ */
+long long lec_format_csv_rows(const double* values, long long rows, long long cols, long long row_stride,
+                              const char* labels, int label_len, char* out, long long cap);
 
 #ifdef __cplusplus
 }

@@ -75,6 +75,25 @@ def setup_results_directory(args, method):
     return results_subdirectory, figures_directory, results_subdirectory_vertical_levels
 
 
+def _leave_only_the_log(results_subdirectory):
+    """A run that failed leaves no half-written results behind.  Like the reference, the results tree is created BEFORE the input is
+    read (lorenzcycletoolkit.py:250-258 there), so a file the reader refuses, a bad namelist or a failure in mid-analysis would
+    leave empty directories and header-only CSVs that look like results.  When THIS run created the tree, everything but the log --
+    which carries the error -- is removed again; a tree that existed before (earlier results) is not touched."""
+    import shutil
+    for name in os.listdir(results_subdirectory):
+        path = os.path.join(results_subdirectory, name)
+        if name.startswith("log."):
+            continue
+        if os.path.isdir(path):
+            shutil.rmtree(path, ignore_errors=True)
+        else:
+            try:
+                os.remove(path)
+            except OSError:
+                pass
+
+
 def initialize_logging(results_subdirectory, args):
     """Reference src/utils/tools.py:32-73: logger "lorenzcycletoolkit", file log.<stem> + console.  In a time-sharded run only
     rank 0 logs to the file; the other ranks report warnings and errors on the console."""
@@ -130,6 +149,7 @@ def main(argv=None):
     from lorenzcycletoolkit_amd.parallel import shard_from_env
     args.shard = shard_from_env()                      # None: the ordinary one-process run
     method = "fixed" if args.fixed else ("track" if args.track else "choose")
+    tree_is_new = not os.path.isdir(os.path.join("./LEC_Results/", "".join(args.infile.split("/")[-1].split(".nc")) + "_" + method))
     if args.shard is None or args.shard.root:
         results_subdirectory, figures_directory, results_subdirectory_vertical_levels = setup_results_directory(args, method)
     else:                                              # the paths only: rank 0 creates the tree and writes every file
@@ -149,30 +169,48 @@ def main(argv=None):
     if args.shard is not None:
         app_logger.info(f"Time-sharded run: {args.shard.world} ranks (backend {args.shard.backend}), one GPU each; rank 0 writes the results")
     try:
-        opened = None
+        opened, auto_chose = None, False
         if args.ingest == "device":
             args.device_ingest = True
         elif args.ingest == "auto" and not args.device_ingest:
             from lorenzcycletoolkit_amd.ingest import prefers_device_ingest
-            args.device_ingest, opened = prefers_device_ingest(args, "inputs/namelist", keep_open=True)
+            args.device_ingest, opened = prefers_device_ingest(args, "inputs/namelist", keep_open=True, app_logger=app_logger)
+            auto_chose = args.device_ingest
             if args.device_ingest:
                 app_logger.info("The input is a deflated NetCDF-4 file whose chunks the GPU can inflate, or a large file: streaming it to the "
                                 "GPU (--ingest device); --ingest host prepares the data on the host instead (same results)")
+        analyse = lambda d: run_lec_analysis(d, args, results_subdirectory, figures_directory, results_subdirectory_vertical_levels, app_logger)
+        data = None
         if args.device_ingest:
             from lorenzcycletoolkit_amd.ingest import prepare_streamed
-            data = prepare_streamed(args, "inputs/namelist", app_logger, raw=opened)
-        else:
+            try:
+                data = prepare_streamed(args, "inputs/namelist", app_logger, raw=opened)
+                phases.mark("open_and_plan")
+                try:
+                    analyse(data)
+                finally:
+                    data.raw.close()
+            except (ValueError, NotImplementedError) as e:
+                # A streamed path that --ingest auto chose BY ITSELF must not fail a run the host preparation can do: the
+                # file is closed, the reason logged, and the data are prepared on the host.  The frameworks write their files only
+                # after the engine has returned and create the header files anew (mode "w"), so nothing half-done is left.  Asked for explicitly
+                # (--ingest device / --device-ingest) the error stands.
+                if not auto_chose or args.shard is not None:       # (ranks of a sharded run must not part ways)
+                    raise
+                if data is None and opened is not None:
+                    opened.close()
+                app_logger.warning(f"--ingest auto: the streamed path refused this input ({type(e).__name__}: {e}); preparing the data on the host instead")
+                args.device_ingest, data = False, None
+        if not args.device_ingest:
             data = prepare_data(args, "inputs/namelist", app_logger)
-        phases.mark("open_and_plan" if args.device_ingest else "open_decode_and_prepare")
-        try:
-            run_lec_analysis(data, args, results_subdirectory, figures_directory, results_subdirectory_vertical_levels, app_logger)
-        finally:
-            if args.device_ingest:
-                data.raw.close()
+            phases.mark("open_decode_and_prepare")
+            analyse(data)
         if args.shard is not None:
             args.shard.barrier()                       # the ranks leave together, after rank 0 has written the files
     except Exception:
         app_logger.exception("LEC analysis failed")
+        if tree_is_new and (args.shard is None or args.shard.root):
+            _leave_only_the_log(results_subdirectory)
         raise
     finally:
         phases.mark("end")
@@ -184,11 +222,14 @@ def main(argv=None):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1:])
+    status = main(sys.argv[1:])
     # The results are on disk and the logs flushed: leave without the interpreter's teardown.  A run that pinned / registered tens of
     # GB of host memory and holds a HIP context spends 1-2.5 s there (freeing pinned blocks one by one, unloading the runtime) -- a
     # quarter of the wall clock of a 96-step ERA5 file (profiles/r04_notes.md section 6); the operating system reclaims it all at once.
+    # Everything must be flushed BEFORE this line: os._exit skips atexit handlers and buffered file objects (phases.dump and the CSV
+    # writers close their files; logging is shut down here).  main()'s return value is the exit status -- a failure raises and never
+    # gets here, so the interpreter's ordinary exit reports it.
     logging.shutdown()
     sys.stdout.flush()
     sys.stderr.flush()
-    os._exit(0)
+    os._exit(int(status or 0))

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # LEC_LIB: alternative build of the same ABI (kernel experiments only)
 LIB_PATH = os.environ.get("LEC_LIB") or os.path.join(_HERE, "liblec_hip.so")
 
-LEC_ABI_VERSION = 8
+LEC_ABI_VERSION = 9
 LEC_NSTAT = 32
 LEC_NLEVRAW = 40
 LEC_NSCALAR = 16
@@ -42,7 +42,7 @@ def source_digest() -> str:
 
 EXPORTS = ["lec_version", "lec_last_error", "lec_max_row", "lec_rowstats", "lec_reduce", "lec_dropmask", "lec_ingest", "lec_track_diag",
            "lec_check_boxes", "lec_check_maps", "lec_host_register", "lec_host_unregister", "lec_copy_rows_async",
-           "lec_inflate", "lec_inflate_status_text", "lec_chunk_scatter"]
+           "lec_inflate", "lec_inflate_status_text", "lec_chunk_scatter", "lec_format_csv_rows"]
 
 
 class Tuning(C.Structure):
@@ -177,6 +177,8 @@ def load():
     lib.lec_inflate_status_text.argtypes = [C.c_int]
     lib.lec_chunk_scatter.restype = C.c_int
     lib.lec_chunk_scatter.argtypes = [C.POINTER(ChunkScatterArgs)]
+    lib.lec_format_csv_rows.restype = C.c_longlong
+    lib.lec_format_csv_rows.argtypes = [C.c_void_p, C.c_longlong, C.c_longlong, C.c_longlong, C.c_char_p, C.c_int, C.c_void_p, C.c_longlong]
     if lib.lec_version() != LEC_ABI_VERSION:
         raise LecLibraryError(f"liblec_hip.so ABI {lib.lec_version()} != expected {LEC_ABI_VERSION}")
     _lib = lib

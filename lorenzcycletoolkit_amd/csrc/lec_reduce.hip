@@ -577,7 +577,10 @@ static int reduce_impl(const lec_reduce_args* a, bool mask_only, const char* who
     if (vertical && !mask_only && (!a->scalars_d || !a->levels_d || !a->nanflag_d)) return lec_set_error(LEC_ERR_ARG, "lec_reduce: null output pointer");
     if (a->t_count < 1 || a->nl < 2 || a->nyb_max < 2) return lec_set_error(LEC_ERR_ARG, "lec_reduce: needs t_count>=1, nl>=2, nyb_max>=2");
     if (a->nl > kMaxNl) return lec_set_error(LEC_ERR_UNSUPPORTED, "lec_reduce: more than 160 levels");
-    if ((long long)a->t_count * a->nl > 0x7fffffffLL) return lec_set_error(LEC_ERR_UNSUPPORTED, "lec_reduce: nl * t_count must stay below 2^31 in one call");
+    // HIP refuses a launch whose grid x block reaches 2^32 threads: (nl * t_count) workgroups of 64 threads and, for the vertical
+    // half, t_count workgroups of 64
+    if ((long long)a->t_count * a->nl * 64 > 0xffffffffLL)
+        return lec_set_error(LEC_ERR_UNSUPPORTED, "lec_reduce: nl * t_count must stay below 2^26 in one call (cut the series into several calls)");
     if (a->n_box != 1 && a->n_box != a->t_count) return lec_set_error(LEC_ERR_ARG, "lec_reduce: n_box must be 1 or t_count");
     if (a->drop_any_time < 0 || a->drop_any_time > 2) return lec_set_error(LEC_ERR_ARG, "lec_reduce: drop_any_time must be 0, 1 or 2");
     if (levels && ((reinterpret_cast<uintptr_t>(a->rows_d) | reinterpret_cast<uintptr_t>(a->lattab2_d)) & 15))

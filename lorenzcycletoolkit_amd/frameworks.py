@@ -68,6 +68,7 @@ class BoxData:
         self.VerticalCoordIndexer = variable_list_df.loc["Vertical Level"]["Variable"]
         self.PressureData = data.level
         self.time = data.time
+        self._row_labels = {}
         dev = _device(args)
         self.engine = LECEngine(data.lat, data.lon, data.level, device=dev)
         limits = boxes_limits if boxes_limits is not None else [(western_limit, eastern_limit, southern_limit, northern_limit)]
@@ -122,6 +123,13 @@ class BoxData:
         self.levels = self.result.levels_dict()
         self.nanflag = self.result.nanflag.cpu().numpy()
 
+    def row_labels(self, method: str):
+        """The time-stamp column of the per-level tables (formatted once per series, not once per table)."""
+        got = self._row_labels.get(method)
+        if got is None:
+            got = self._row_labels[method] = time_labels(self.time, method)
+        return got
+
     def _compute_resident(self, data: ds.LECDataset, variable_list_df: pd.DataFrame, dev, dTdt, merge=None, out=None) -> LECResult:
         """Host-prepared cubes, uploaded whole (a time-sharded rank: the steps it holds)."""
         (t0, t1), (h0, h1) = self.t_own, self.t_held
@@ -165,6 +173,42 @@ class BoxData:
                                    drop_any_time=not self.per_step_boxes, merge_dropmask=merge, out=out)
 
 
+def time_labels(times, method: str):
+    """The first field of every row of a per-level table, as the reference's pandas call prints it, as one byte string of
+    fixed-width labels: the moving framework formats its index itself ("%Y-%m-%d %H:%M:%S", conversion_terms.py:299-300); the fixed
+    framework leaves a DatetimeIndex to pandas, which prints dates alone when every stamp is a midnight -- taken from pandas itself
+    (an index without columns through to_csv) so that the rule is pandas' own."""
+    idx = pd.DatetimeIndex(times)
+    if method == "fixed":
+        labels = pd.DataFrame(index=idx).to_csv(header=None).splitlines()
+    else:
+        labels = list(idx.strftime("%Y-%m-%d %H:%M:%S"))
+    width = len(labels[0]) if labels else 0
+    if any(len(x) != width for x in labels) or any(("," in x or '"' in x) for x in labels):
+        return None, 0                           # (stamps pandas prints at mixed widths: the caller falls back to pandas itself)
+    return "".join(labels).encode("ascii"), width
+
+
+def format_level_table(table, labels) -> bytes:
+    """`table` [time, level] (float64) as the lines DataFrame.to_csv(header=None) writes for it (lec_format_csv_rows)."""
+    import ctypes as C
+    from . import _lib
+    blob, width = labels
+    a = np.ascontiguousarray(table, dtype=np.float64)
+    if a.ndim != 2:
+        raise ValueError("a per-level table is [time, level]")
+    rows, cols = a.shape
+    if blob is None or rows * width != len(blob):
+        raise ValueError("one fixed-width label per row")
+    lib = _lib.load()
+    cap = rows * (width + 27 * cols + 1)
+    out = C.create_string_buffer(max(cap, 1))
+    n = lib.lec_format_csv_rows(a.ctypes.data, rows, cols, cols, blob, width, C.addressof(out), cap)
+    if n < 0:
+        _lib.check(1, "lec_format_csv_rows")
+    return out.raw[:n]
+
+
 class _Terms:
     """Shared plumbing of the four analysis classes: hand out a finished series and append its
     per-level CSV rows exactly where the reference's calc_* would (``_save_vertical_levels``,
@@ -176,18 +220,23 @@ class _Terms:
         self.box_obj, self.method, self.app_logger = box_obj, method, app_logger
 
     def _save_vertical_levels(self, name: str):
+        """One table appended to its CSV file: byte for byte what the reference's pandas call writes (conversion_terms.py:287-308:
+        DataFrame.to_csv(mode="a", header=None) -- float cells as repr(float), NaN as an empty field), formatted for the whole
+        series in one call of the library (lec_format_csv_rows) instead of one Python object per cell."""
         b = self.box_obj
         path = f"{b.results_subdirectory_vertical_levels}/{name}_{b.VerticalCoordIndexer}.csv"
         table = b.levels[name]
-        if self.method == "fixed":
-            if name in ("Cz_1", "Ce_1"):        # level-only term: written transposed (conversion_terms.py:293-294)
-                df = pd.DataFrame({b.VerticalCoordIndexer: b.PressureData, name: table[0]}).T
-            else:
-                df = pd.DataFrame(table, index=pd.DatetimeIndex(b.time), columns=b.PressureData)
-        else:
-            idx = pd.DatetimeIndex(b.time).strftime("%Y-%m-%d %H:%M:%S")
-            df = pd.DataFrame(table, index=idx, columns=b.PressureData)
-        df.to_csv(path, mode="a", header=None)
+        if self.method == "fixed" and name in ("Cz_1", "Ce_1"):        # level-only term: written transposed (conversion_terms.py:293-294)
+            df = pd.DataFrame({b.VerticalCoordIndexer: b.PressureData, name: table[0]}).T
+            df.to_csv(path, mode="a", header=None)
+            return
+        labels = b.row_labels(self.method)
+        if labels[0] is None:                    # time stamps pandas prints at mixed widths (sub-second steps): pandas writes the table
+            idx = pd.DatetimeIndex(b.time) if self.method == "fixed" else pd.DatetimeIndex(b.time).strftime("%Y-%m-%d %H:%M:%S")
+            pd.DataFrame(table, index=idx, columns=b.PressureData).to_csv(path, mode="a", header=None)
+            return
+        with open(path, "ab") as f:
+            f.write(format_level_table(table, labels))
 
     def _series(self, name: str, tables):
         for t in tables:
@@ -244,8 +293,9 @@ def _create_level_csvs(directory, time_name, vert_name, level_pa):
 def _log_ingest(box_obj, app_logger):
     st = getattr(box_obj, "ingest_stats", None)
     if st:
-        app_logger.info("Device ingest: %.1f MB over the link in %d chunk(s) of %d step(s), staging %s, inflate %s, storage %s" % (
-            st["bytes_moved"] / 1e6, st["chunks"], st["chunk_steps"], st["staging"], st.get("inflate", "none"), st["storage"]))
+        app_logger.info("Device ingest: %.1f MB over the link in %d chunk(s) of %d step(s), staging %s, inflate %s, storage %s, device buffers %.2f GB" % (
+            st["bytes_moved"] / 1e6, st["chunks"], st["chunk_steps"], st["staging"], st.get("inflate", "none"), st["storage"],
+            st.get("device_buffer_bytes", 0) / 1e9))
         if "seconds" in st:
             app_logger.info("Device ingest seconds: " + ", ".join(f"{k} {v:.3f}" for k, v in st["seconds"].items()) +
                             (f"; {st['register_calls']} registrations, {st['registered_bytes'] / 1e9:.2f} GB" if "register_calls" in st else ""))

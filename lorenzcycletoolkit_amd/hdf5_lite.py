@@ -147,6 +147,14 @@ class H5File:
             pass
         self._f.close()
 
+    def _refusal(self, how: str) -> "Hdf5Error":
+        """A layout of HDF5 metadata this reader does not follow: says which object of which file, and what gets the user past it --
+        there is no other HDF5 reader to fall back on (the image has no netCDF4 / h5py for the default interpreter)."""
+        return Hdf5Error(f"{self.path}: the links or attributes of {getattr(self, '_context', 'an object')} are {how}, which this reader does "
+                         "not follow.  Rewrite the file without that layout and run again: `nccopy -k cdf5 in.nc out.nc` (classic 64-bit-data "
+                         "NetCDF: no HDF5 container at all; `-k nc3` for files below 2 GiB per variable) or `nccopy -k nc4 -d0 in.nc out.nc` "
+                         "(NetCDF-4 rewritten by the netCDF library with its default, compact metadata)")
+
     # ---- primitive reads -------------------------------------------------------------------
     def _u(self, off: int, n: int) -> int:
         return int.from_bytes(self._m[off: off + n], "little")
@@ -182,6 +190,7 @@ class H5File:
         if self.base not in (0, base):
             raise Hdf5Error("non-zero base address not supported")
         self.base = base
+        self._context = "the root group"
         msgs = self._object_messages(root)
         self.attrs = self._attributes(msgs)
         links = self._group_links(msgs)
@@ -192,6 +201,7 @@ class H5File:
                 dm = self._object_messages(addr)
             except Hdf5Error:
                 continue
+            self._context = f"the dataset '{name}'"
             var = self._dataset(name, dm)
             if var is not None:
                 self.variables[name] = var
@@ -398,7 +408,7 @@ class H5File:
         root = self._addr(p); p += self.O
         cur_rows = self._u(p, 2)
         if filt_len:
-            raise Hdf5Error("filtered fractal heaps not supported")
+            raise self._refusal("stored in a FILTERED fractal heap (compressed metadata)")
         off_bytes = (max_bits + 7) // 8
         max_direct_rows = (max_direct // start).bit_length() - 1 + 2
 
@@ -417,7 +427,7 @@ class H5File:
                 size = start if r < 2 else start << (r - 1)
                 if off < row_off + width * size:
                     if r >= max_direct_rows:
-                        raise Hdf5Error("nested fractal-heap indirect blocks are not supported")
+                        raise self._refusal("stored in a fractal heap with NESTED indirect blocks (a very large number of attributes or links)")
                     c = (off - row_off) // size
                     child = self._addr(q + (r * width + c) * self.O)
                     return child + self.base + (off - row_off - c * size)

@@ -80,7 +80,7 @@ def prepare_streamed(args, varlist: str = "inputs/namelist", app_logger=None, ch
 AUTO_DEVICE_BYTES = 1 << 30      # --ingest auto: files from this size on are streamed to the device whatever their container
 
 
-def prefers_device_ingest(args, varlist: str = "inputs/namelist", keep_open: bool = False):
+def prefers_device_ingest(args, varlist: str = "inputs/namelist", keep_open: bool = False, app_logger=None):
     """--ingest auto.  True (stream the file's bytes and prepare them on the GPU) for
       * a chunked NetCDF-4 file with at least one DEFLATED field variable, every field variable of which the device can take as it
         lies in the file (``H5Variable.chunk_streams``: fully written, filters within shuffle / deflate / fletcher32): the host path
@@ -91,7 +91,7 @@ def prefers_device_ingest(args, varlist: str = "inputs/namelist", keep_open: boo
     False (prepare on the host) for everything else: small files, other axis orders, a framework the streamed path does not serve.
     Never raises: a file that cannot be judged is left to the host path's messages.  Either way the output files are the same.
     ``keep_open``: return (decision, the opened RawDataset or None) -- on True the caller hands the data set to ``prepare_streamed``."""
-    verdict, raw = _prefers_device_ingest(args, varlist)
+    verdict, raw = _prefers_device_ingest(args, varlist, app_logger)
     if keep_open and verdict:
         return True, raw
     if raw is not None:
@@ -99,7 +99,7 @@ def prefers_device_ingest(args, varlist: str = "inputs/namelist", keep_open: boo
     return (verdict, None) if keep_open else verdict
 
 
-def _prefers_device_ingest(args, varlist):
+def _prefers_device_ingest(args, varlist, app_logger=None):
     if not (getattr(args, "fixed", False) or getattr(args, "track", False)) or getattr(args, "cdsapi", False):
         return False, None
     try:
@@ -108,7 +108,9 @@ def _prefers_device_ingest(args, varlist):
         big = os.path.getsize(args.infile) >= AUTO_DEVICE_BYTES
         if not (hdf5 or big):
             return False, None
-        raw = ds.open_raw(args.infile, ds.read_namelist(varlist), mpas=bool(getattr(args, "mpas", False)))
+        # (the logger: what open_raw reports -- the -m/--mpas drop of the `standard_height` dimension -- is said once, here, when the
+        # opened file is handed on to prepare_streamed)
+        raw = ds.open_raw(args.infile, ds.read_namelist(varlist), mpas=bool(getattr(args, "mpas", False)), app_logger=app_logger)
     except Exception:       # noqa: BLE001
         return False, None
     try:
@@ -179,13 +181,18 @@ class RegisteredSpans:
         if at < hi:
             new.append([at, hi, use])
         t_reg = time.perf_counter()
-        for b in new:
-            _lib.check(self.lib.lec_host_register(C.c_void_p(b[0]), b[1] - b[0]), "lec_host_register")
-            self.registered_bytes += b[1] - b[0]
-            self.calls += 1
-        self.seconds += time.perf_counter() - t_reg
-        if new:
-            self.blocks = sorted(self.blocks + new)
+        try:
+            for b in new:
+                _lib.check(self.lib.lec_host_register(C.c_void_p(b[0]), b[1] - b[0]), "lec_host_register")
+                # tracked as soon as it is registered: if a LATER block of this call is refused (the mid-run refusal the pinned
+                # fallback exists for), the blocks already done are released with the rest instead of staying pinned and untracked --
+                # where they would make every later ensure() over those pages fail as overlapping (ADVICE r4)
+                self.blocks.append(b)
+                self.registered_bytes += b[1] - b[0]
+                self.calls += 1
+        finally:
+            self.seconds += time.perf_counter() - t_reg
+            self.blocks.sort()
 
     def pieces(self, lo: int, hi: int):
         """[lo, hi) cut at the boundaries of the registered blocks: a copy must lie inside ONE registered allocation to go out as a
@@ -658,6 +665,7 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
     if dev.type != "cuda":
         raise _lib.LecLibraryError("the device ingest needs a GPU: there is no CPU path")
     t_enter = time.perf_counter()
+    mem_enter = torch.cuda.memory_allocated(dev)
     engine = LECEngine(plan.lat, plan.lon, plan.level, device=dev)
     nt, nl, ny, nx = len(plan.tsel), plan.level.size, plan.lat.size, plan.lon.size
     boxes = [engine.box_from_limits(*lim) for lim in boxes_limits]
@@ -695,10 +703,14 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
                     ct, ck, cj, ci = info["chunk"]
                     per_step += (len({int(k) // ck for k in plan.kmap}) * (jb1 // cj - jb0 // cj + 1) * -(-int(v.data.shape[3]) // ci)) / ct
             sub = nl * (jb1 - jb0 + 1) * int(rvars["Air Temperature"].data.shape[3])
-            per_slot_step = sum(2 * sub * v.data.dtype.itemsize for v in rvars.values()) + 5 * nl * ny * nx * (8 if common == np.float64 else 4)
+            per_slot_step = sum(2 * sub * v.data.dtype.itemsize for v in rvars.values())      # compressed + inflated + raw sub-cube, per slot
+            decoded_step = 5 * nl * ny * nx * (8 if common == np.float64 else 4)               # the decoded cubes: ONE set (below)
             avail = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)      # free + what torch caches
-            by_memory = int(0.45 * avail / (slots * per_slot_step)) - 2
+            by_memory = int(0.45 * avail / (slots * per_slot_step + decoded_step)) - 2
             chunk_steps = int(np.clip(-(-13000 // max(int(per_step), 1)), 8, max(8, min(32, by_memory))))
+            # ... or a third of the series, whichever is smaller: a short series should run its three slots round, not size each of
+            # them for most of the file (device buffers are paid for per byte: 10-17 ms per GB of hipMalloc, profiles/r05_notes.md)
+            chunk_steps = min(chunk_steps, max(8, -(-(t1 - t0) // slots)))
     chunk_steps = max(1, min(int(chunk_steps), t1 - t0))
     span = chunk_steps + 2                                                # own steps + the one-step halo of T either side
     # staged sub-cube of every file time step: the kept levels (already in output order) x the latitude band of the domain
@@ -738,7 +750,12 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
         chunk_steps = max(1, min(chunk_steps, max(8, -(-(t1 - t0) // (2 * slots)))))
         span = chunk_steps + 2
     stagers = {r: _make_stager(rvars[r], span, dev, file_levels, j0, j1, slots, not direct, inflate, spans if chunk_direct else None) for r in roles}
-    cubes = [{keys[r]: torch.empty((span, nl, ny, nx), dtype=out_dtype, device=dev) for r in roles} for _ in range(slots)]
+    # ONE set of decoded cubes, not one per slot: lec_ingest writes them and lec_rowstats reads them on the same (compute) stream, chunk
+    # after chunk in order, so the next chunk's decode cannot overtake this chunk's row pass; what the slots double-buffer is the RAW
+    # side (uploads and the device inflate run ahead on their own streams).  Rounds 1-4 held `slots` sets: a third of the 114 GB a
+    # global ERA5 box allocated for a 37-GB series.  (All five are `span` steps long: the kernels index every field with the same time
+    # index, and only T's halo rows are ever written in the others.)
+    cubes = {keys[r]: torch.empty((span, nl, ny, nx), dtype=out_dtype, device=dev) for r in roles}
     up = lambda a: torch.as_tensor(a, dtype=torch.int32).to(dev)
     maps = (up(np.searchsorted(file_levels, plan.kmap)), up(plan.jmap - j0), up(plan.imap))   # maps into the staged sub-cube
     own_boxes = boxes[t0:t1] if per_step_boxes else boxes
@@ -761,6 +778,7 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
     phi_scale = ds.field_scale(variable_list_df, geo_role)
 
     t_setup = time.perf_counter()               # (tables, staging / device buffers allocated)
+    mem_setup = torch.cuda.memory_allocated(dev) - mem_enter
     compute = torch.cuda.current_stream(dev)
     copier = torch.cuda.Stream(device=dev)
     copied = [[torch.cuda.Event() for _ in roles] for _ in range(slots)]      # the variable's upload of the slot has landed
@@ -816,12 +834,12 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
             with torch.cuda.device(dev):
                 unit = 1.0 if r == geo_role else ds.field_scale(variable_list_df, r)
                 _ingest_call(lib, rvars[r], stagers[r].raw_dev[slot][a].data_ptr(), b - a, (nl_in, ny_in, nx_in, nl, ny, nx), maps, unit,
-                             decode[r], common, cubes[slot][keys[r]][a].data_ptr(), compute)
+                             decode[r], common, cubes[keys[r]][a].data_ptr(), compute)
         consumed[slot].record(compute)
-        f = {k: t[: h1 - h0] for k, t in cubes[slot].items()}
+        f = {k: t[: h1 - h0] for k, t in cubes.items()}
         if keep is not None:                    # (u, v, geopotential start at their own first step: rows [c0 - h0, c1 - h0) of the slot)
             for k in keep:
-                keep[k][c0 - t0: c1 - t0].copy_(cubes[slot][k][c0 - h0: c1 - h0, k_keep])
+                keep[k][c0 - t0: c1 - t0].copy_(cubes[k][c0 - h0: c1 - h0, k_keep])
         part = own_boxes.part(c0 - t0, c1 - t0) if per_step_boxes else fixed_box
         engine.rowstats(f["tair"], f["u"], f["v"], f["omega"], f["geopt"], part,
                         tcoef=tcoef_all[h0:h1] if with_q else None, t_begin=c0 - h0, t_count=c1 - c0, with_q=with_q,
@@ -844,7 +862,7 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
         if keep is not None:
             stats["level_slices"] = keep
         stats.update(inflate="device" if on_device else ("host" if any(hasattr(v.data, "chunk_streams") for v in rvars.values()) else "none"))
-        stats.update(row_record_bytes=rows.numel() * 8, levraw_bytes=levraw.numel() * 8)
+        stats.update(row_record_bytes=rows.numel() * 8, levraw_bytes=levraw.numel() * 8, device_buffer_bytes=int(mem_setup))
         torch.cuda.synchronize(dev)
         stats.update(seconds=dict(setup=t_setup - t_enter, chunk_loop_host=t_loop - t_setup, drain=time.perf_counter() - t_loop,
                                   registering=(spans.seconds if spans is not None else 0.0)))

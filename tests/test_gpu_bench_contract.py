@@ -46,6 +46,7 @@ def test_bench_json_contract():
     pr = d["parity"]
     assert pr["ok"] is True and pr["worst_rel_to_scale"] <= 1e-9 and pr["levels_worst_rel_to_scale"] <= 1e-9
     assert pr["steps"] == 2 and pr["terms_compared"] == 16 and pr["level_tables_compared"] == 21 and "59 x 128" in pr["box"]     # polar rows left out
+    assert d["config"]["baseline_config"]["id"] is None        # a small grid is not a BASELINE configuration (3 needs 37 x 721 x 1440)
     # where a pass's time goes
     sg = d["config"]["segments_ms"]
     for k in ("stage1", "stage2", "gather", "pass_total_synchronised", "pass_timed_unsynchronised", "stage1_kernels_hip_events", "fixed_cost_per_pass"):
@@ -74,12 +75,27 @@ def test_bench_starts_its_own_ranks_and_counts_them():
         assert k in sg, k
 
 
+def test_a_two_rank_line_carries_the_cpu_leg_and_the_parity_of_rank_0():
+    """north_star: the N-GPU throughput "next to the reference CPU path timed on the node's own host cores in the same run".  Rank 0 runs
+    the oracle after the timed region while rank 1 waits in the closing barrier; `parity` is rank 0's shard against the oracle."""
+    r, lines = _bench(["--gpus", "2", "--timesteps", "3", "--cpu-baseline", "full"] + SMALL, env={"LEC_DIST_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert [ln for ln in r.stdout.splitlines() if ln.strip()] == lines and len(lines) == 1
+    d = json.loads(lines[0])
+    cb, pr = d["cpu_baseline"], d["parity"]
+    assert d["n_gpus"] == 2 and cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["ranks_waiting_in_the_closing_barrier"] == 1
+    assert "all_cores" not in cb and "1 repetition" in cb["sample"]                 # "full" becomes the one-thread leg at N > 1
+    assert pr["ok"] is True and pr["steps"] == 3 and pr["shard"] == "rank 0 of 2: global time steps 0..2" and pr["terms_compared"] == 16
+    assert d["config"]["baseline_config"]["id"] is None
+
+
 def test_bench_runs_the_rccl_code_path_with_one_rank():
     """--force-dist: process group over backend "nccl" (= RCCL), barrier, the mask all_reduce and the gather run with world size 1 --
     the N > 1 code path of the product on the one GPU this box has (more RCCL ranks need more GPUs)."""
-    r, lines = _bench(["--force-dist", "--timesteps", "3", "--cpu-baseline", "none"] + SMALL)
+    r, lines = _bench(["--force-dist", "--timesteps", "3", "--cpu-baseline", "quick"] + SMALL)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads(lines[0])
+    assert d["cpu_baseline"]["value"] > 0 and d["parity"]["ok"] is True          # the CPU leg runs on the distributed code path too
     assert [ln for ln in r.stdout.splitlines() if ln.strip()] == lines          # RCCL's version banner went to stderr
     assert d["n_gpus"] == 1 and d["config"]["backend"] == "nccl" and d["config"]["results_finite"] is True and d["config"]["gathered_series_ok"] is True
     assert "mask_all_reduce" in d["config"]["segments_ms"] and "gather.collective" in d["config"]["segments_ms"]

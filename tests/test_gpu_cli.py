@@ -179,6 +179,36 @@ def test_reg1_sample_tables_pin_the_engine(workdir, golden_dir, kind, ingest):
     print(kind, ingest, worst)
 
 
+def test_ingest_auto_falls_back_to_the_host_preparation(workdir, monkeypatch):
+    """`--ingest auto` (the default) sends a deflated NetCDF-4 file to the streamed device path by itself.  If that path then refuses
+    the input (ValueError / NotImplementedError), the run must not fail where the host preparation works: the file is closed, the
+    reason logged, the data prepared on the host -- same files as `--ingest host`.  Asked for by name, the refusal stands."""
+    from lorenzcycletoolkit_amd import ingest
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(ROOT, "tests", "golden", "hdf5", "cds_new_layout.nc")
+    shutil.copy(os.path.join(ROOT, "inputs", "namelist_ERA5-copernicus-new"), workdir / "inputs" / "namelist")
+    (workdir / "inputs" / "box_limits").write_text("min_lon;-60\nmax_lon;30\nmin_lat;-40\nmax_lat;30\n")
+    out = workdir / "LEC_Results" / "cds_new_layout_fixed"
+    tree = lambda: {os.path.relpath(os.path.join(d, f), out): open(os.path.join(d, f), "rb").read()
+                    for d, _, fs in os.walk(out) for f in fs if not f.startswith("log.")}
+    _main([src, "-r", "-f", "--ingest", "host"])
+    host = tree()
+    shutil.rmtree(out)
+    closed = []
+    real_close = ingest.ds.RawDataset.close
+    monkeypatch.setattr(ingest.ds.RawDataset, "close", lambda self: (closed.append(1), real_close(self))[1])
+
+    def refuse(*a, **k):
+        raise ValueError("simulated refusal of the streamed path")
+    monkeypatch.setattr(ingest, "lec_streamed", refuse)
+    _main([src, "-r", "-f"])                                       # auto: device chosen, refused in mid-run, host preparation takes over
+    assert tree() == host and closed
+    log = open(out / "log.cds_new_layout").read()
+    assert "whose chunks the GPU can inflate" in log and "simulated refusal" in log and "preparing the data on the host instead" in log
+    with pytest.raises(ValueError, match="simulated refusal"):
+        _main([src, "-r", "-f", "--ingest", "device"])
+
+
 def _write_era5_style(path, nt=6):
     """What the reference's missing samples/testdata_ERA5.nc looks like to the toolkit: namelist_ERA5 names (T, Z, W, U, V; time,
     level, latitude, longitude), hourly from 2005-08-09, int16-packed, latitudes N -> S, levels in millibars incl. 850 hPa."""

@@ -320,3 +320,44 @@ def test_ingest_auto_takes_the_device_for_deflated_files_only(workdir, golden_di
     args = cli.create_arg_parser().parse_args(["x.nc", "-r", "-f"])
     assert args.ingest == "auto" and args.device_ingest is False
     assert cli.create_arg_parser().parse_args(["x.nc", "-r", "-f", "--ingest", "host"]).ingest == "host"
+
+
+def test_a_refused_metadata_layout_names_the_object_and_leaves_only_the_log(workdir, golden_dir):
+    """hdf5_lite follows dense link / attribute storage through unfiltered fractal heaps with direct blocks.  A FILTERED heap (compressed
+    metadata) is refused -- there is no other HDF5 reader here to fall back on -- and the refusal must say which object of which file
+    and how to get past it (nccopy).  Through the command line the run fails before anything is computed; like the reference the
+    results tree exists by then (lorenzcycletoolkit.py:250-258 there), and what this run created is removed again except the log, which
+    carries the error.  (The fixture: float_contiguous_latest.nc with the filter-length field of ONE of its six heaps set, heap by heap.)"""
+    import re
+    import shutil
+    import lorenzcycletoolkit as cli
+    blob = open(os.path.join(FIX, "float_contiguous_latest.nc"), "rb").read()
+    heaps = [m.start() for m in re.finditer(b"FRHP", blob)]
+    assert len(heaps) == 6
+    seen = set()
+    for at in heaps:
+        bad = bytearray(blob)
+        bad[at + 7: at + 9] = (12).to_bytes(2, "little")          # "I/O filters' encoded length" of the heap header
+        path = workdir / "filtered_heap.nc"
+        path.write_bytes(bytes(bad))
+        with pytest.raises(hdf5_lite.Hdf5Error) as e:
+            hdf5_lite.H5File(str(path))
+        msg = str(e.value)
+        assert str(path) in msg and "FILTERED fractal heap" in msg and "nccopy -k cdf5" in msg and "nccopy -k nc4 -d0" in msg
+        seen.add(re.search(r"attributes of (the root group|the dataset '\w+')", msg).group(1))
+    assert seen == {"the root group"} | {f"the dataset '{v}'" for v in "tuvwz"}
+    # through the command line (host preparation: no GPU is touched before the reader refuses)
+    (workdir / "inputs" / "box_limits").write_text("min_lon;-60\nmax_lon;30\nmin_lat;-40\nmax_lat;30\n")
+    out = workdir / "LEC_Results" / "filtered_heap_fixed"
+    with pytest.raises(hdf5_lite.Hdf5Error, match="nccopy"):
+        cli.main([str(path), "-r", "-f", "--ingest", "host"])
+    assert sorted(os.listdir(out)) == ["log.filtered_heap"]
+    log = open(out / "log.filtered_heap").read()
+    assert "LEC analysis failed" in log and "FILTERED fractal heap" in log and "nccopy" in log
+    # a tree that held earlier results is left alone
+    os.makedirs(out / "results_vertical_levels")
+    (out / "earlier_results.csv").write_text("kept\n")
+    with pytest.raises(hdf5_lite.Hdf5Error):
+        cli.main([str(path), "-r", "-f", "--ingest", "host"])
+    assert (out / "earlier_results.csv").read_text() == "kept\n" and (out / "results_vertical_levels").is_dir()
+    shutil.rmtree(workdir / "LEC_Results")

@@ -180,6 +180,46 @@ def test_registered_spans_bookkeeping():
     assert rt.reg == {} and sp.blocks == []
 
 
+def test_a_registration_refused_in_mid_call_leaves_no_untracked_block():
+    """ensure() over a range with a registered block in its middle registers TWO new blocks; the runtime refuses the second.  The first
+    stays tracked: a later request over its pages finds it covered (no overlapping registration, which the runtime would refuse
+    too -- one refusal would cascade every variable into the pinned fallback), and close() releases it."""
+    from lorenzcycletoolkit_amd import _lib, ingest
+
+    class Runtime:
+        def __init__(self):
+            self.reg, self.calls, self.fail_at = {}, 0, None
+
+        def lec_host_register(self, p, n):
+            self.calls += 1
+            if self.calls == self.fail_at:
+                return 2
+            a = p.value
+            assert all(a >= e or a + n <= b for b, e in self.reg.items()), "overlapping registration"
+            self.reg[a] = a + n
+            return 0
+
+        def lec_host_unregister(self, p):
+            del self.reg[p.value]
+            return 0
+
+    rt = Runtime()
+    sp = ingest.RegisteredSpans(rt)
+    base = 1 << 30
+    sp.ensure(base + 8192, base + 12288, 0)
+    rt.fail_at = 3                                        # the call below registers [base, base+8192) (2nd call) and [base+12288, base+20480) (3rd)
+    with pytest.raises(_lib.LecLibraryError):
+        sp.ensure(base, base + 20480, 1)
+    assert [b[:2] for b in sp.blocks] == [[base, base + 8192], [base + 8192, base + 12288]] and set(rt.reg) == {base, base + 8192}
+    rt.fail_at = None
+    sp.ensure(base + 100, base + 9000, 2)                 # covered: nothing new is registered (an untracked block would be registered AGAIN here)
+    assert rt.calls == 3
+    sp.ensure(base, base + 20480, 2)                      # the refused tail alone
+    assert rt.calls == 4 and sp.registered_bytes == 20480
+    sp.close()
+    assert rt.reg == {} and sp.blocks == []
+
+
 def test_chunk_copy_plan_places_every_stream_and_keeps_its_alignment():
     """ingest.chunk_copy_plan on random layouts: adjacent chunks, small and large gaps, repeated chunks, any order, with and without
     the 4 checksum bytes: copying the runs reproduces every stream at its planned offset, offsets keep the file alignment modulo 16,
