@@ -546,7 +546,12 @@ __global__ void __launch_bounds__(64 * TG, 2) lec_boxtile_kernel(const RowParams
         // ---- up to kLB finished levels x 4 rows: one (level, row) per lane finishes its record
         if (row_done && (slot == kLB - 1 || k == k1 - 1) && !(LEC_BT_ABLATE & 4)) {
 #pragma clang fp contract(off)
-            const int lv = lane >> 2, r = lane & 3;
+            // (the epilogue's lane arithmetic and its scale factors are made opaque here: hoisted out of the pass loop as loop invariants
+            // they cost the shipped instantiation three spilled registers, reloaded from scratch in every pass -- this branch runs once
+            // per four levels)
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const int lv = ln >> 2, r = ln & 3;
             const int jb = jb0 + r;
             if (lv <= slot && jb >= 0 && jb < p.nyb_max && live) {
                 const int kout = k - slot + lv;
@@ -562,6 +567,7 @@ __global__ void __launch_bounds__(64 * TG, 2) lec_boxtile_kernel(const RowParams
 #pragma unroll
                     for (int s = 0; s < kNA; ++s) tot[s] = st[s];
                     double scale = inv_xlen;
+                    asm volatile("" : "+v"(scale));
                     if (UNIFORM) {
                         // the trapezoid's end points, weight 1/2 each: the first point has a = b = c = d = e = 0 (it is the shift),
                         // so only its f counts; the last point brings all 20 monomials

@@ -683,9 +683,10 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
     decode, common = storage_dtypes(rvars)
     out_dtype = torch.float64 if common == np.float64 else torch.float32
     on_gpu = inflate != "host" and any(getattr(v.data, "chunk_streams", lambda: None)() is not None for v in rvars.values())
+    slots_given = slots is not None
     if slots is None:
         # pipeline slots: two keep a copy-bound pipeline full; a launch of the device inflate lasts as long as its slowest chunk
-        # (tens of ms), so a third slot lets the tail of one batch overlap the next two
+        # (tens of ms), so a third slot lets the tail of one batch overlap the next two -- where the buffers stay small (below)
         slots = 3 if on_gpu else 2
     if slots < 2:
         raise ValueError("slots must be >= 2")
@@ -711,6 +712,12 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
             # ... or a third of the series, whichever is smaller: a short series should run its three slots round, not size each of
             # them for most of the file (device buffers are paid for per byte: 10-17 ms per GB of hipMalloc, profiles/r05_notes.md)
             chunk_steps = min(chunk_steps, max(8, -(-(t1 - t0) // slots)))
+            # Two slots instead of three where three would hold more than ~40 GB: measured on the 96-step global ERA5 box (chunks of
+            # 21 steps), 62 GB and 1.39 s against 86 GB and 1.33 s -- while SMALLER chunks cost far more than they save (12 steps:
+            # 1.72 s, 8 steps: 2.06 s) -- and on some boxes the driver makes a process wait ~27 ms per GB it allocates beyond the
+            # first ~35 GB (profiles/r05_notes.md section 4: 1.4 s of `setup` for 86 GB, 0.1-0.6 s for 45 GB, none on other boxes).
+            if not slots_given and slots * (min(chunk_steps, t1 - t0) + 2) * per_slot_step > 40e9:
+                slots = 2
     chunk_steps = max(1, min(int(chunk_steps), t1 - t0))
     span = chunk_steps + 2                                                # own steps + the one-step halo of T either side
     # staged sub-cube of every file time step: the kept levels (already in output order) x the latitude band of the domain
@@ -755,7 +762,11 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
     # side (uploads and the device inflate run ahead on their own streams).  Rounds 1-4 held `slots` sets: a third of the 114 GB a
     # global ERA5 box allocated for a 37-GB series.  (All five are `span` steps long: the kernels index every field with the same time
     # index, and only T's halo rows are ever written in the others.)
-    cubes = {keys[r]: torch.empty((span, nl, ny, nx), dtype=out_dtype, device=dev) for r in roles}
+    # ... and they hold a SUB-CHUNK of `dec_steps` steps (about 1 GiB per field): a chunk's raw sub-cubes are decoded and row-passed
+    # piece by piece (the raw side keeps its large chunks -- the device inflate wants ~13000 streams per batch --, the decoded side
+    # does not need them: 8 steps of a 37 x 721 x 1440 grid are 213,000 rows per launch).  Same kernels on the same rows: same bits.
+    dec_steps = min(chunk_steps, max(4, (1 << 30) // (nl * ny * nx * (8 if common == np.float64 else 4))))
+    cubes = {keys[r]: torch.empty((dec_steps + 2, nl, ny, nx), dtype=out_dtype, device=dev) for r in roles}
     up = lambda a: torch.as_tensor(a, dtype=torch.int32).to(dev)
     maps = (up(np.searchsorted(file_levels, plan.kmap)), up(plan.jmap - j0), up(plan.imap))   # maps into the staged sub-cube
     own_boxes = boxes[t0:t1] if per_step_boxes else boxes
@@ -772,7 +783,7 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
     if keep_level is not None:
         k_keep = int(np.flatnonzero(plan.level == float(keep_level))[0])
         keep = {k: torch.empty((t1 - t0, ny, nx), dtype=out_dtype, device=dev) for k in ("u", "v", "geopt")}
-    rows = torch.empty((chunk_steps, nl, bt.nyb_max, _lib.LEC_NSTAT), dtype=torch.float64, device=dev)
+    rows = torch.empty((dec_steps, nl, bt.nyb_max, _lib.LEC_NSTAT), dtype=torch.float64, device=dev)
     levraw = torch.empty((t1 - t0, nl, _lib.LEC_NLEVRAW), dtype=torch.float64, device=dev)
     time_s = plan.time_s
     phi_scale = ds.field_scale(variable_list_df, geo_role)
@@ -831,20 +842,26 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
                         moved += (b - a) * stagers[r].step_elems * stagers[r].itemsize
                 copied[slot][n].record(up)
             compute.wait_event(copied[slot][n])
+        # decode + row pass, sub-chunk by sub-chunk: T with the one-step halo of the SUB-chunk (rows of the raw slot count from h0)
+        for s0 in range(c0, c1, dec_steps):
+            s1 = min(s0 + dec_steps, c1)
+            g0, g1 = (max(s0 - 1, 0), min(s1 + 1, nt)) if with_q else (s0, s1)
             with torch.cuda.device(dev):
-                unit = 1.0 if r == geo_role else ds.field_scale(variable_list_df, r)
-                _ingest_call(lib, rvars[r], stagers[r].raw_dev[slot][a].data_ptr(), b - a, (nl_in, ny_in, nx_in, nl, ny, nx), maps, unit,
-                             decode[r], common, cubes[keys[r]][a].data_ptr(), compute)
+                for r in roles:
+                    a, b = (g0 - h0, g1 - h0) if r == "Air Temperature" else (s0 - h0, s1 - h0)
+                    unit = 1.0 if r == geo_role else ds.field_scale(variable_list_df, r)
+                    _ingest_call(lib, rvars[r], stagers[r].raw_dev[slot][a].data_ptr(), b - a, (nl_in, ny_in, nx_in, nl, ny, nx), maps, unit,
+                                 decode[r], common, cubes[keys[r]][a - (g0 - h0)].data_ptr(), compute)
+            f = {k: t[: g1 - g0] for k, t in cubes.items()}
+            if keep is not None:                # (u, v, geopotential start at their own first step: rows [s0 - g0, s1 - g0) of the cubes)
+                for k in keep:
+                    keep[k][s0 - t0: s1 - t0].copy_(cubes[k][s0 - g0: s1 - g0, k_keep])
+            part = own_boxes.part(s0 - t0, s1 - t0) if per_step_boxes else fixed_box
+            engine.rowstats(f["tair"], f["u"], f["v"], f["omega"], f["geopt"], part,
+                            tcoef=tcoef_all[g0:g1] if with_q else None, t_begin=s0 - g0, t_count=s1 - s0, with_q=with_q,
+                            rows_out=rows[: s1 - s0], per_step_boxes=per_step_boxes)
+            engine.level_stage(rows[: s1 - s0], part, levraw[s0 - t0: s1 - t0], phi_scale=phi_scale)
         consumed[slot].record(compute)
-        f = {k: t[: h1 - h0] for k, t in cubes.items()}
-        if keep is not None:                    # (u, v, geopotential start at their own first step: rows [c0 - h0, c1 - h0) of the slot)
-            for k in keep:
-                keep[k][c0 - t0: c1 - t0].copy_(cubes[k][c0 - h0: c1 - h0, k_keep])
-        part = own_boxes.part(c0 - t0, c1 - t0) if per_step_boxes else fixed_box
-        engine.rowstats(f["tair"], f["u"], f["v"], f["omega"], f["geopt"], part,
-                        tcoef=tcoef_all[h0:h1] if with_q else None, t_begin=c0 - h0, t_count=c1 - c0, with_q=with_q,
-                        rows_out=rows[: c1 - c0], per_step_boxes=per_step_boxes)
-        engine.level_stage(rows[: c1 - c0], part, levraw[c0 - t0: c1 - t0], phi_scale=phi_scale)
         used[slot] = True
     t_loop = time.perf_counter()                # (every chunk enqueued)
     res = engine.vertical_stage(levraw, own_boxes if per_step_boxes else fixed_box, drop_any_time=not per_step_boxes,

@@ -72,11 +72,13 @@ def drop_cache(path):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r04_cli_end_to_end.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r05_cli_end_to_end.json"))
     ap.add_argument("--big-steps", type=int, default=96)
     ap.add_argument("--big-dir", default=os.environ.get("TMPDIR", "/tmp"))
     ap.add_argument("--skip-big", action="store_true")
     ap.add_argument("--layout", default="era5_int16")
+    ap.add_argument("--long-steps", type=int, default=744, help="also time a LONG series on a small grid (a month of hourly steps, 37 x 41 x 80, "
+                    "shuffle + deflate: the host phases -- chunk index, CSV writing -- dominate there); 0 = skip")
     ap.add_argument("--classic-steps", type=int, default=24, help="also time an uncompressed CLASSIC NetCDF file of this many ERA5-size steps (0 = skip)")
     a = ap.parse_args()
     results = {"host": {"cpus": os.cpu_count()}, "cases": []}
@@ -148,6 +150,28 @@ def main():
                 finally:
                     if os.path.exists(big):
                         os.remove(big)
+    if not a.skip_big and a.long_steps > 0 and results.get("h5py_on_this_box"):
+        big = os.path.join(a.big_dir, f"era5_long_T{a.long_steps}.nc")
+        t0 = time.time()
+        r = subprocess.run([CONDA, os.path.join(ROOT, "tools", "make_big_nc4.py"), "--out", big, "--timesteps", str(a.long_steps), "--ny", "41", "--nx", "80"],
+                           capture_output=True, text=True)
+        results["long_file"] = {"path": big, "write_s": time.time() - t0, "note": r.stdout.strip()[-400:], "returncode": r.returncode, "stderr": r.stderr[-400:],
+                                "bytes": os.path.getsize(big) if os.path.exists(big) else 0}
+        print(results["long_file"], flush=True)
+        save()
+        if r.returncode == 0:
+            try:
+                with tempfile.TemporaryDirectory() as wd:
+                    os.makedirs(os.path.join(wd, "inputs"))
+                    open(os.path.join(wd, "inputs", "namelist"), "w").write(NAMELIST_ERA5)
+                    open(os.path.join(wd, "inputs", "box_limits"), "w").write("min_lon;-80\nmax_lon;-20\nmin_lat;-60\nmax_lat;-10\n")
+                    for rep in ("first", "second", "third"):
+                        results["cases"].append(run_case(wd, [big, "-r", "-f"], f"long:regional_box_fixed:default_flags:{rep}", timeout=600))
+                        print(json.dumps(results["cases"][-1])[:600], flush=True)
+                        save()
+            finally:
+                if os.path.exists(big):
+                    os.remove(big)
     if not a.skip_big and a.classic_steps > 0:
         big = os.path.join(a.big_dir, f"era5_classic_T{a.classic_steps}.nc")
         t0 = time.time()

@@ -5,6 +5,9 @@
 //   B  one wave per box row (61 of 64 lanes; the one-wave-per-row kernel's mapping)
 //   C  as A, whole 128-byte lines: segments widened to the enclosing 16-element-aligned span (where rows are aligned)
 //   S  contiguous stream of the same number of bytes per field
+//   E  (round 5) a per-step, box-ALIGNED crop: cubes [T][37][61][64] -- every box row starts on a 128-byte line and has a 512-byte
+//      pitch, what a crop written per time step by lec_ingest for the moving framework would give (4 lines per 61-point row instead
+//      of 4.8) -- read one wave per row like B; the rate is quoted on the same ALGORITHMIC bytes (61 x 61 x 8 per level and field)
 // Build: hipcc -O3 --offload-arch=gfx950 probe_boxread.hip -o probe_boxread ; run: ./probe_boxread [T]
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -14,7 +17,7 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 constexpr int NL = 37, NY = 162, NX = 243, NB = 61;
-struct P { const double* f[8]; const int* box; double* out; int T; int nx; int ny; };
+struct P { const double* f[8]; const double* g[8]; const int* box; double* out; int T; int nx; int ny; };
 
 template <int NF, int VARIANT>
 __global__ void __launch_bounds__(256) probe(const P p) {
@@ -46,6 +49,14 @@ __global__ void __launch_bounds__(256) probe(const P p) {
         for (int r = w; r < NB; r += 4) {
 #pragma unroll
             for (int f = 0; f < NF; ++f) acc += __builtin_nontemporal_load(p.f[f] + base + (size_t)(js + r) * p.nx + col);
+        }
+    } else if (VARIANT == 5) {
+        const int lane = tid & 63, w = tid >> 6;
+        const size_t cbase = ((size_t)tl * NL + k) * (NB * 64);
+        const int col = min(lane, NB - 1);
+        for (int r = w; r < NB; r += 4) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f) acc += __builtin_nontemporal_load(p.g[f] + cbase + (size_t)r * 64 + col);
         }
     } else if (VARIANT == 4) {
         // D: 16 bytes per lane (two columns), 32 lanes per row, two rows per wave instruction (rows are only 8-byte aligned)
@@ -90,6 +101,8 @@ int main(int argc, char** argv) {
     const size_t n = (size_t)T * NL * NY * nx;
     P p; p.T = T; p.nx = nx; p.ny = NY;
     for (int f = 0; f < 7; ++f) { double* d; CK(hipMalloc(&d, n * 8)); CK(hipMemset(d, 0, n * 8)); p.f[f] = d; }
+    const size_t nc = (size_t)T * NL * NB * 64;
+    for (int f = 0; f < 7; ++f) { double* d; CK(hipMalloc(&d, nc * 8)); CK(hipMemset(d, 0, nc * 8)); p.g[f] = d; }
     std::vector<int> box(2 * T);
     for (int t = 0; t < T; ++t) {
         const double clat = -37.5 + 12.0 * sin(2 * M_PI * t / 400.0), clon = -50.0 + 22.0 * cos(2 * M_PI * t / 700.0);
@@ -100,9 +113,9 @@ int main(int argc, char** argv) {
     const double gb = (double)T * NL * NB * NB * 8 / 1e9;      // algorithmic GB per field
     printf("T=%d nx=%d: %.3f GB per field per launch\n", T, nx, gb);
 #define ROW(NF) do { \
-    const float a = run<NF, 0>(p, 5), b = run<NF, 1>(p, 5), c = run<NF, 2>(p, 5), s = run<NF, 3>(p, 5), d = run<NF, 4>(p, 5); \
-    printf("NF=%d  A strips %.3f ms %.0f GB/s | B rows %.3f ms %.0f GB/s | C aligned spans %.3f ms %.0f GB/s (algorithmic) | D 16B/lane 2 rows %.3f ms %.0f GB/s | S stream %.3f ms %.0f GB/s\n", \
-           NF, a, NF * gb / a * 1e3, b, NF * gb / b * 1e3, c, NF * gb / c * 1e3, d, NF * gb / d * 1e3, s, NF * gb / s * 1e3); } while (0)
+    const float a = run<NF, 0>(p, 5), b = run<NF, 1>(p, 5), c = run<NF, 2>(p, 5), s = run<NF, 3>(p, 5), d = run<NF, 4>(p, 5), e = run<NF, 5>(p, 5); \
+    printf("NF=%d  A strips %.3f ms %.0f GB/s | B rows %.3f ms %.0f GB/s | C aligned spans %.3f ms %.0f GB/s (algorithmic) | D 16B/lane 2 rows %.3f ms %.0f GB/s | S stream %.3f ms %.0f GB/s | E aligned per-step crop, rows %.3f ms %.0f GB/s\n", \
+           NF, a, NF * gb / a * 1e3, b, NF * gb / b * 1e3, c, NF * gb / c * 1e3, d, NF * gb / d * 1e3, s, NF * gb / s * 1e3, e, NF * gb / e * 1e3); } while (0)
     ROW(1); ROW(4); ROW(5); ROW(7);
     return 0;
 }
