@@ -47,7 +47,8 @@ extern "C" {
 /* ABI 8 (round 4): lec_reduce_args.stage (the two halves of stage 2 run apart; no 65535-step limit), lec_inflate_args.dst_bytes and
  * lec_chunk_scatter_args.src_bytes (the destination / payload ranges of every descriptor are bounds-checked on the device). */
 #define LEC_ABI_VERSION 9
-/* ABI 9 (round 5): lec_format_csv_rows (host): a per-level table as the text pandas writes for it, one call per table. */
+/* ABI 9 (round 5): lec_format_csv_rows (host): a per-level table as the text pandas writes for it, one call per table;
+ * lec_rowstats_args.tm_d / tp_d: box-packed series of the moving framework (the struct grew by two pointers at its end). */
 
 /* number of fp64 values per (time, level, lat) row record written by lec_rowstats */
 #define LEC_NSTAT 32
@@ -124,6 +125,18 @@ enum lec_stat {
  * tc[t][2] T[t+1] with tc = tcoef_d (np.gradient coefficients over the cube's time axis;
  * thermodynamics.py:109-110), neighbours taken from the same cube (so the cube must include the
  * halo time steps a shard needs; coefficients of non-existent neighbours must be 0).
+ *
+ * Box-packed series (ABI 9; box_per_step == 1, served by the box-tile kernel).  The reference's moving framework slices the box of
+ * every time step out of the data (src/utils/box_data.py:297-310) before anything is computed; a producer that gathers anyway -- the
+ * device ingest from file bytes, a host that uploads a track -- may hand over just those slices: cubes [nt][nl][ny][nx] whose step t
+ * holds box t alone, its south-west corner at [t][k][0][0] (ny, nx >= the tallest / widest box; what lies outside a step's box is
+ * never read).  `box_d` then describes the boxes AS THE CUBES HOLD THEM, {0, nxb - 1, 0, nyb - 1}, while every table indexed by box
+ * (boxtab_d, wlon_d, glon_d, lattab_d) is built from the box's true grid coordinates as always.  The cube's time neighbours of step t
+ * are other boxes, so T(t - 1) and T(t + 1) ON THE BOX OF STEP t come in two more cubes of the same layout, `tm_d` / `tp_d` (the step
+ * itself where a neighbour does not exist: its coefficient is 0 -- but 0 x NaN is NaN), and dT/dt = tc[t][0] tm[t] + tc[t][1] T[t] +
+ * tc[t][2] tp[t].  Same arithmetic on the same values: the row records are bit-identical to those of the unpacked cubes.  Rows of
+ * 488 bytes scattered through a 243-column crop replay at 4.8 TB/s on MI355X, a step's box stored as one dense block at 5.7
+ * (tools/probes/probe_boxread.hip) -- and a producer writes a tenth of the bytes.
  */
 typedef struct lec_rowstats_args {
     /* fields */
@@ -153,6 +166,9 @@ typedef struct lec_rowstats_args {
     double* rows_d;             /* [t_count][nl][nyb_max][LEC_NSTAT] */
     void* stream;
     lec_tuning tuning;          /* all zero = defaults */
+    /* ABI 9: a BOX-PACKED series (see above); both NULL otherwise */
+    const void* tm_d;           /* T of the previous time step on the box of step t, laid out like tair_d */
+    const void* tp_d;           /* T of the next time step on the box of step t */
 } lec_rowstats_args;
 
 /*

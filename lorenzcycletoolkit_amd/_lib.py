@@ -67,6 +67,7 @@ class RowstatsArgs(C.Structure):
         ("lattab_d", C.c_void_p), ("levtab_d", C.c_void_p), ("tcoef_d", C.c_void_p),
         ("rows_d", C.c_void_p), ("stream", C.c_void_p),
         ("tuning", Tuning),
+        ("tm_d", C.c_void_p), ("tp_d", C.c_void_p),
     ]
 
 

@@ -238,8 +238,10 @@ __global__ void __launch_bounds__(64 * TG, 2) lec_boxtile_kernel(const RowParams
     const bool has_p = p.P != nullptr;
     const TIN* __restrict__ gP = (const TIN*)(has_p ? p.P : p.T) + t0off;
     // neighbours in time: the own time step where there is none (the coefficient is 0 there); MODE 2: the dT/dt cube
-    const TIN* __restrict__ gD0 = (MODE == 2) ? (const TIN*)p.DT + t0off : ((t > 0) ? gT - cube : gT);
-    const TIN* __restrict__ gD1 = (t < p.nt - 1) ? gT + cube : gT;
+    // (a box-packed series: the cube's neighbouring steps hold other boxes; T(t-1), T(t+1) on THIS step's box come in cubes of their own)
+    const bool packed = TG == 1 && MODE == 1 && p.TM != nullptr;
+    const TIN* __restrict__ gD0 = (MODE == 2) ? (const TIN*)p.DT + t0off : (packed ? (const TIN*)p.TM + t0off : ((t > 0) ? gT - cube : gT));
+    const TIN* __restrict__ gD1 = packed ? (const TIN*)p.TP + t0off : ((t < p.nt - 1) ? gT + cube : gT);
     double ta = 0, tb = 0, tc = 0;
     if (MODE == 1) { const double* tcf = p.tcoef + (size_t)t * 3; ta = tcf[0]; tb = tcf[1]; tc = tcf[2]; }
     // which time neighbours come from the group's LDS (the previous / next wave's own T rows) instead of from memory
@@ -604,7 +606,7 @@ int launch_tiles(RowParams p, bool uniform, int mode, int tg, hipStream_t st) {
     const bool window = mode != 0 && p.nxb_max <= kCW;    // same arithmetic either way: only where the T neighbours come from differs
     // time groups: TG consecutive steps per workgroup share T(t +- 1) through LDS (per-point dT/dt from the cube, one column chunk)
     if (tg == 0) tg = kDefaultTG;
-    if (!(mode == 1 && window) || p.t_count < 2) tg = 1;
+    if (!(mode == 1 && window) || p.t_count < 2 || p.TM) tg = 1;      // (box-packed: the steps' boxes share no grid rows in memory)
     const long long n_rb = tg > 1 ? (p.nyb_max + 3 + kWR - 1) / kWR : (p.nyb_max + kWR - 1) / kWR;     // (room for boxes up to 3 rows apart)
     p.jrows = (int)n_rb;
     const long long n_units = (p.t_count + tg - 1) / tg;  // workgroups along time

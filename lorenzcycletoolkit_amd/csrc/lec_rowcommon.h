@@ -140,6 +140,7 @@ __device__ __forceinline__ double block_sums(const double (&v)[N], double* red, 
 
 struct RowParams {
     const void* T; const void* U; const void* V; const void* W; const void* P; const void* DT;
+    const void* TM; const void* TP;      // box-packed series (box-tile kernel only): T(t-1), T(t+1) on the box of step t; else null
     int nt, nl, ny, nx;
     int t_begin, t_count;
     int n_box, nxb_max, nyb_max;

@@ -331,6 +331,12 @@ extern "C" int lec_rowstats(const lec_rowstats_args* a) {
         if (!a->dTdt_d && !a->tcoef_d) return lec_set_error(LEC_ERR_ARG, "lec_rowstats: with_q needs dTdt_d or tcoef_d");
         if (!a->dTdt_d && a->nt < 2) return lec_set_error(LEC_ERR_ARG, "lec_rowstats: dT/dt from the cube needs nt >= 2");
     }
+    const bool packed = a->tm_d || a->tp_d;
+    if (packed) {      // a box-packed series: per-step boxes at the origin of their slabs, time neighbours in cubes of their own
+        if (!a->tm_d || !a->tp_d) return lec_set_error(LEC_ERR_ARG, "lec_rowstats: a box-packed series needs both tm_d and tp_d");
+        if (!a->box_per_step || !a->with_q || a->dTdt_d || !a->tcoef_d)
+            return lec_set_error(LEC_ERR_ARG, "lec_rowstats: tm_d / tp_d go with box_per_step, with_q, tcoef_d and no dTdt_d");
+    }
     const lec_tuning& tu = a->tuning;
     if (tu.kernel < LEC_KERNEL_AUTO || tu.kernel > LEC_KERNEL_BOX_TILE) return lec_set_error(LEC_ERR_ARG, "lec_rowstats: tuning.kernel is not an enum lec_kernel value");
     if (tu.order != LEC_ORDER_AUTO && tu.order != LEC_ORDER_MEMORY && tu.order != LEC_ORDER_XCD_LAT && tu.order != LEC_ORDER_XCD_TILED)
@@ -350,7 +356,9 @@ extern "C" int lec_rowstats(const lec_rowstats_args* a) {
     }
     const size_t esz = a->dtype == LEC_F32 ? 4 : 8;
     const int vecw = (int)(16 / esz);
-    const void* cubes[6] = {a->tair_d, a->u_d, a->v_d, a->omega_d, a->geopt_d, a->dTdt_d};
+    if (packed && (!tile_call || tu.block_shape > 1))
+        return lec_set_error(LEC_ERR_ARG, "lec_rowstats: a box-packed series runs on the box-tile kernel, one time step per workgroup");
+    const void* cubes[8] = {a->tair_d, a->u_d, a->v_d, a->omega_d, a->geopt_d, a->dTdt_d, a->tm_d, a->tp_d};
     bool aligned = (a->nx % vecw) == 0, aligned8 = (a->nx % 2) == 0;
     for (const void* c : cubes) {
         if (!c) continue;
@@ -364,6 +372,7 @@ extern "C" int lec_rowstats(const lec_rowstats_args* a) {
 
     RowParams p;
     p.T = a->tair_d; p.U = a->u_d; p.V = a->v_d; p.W = a->omega_d; p.P = a->geopt_d; p.DT = a->dTdt_d;
+    p.TM = a->tm_d; p.TP = a->tp_d;
     p.nt = a->nt; p.nl = a->nl; p.ny = a->ny; p.nx = a->nx;
     p.t_begin = a->t_begin; p.t_count = a->t_count;
     p.n_box = a->box_per_step ? 2 : 1;      // kernels index the box tables by time step iff n_box != 1

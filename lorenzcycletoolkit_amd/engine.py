@@ -125,12 +125,38 @@ class LECEngine:
         """Nearest-grid-point inclusive box, as BoxData._set_domain_limits (box_data.py:115-131)."""
         return tables.box_indices(self.lat, self.lon, west, east, south, north)
 
-    def prepare_boxes(self, boxes, nyb_min: int = 0) -> PreparedBoxes:
+    def prepare_boxes(self, boxes, nyb_min: int = 0, packed: bool = False) -> PreparedBoxes:
         """Index quadruples (iw, ie, js, jn) -> PreparedBoxes for ``rowstats`` / ``reduce`` / ``compute``.  ``nyb_min``: the row
-        count of the record buffer the boxes will be used with (chunks of a series share the tallest box's)."""
+        count of the record buffer the boxes will be used with (chunks of a series share the tallest box's).  ``packed``: the boxes
+        of a BOX-PACKED series (``pack_boxes``; include/lec_hip.h): stage 1 then addresses every step's box at the origin of its
+        slab, while every table is built from the true grid boxes as always."""
         boxes = [tuple(int(x) for x in b) for b in boxes]
         bt, dev = self._box_tables(boxes, nyb_min)
+        if packed:
+            dev = dict(dev, box_data=self._up(np.array([(0, b[1] - b[0], 0, b[3] - b[2]) for b in boxes], dtype=np.int32), torch.int32))
         return PreparedBoxes(boxes, bt, dev)
+
+    def pack_boxes(self, cube: torch.Tensor, boxes, shift: int = 0, ny: Optional[int] = None, nx: Optional[int] = None) -> torch.Tensor:
+        """[nt, nl, ny_grid, nx_grid] -> the box-packed layout [len(boxes), nl, ny, nx] (default: the tallest / widest box): step t
+        holds box t of ``cube[t + shift]`` (clamped to the cube: the step itself where a time neighbour does not exist) at its
+        origin, zeros outside.  One gather on the device -- for tests, ``bench.py --moving`` and host-prepared tracks; the streamed
+        moving framework writes the same layout straight from the file bytes (``ingest.lec_streamed``, ``lec_ingest``)."""
+        b = np.array([tuple(int(x) for x in q) for q in (boxes.boxes if isinstance(boxes, PreparedBoxes) else boxes)], dtype=np.int64)
+        nt = cube.shape[0]
+        if len(b) != nt:
+            raise ValueError("pack_boxes: one box per time step of the cube")
+        nxb, nyb = b[:, 1] - b[:, 0] + 1, b[:, 3] - b[:, 2] + 1
+        ny, nx = int(ny or nyb.max()), int(nx or nxb.max())
+        dev = cube.device
+        tt = torch.as_tensor(np.clip(np.arange(nt) + shift, 0, nt - 1), device=dev)[:, None, None, None]
+        kk = torch.arange(cube.shape[1], device=dev)[None, :, None, None]
+        jj = torch.arange(ny, device=dev)[None, None, :, None]
+        ii = torch.arange(nx, device=dev)[None, None, None, :]
+        up = lambda a: torch.as_tensor(a, device=dev)[:, None, None, None]
+        inside = (jj < up(nyb)) & (ii < up(nxb))
+        rows = torch.minimum(up(b[:, 2]) + jj, up(b[:, 3]))
+        cols = torch.minimum(up(b[:, 0]) + ii, up(b[:, 1]))
+        return torch.where(inside, cube[tt, kk, rows, cols], torch.zeros((), dtype=cube.dtype, device=dev)).contiguous()
 
     def _resolve_boxes(self, boxes, nyb_min: int = 0):
         if isinstance(boxes, PreparedBoxes):
@@ -199,8 +225,11 @@ class LECEngine:
                  time_s=None, dTdt: Optional[torch.Tensor] = None, t_begin: int = 0,
                  t_count: Optional[int] = None, with_q: bool = True, timing: Optional[list] = None,
                  rows_out: Optional[torch.Tensor] = None, tuning: Optional[dict] = None,
-                 per_step_boxes: Optional[bool] = None, tcoef: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 per_step_boxes: Optional[bool] = None, tcoef: Optional[torch.Tensor] = None,
+                 tm: Optional[torch.Tensor] = None, tp: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Stage 1 (``lec_rowstats``): row records [t_count, nl, nyb_max, 32] of time steps [t_begin, t_begin + t_count).
+        ``tm`` / ``tp``: a BOX-PACKED series (``pack_boxes``; ``boxes`` prepared with ``packed=True``): the cubes hold every step's
+        box at the origin of its slab, ``tm`` / ``tp`` T of the previous / next step on that box.  Same records, bit for bit.
         ``tuning``: see ``make_tuning`` (kernel family / order / tile shape; default = the library's choice).
         ``tcoef``: the d/dt coefficients of the cube's time steps already on the device (fp64 [nt, 3], e.g. rows [h0, h1) of
         ``time_coefs_device`` of the whole series) instead of ``time_s`` -- a chunk loop then uploads nothing per call (an upload from
@@ -208,12 +237,18 @@ class LECEngine:
         if tair.dim() != 4:
             raise ValueError("fields must be [time, level, lat, lon]")
         nt, nl, ny, nx = tair.shape
-        if (nl, ny, nx) != (self.level.size, self.lat.size, self.lon.size):
+        packed = tm is not None or tp is not None
+        if packed:
+            if tm is None or tp is None or dTdt is not None or not with_q or not isinstance(boxes, PreparedBoxes) or "box_data" not in boxes.dev:
+                raise ValueError("a box-packed series: give tm and tp, no dTdt cube, with_q, and boxes from prepare_boxes(..., packed=True)")
+            if nl != self.level.size or ny < boxes.bt.nyb_max or nx < boxes.bt.nxb_max or ny > self.lat.size or nx > self.lon.size:
+                raise ValueError(f"packed cubes {tuple(tair.shape)}: need {self.level.size} levels and slabs that hold the tallest / widest box")
+        elif (nl, ny, nx) != (self.level.size, self.lat.size, self.lon.size):
             raise ValueError(f"field shape {tuple(tair.shape)} does not match the engine grid "
                              f"({self.level.size} levels, {self.lat.size} lats, {self.lon.size} lons)")
         if tair.dtype not in (torch.float64, torch.float32):
             raise ValueError("fields must be float64 or float32")
-        cubes = [tair, u, v, omega] + ([geopt] if geopt is not None else []) + ([dTdt] if dTdt is not None else [])
+        cubes = [tair, u, v, omega] + ([geopt] if geopt is not None else []) + ([dTdt] if dTdt is not None else []) + ([tm, tp] if packed else [])
         for c in cubes:
             if c.shape != tair.shape or c.dtype != tair.dtype or c.device != tair.device or not c.is_contiguous():
                 raise ValueError("all field cubes must share shape, dtype, device and be contiguous")
@@ -256,7 +291,7 @@ class LECEngine:
                 b = min(a + self.MAX_STEPS_PER_LAUNCH, t_count)
                 self.rowstats(tair, u, v, omega, geopt, whole.part(a, b) if per_step_boxes else whole, dTdt=dTdt, t_begin=t_begin + a,
                               t_count=b - a, with_q=with_q, timing=timing, rows_out=rows[a:b], tuning=tuning, per_step_boxes=per_step_boxes,
-                              tcoef=tcoef)
+                              tcoef=tcoef, tm=tm, tp=tp)
             return rows
         if rows_out is None:
             rows = torch.empty((t_count, nl, bt.nyb_max, _lib.LEC_NSTAT), **f64)
@@ -270,9 +305,9 @@ class LECEngine:
             dtype=_lib.LEC_F64 if tair.dtype == torch.float64 else _lib.LEC_F32, with_q=int(bool(with_q)),
             nt=nt, nl=nl, ny=ny, nx=nx, t_begin=t_begin, t_count=t_count,
             n_box=len(boxes), nxb_max=bt.nxb_max, nyb_max=bt.nyb_max, lon_uniform=int(bt.lon_uniform),
-            box_per_step=int(bool(per_step_boxes)), reserved0=0, box_d=_ptr(dev["box"]), boxtab_d=_ptr(dev["boxtab"]), wlon_d=_ptr(dev["wlon"]), glon_d=_ptr(dev["glon"]),
+            box_per_step=int(bool(per_step_boxes)), reserved0=0, box_d=_ptr(dev["box_data"] if packed else dev["box"]), boxtab_d=_ptr(dev["boxtab"]), wlon_d=_ptr(dev["wlon"]), glon_d=_ptr(dev["glon"]),
             lattab_d=_ptr(dev["lattab"]), levtab_d=_ptr(self._levtab), tcoef_d=_ptr(tcoef),
-            rows_d=_ptr(rows), stream=stream, tuning=make_tuning(tuning))
+            rows_d=_ptr(rows), stream=stream, tuning=make_tuning(tuning), tm_d=_ptr(tm), tp_d=_ptr(tp))
         with torch.cuda.device(tair.device):
             if timing is not None:
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
