@@ -57,6 +57,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true", help="same as --cpu-baseline none")
     ap.add_argument("--moving", action="store_true", help="semi-Lagrangian configuration: one 15x15 degree box per time step "
                     "on a track-extent crop of the 0.25 degree grid (BASELINE config 5)")
+    ap.add_argument("--moving-layout", choices=["packed", "cube"], default="packed", help="--moving: how the series lies in HBM when the timed "
+                    "region starts -- 'packed' (default): every time step's box alone, at the origin of its slab, with dT/dt as the series' own "
+                    "data (what the streamed moving framework's ingest writes; include/lec_hip.h 'box-packed series'); 'cube': the whole "
+                    "track-extent crop, boxes as index quadruples into it (rounds 1-4).  Same records, bit for bit")
     ap.add_argument("--tuning", type=str, default="", help="A/B runs: lec_tuning fields, e.g. kernel=row_sweep,tile_t=4 (default: the library's choice)")
     ap.add_argument("--force-dist", action="store_true", help="with one rank: still create the process group and run the collectives "
                     "(the N > 1 code path -- RCCL init, barrier, mask all_reduce, gather -- on a one-GPU box)")
@@ -186,7 +190,7 @@ def cpu_baseline_and_parity(kind, eng, held, lat, lon, level, time_s, device):
         usable = len(os.sched_getaffinity(0))
     except AttributeError:
         usable = ncpu
-    h0, h1, f = held
+    h0, h1, f = held[:3]
     nt = min(3 if kind in ("full", "single") else 2, h1 - h0)
     ny, nx = lat.size, lon.size
     south, north = (lat[1], lat[-2]) if abs(lat[0]) >= 90.0 - 1e-9 else (lat[0], lat[-1])
@@ -331,18 +335,35 @@ def run_rank(args):
     chunk_boxes = {c: boxes_of(*c) for c in chunks}      # host work (nearest-grid-point boxes of a chunk's steps): once, outside the timed region
     all_boxes = [bx for c in chunks for bx in chunk_boxes[c]] if args.moving else [box]
     nyb_max = max(b[3] - b[2] + 1 for b in all_boxes) if args.moving else lat.size
+    packed = bool(args.moving and args.moving_layout == "packed" and with_q)
     if args.moving:        # thousands of boxes: build and upload their tables once (PreparedBoxes), not at every call
-        chunk_boxes = {c: eng.prepare_boxes(bx, nyb_min=nyb_max) for c, bx in chunk_boxes.items()}
-        all_boxes = eng.prepare_boxes(all_boxes, nyb_min=nyb_max)
+        chunk_boxes = {c: eng.prepare_boxes(bx, nyb_min=nyb_max, packed=packed) for c, bx in chunk_boxes.items()}
+        all_boxes = eng.prepare_boxes(all_boxes, nyb_min=nyb_max, packed=packed)
+    tc_all = eng.time_coefs_device(time_s) if with_q else None      # d/dt coefficients of the whole axis on the device: no upload per call
+    check_cube = {}
 
     def generate(a, b):
+        """(first held step, end, fields, the call's dT/dt arguments) of the steps [a, b) as they lie in HBM for the timed passes."""
         h0, h1 = halo_range(a, b, T_global)                  # one-step halo for dT/dt (thermodynamics.py:109-110)
         f = synthetic_cube(h1 - h0, level, lat, lon, device=device, dtype=tdtype, seed=1234, t0_global=h0)
         if args.no_q:
             f["geopt"] = None
-        return h0, h1, f
+        if not packed:
+            return h0, h1, f, ({"tcoef": tc_all[h0:h1]} if with_q else {})
+        # the box-packed series: each step's box gathered out of the track-extent cube (the reference's per-step slice,
+        # box_data.py:297-310 -- done by whoever produces the data: here the generator, in the product lec_ingest), dT/dt over the
+        # series' time axis formed on each step's own box (fp64 storage: as a cube, lec_dtdt; fp32: the two neighbours' T)
+        if rank == 0 and not check_cube:                     # the first steps of the cube stay, for the cross-check after the timed passes
+            n = min(b - a, 8) + 1
+            check_cube.update(h0=h0, f={k: (None if v is None else v[:n + (a - h0)].clone()) for k, v in f.items()})
+        ps = eng.pack_series(f["tair"], f["u"], f["v"], f["omega"], f["geopt"], boxes_of(h0, h1), tc_all[h0:h1])
+        del f
+        cut = lambda x: None if x is None else x[a - h0: b - h0].contiguous()
+        kw = {k: cut(ps[k]) for k in ("dTdt", "tm", "tp") if k in ps}
+        if "tm" in kw:
+            kw["tcoef"] = tc_all[a:b]
+        return a, b, {k: cut(ps[k]) for k in ("tair", "u", "v", "omega", "geopt")}, kw
 
-    tc_all = eng.time_coefs_device(time_s) if with_q else None      # d/dt coefficients of the whole axis on the device: no upload per call
     held = generate(*chunks[0]) if resident else None
     # Everything a pass writes is allocated ONCE, here: the row records, the NaN counters, and (SeriesGatherer) the send / receive
     # buffers of the gather in two pipeline slots.  lec_reduce writes its packed [T_local, 16 + 21 nl] records straight into the
@@ -395,28 +416,28 @@ def run_rank(args):
         out = gat.send(slot)
         mark("gather_finish_previous")
         if resident:
-            h0, h1, f = held
+            h0, h1, f, dkw = held
             timing = [] if record else None
-            eng.rowstats(f["tair"], f["u"], f["v"], f["omega"], f["geopt"], all_boxes, tcoef=tc_all[h0:h1] if with_q else None,
-                         t_begin=t0 - h0, t_count=T_local, timing=timing, rows_out=rows, **stage1)
+            eng.rowstats(f["tair"], f["u"], f["v"], f["omega"], f["geopt"], all_boxes, t_begin=t0 - h0, t_count=T_local, timing=timing,
+                         rows_out=rows, **dkw, **stage1)
             if record:
                 kernel_ms.extend(timing)
             mark("stage1")
         else:
             for (a, b) in chunks:
                 g0 = time.perf_counter()
-                h0, h1, f = generate(a, b)
+                h0, h1, f, dkw = generate(a, b)
                 torch.cuda.synchronize()
                 gen_s[0] += time.perf_counter() - g0
                 timing = [] if record else None
                 tic = time.perf_counter()
-                eng.rowstats(f["tair"], f["u"], f["v"], f["omega"], f["geopt"], chunk_boxes[(a, b)], tcoef=tc_all[h0:h1] if with_q else None,
-                             t_begin=a - h0, t_count=b - a, timing=timing, rows_out=rows[a - t0:b - t0], **stage1)
+                eng.rowstats(f["tair"], f["u"], f["v"], f["omega"], f["geopt"], chunk_boxes[(a, b)], t_begin=a - h0, t_count=b - a, timing=timing,
+                             rows_out=rows[a - t0:b - t0], **dkw, **stage1)
                 torch.cuda.synchronize()
                 timed += time.perf_counter() - tic
                 if record:
                     kernel_ms.extend(timing)
-                del f
+                del f, dkw
             sync()
             tick[0] = time.perf_counter()
         tic = time.perf_counter()
@@ -522,7 +543,7 @@ def run_rank(args):
     # the BASELINE target configuration (conversion terms: T, u, v, omega) on the same resident fields, rank 0
     conv = None
     if rank == 0 and resident and with_q and not args.moving:
-        h0, h1, f = held
+        h0, h1, f = held[:3]
         ev = []
         for i in range(2 + 5):
             tm = [] if i >= 2 else None
@@ -540,10 +561,13 @@ def run_rank(args):
     # resident shard -- record by record and term by term (finite is not a check: wrong coefficients give finite numbers too)
     moving_check = None
     if rank == 0 and resident and args.moving:
-        h0, h1, f = held
+        # (a box-packed series: the check runs on the CUBE the series was packed from -- its first steps were kept --, so it also says
+        # that packing changed no bit: the timed pass read the packed series, `a` reads the cube)
+        h0, h1, f = (check_cube["h0"], None, check_cube["f"]) if packed else held[:3]
         n = min(T_local, 8)
         bx = [all_boxes.boxes[i] for i in range(n)]
-        kw = dict(time_s=time_s[h0:h1] if with_q else None, t_begin=t0 - h0, t_count=n, with_q=with_q, per_step_boxes=True, keep_rows=True)
+        nheld = f["tair"].shape[0]
+        kw = dict(time_s=time_s[h0:h0 + nheld] if with_q else None, t_begin=t0 - h0, t_count=n, with_q=with_q, per_step_boxes=True, keep_rows=True)
         a = eng.compute(f["tair"], f["u"], f["v"], f["omega"], f["geopt"], bx, **kw)
         b = eng.compute(f["tair"], f["u"], f["v"], f["omega"], f["geopt"], bx, tuning={"kernel": "row_sweep"}, **kw)
         torch.cuda.synchronize()
@@ -552,7 +576,8 @@ def run_rank(args):
         sc = float(((a.scalars - b.scalars).abs().amax(dim=0) / b.scalars.abs().amax(dim=0).clamp_min(1e-300)).max())
         same = bool(torch.equal(a.scalars, res.scalars[:n]))       # and the timed pass produced exactly these numbers
         moving_check = {"steps": n, "row_records_max_rel_diff_vs_row_sweep": rec, "terms_max_rel_diff_vs_row_sweep": sc,
-                        "timed_pass_bit_identical": same, "ok": bool(rec <= 1e-10 and sc <= 1e-9 and same)}
+                        "timed_pass_bit_identical": same, "ok": bool(rec <= 1e-10 and sc <= 1e-9 and same),
+                        "checked_on": ("the track-extent cube the packed series was gathered from" if packed else "the resident cube")}
 
     if rank == 0:
         finite = bool(torch.isfinite(res.scalars).all().item())
@@ -572,7 +597,7 @@ def run_rank(args):
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if os.path.exists(pmc) and (args.ny, args.nx) == (721, 1440):
             try:
-                key = ("rowstats_moving_hbm_bytes_per_timestep" if args.moving else
+                key = (("rowstats_moving_packed_hbm_bytes_per_timestep" if packed else "rowstats_moving_hbm_bytes_per_timestep") if args.moving else
                        f"rowstats_{args.storage}_{'noq' if args.no_q else 'all'}_hbm_bytes_per_timestep")
                 summ = json.load(open(pmc))
                 per_t = summ.get(key)
@@ -590,7 +615,10 @@ def run_rank(args):
         terms = "Az Ae Kz Ke Cz Ca Ck Ce BAz BAe BKz BKe (T,u,v,omega only)" if args.no_q else "all 16 (incl. BPhi, Gz, Ge)"
         if args.moving:
             workload = (f"synthetic 0.25-degree {nl} lev x {lat.size} x {lon.size} track-extent crop, moving 15x15-degree box "
-                        f"(61 x 61 points) per time step, storage {args.storage}, terms = {terms}")
+                        f"(61 x 61 points) per time step, storage {args.storage}, terms = {terms}"
+                        + ("; the series lies in HBM BOX-PACKED (every step's box gathered out of the crop before the timed region, as the streamed "
+                           "moving framework's ingest writes it: 5 field slabs + " + ("dT/dt as an fp64 cube" if args.storage == "f64" else "T of the two time neighbours")
+                           + " per step; --moving-layout cube = the whole crop, rounds 1-4)" if packed else "; the series lies in HBM as the whole crop"))
         else:
             workload = (f"synthetic ERA5-res {nl} lev x {args.ny} x {args.nx}" + (" on STRETCHED longitudes" if args.nonuniform_lon else "") +
                         f", fixed box = whole grid, storage {args.storage}, terms = {terms}")
@@ -621,7 +649,7 @@ def run_rank(args):
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {
-                "workload": workload, "baseline_config": bcfg,
+                "workload": workload, "baseline_config": bcfg, **({"moving_layout": "packed" if packed else "cube"} if args.moving else {}),
                 "timesteps_per_gpu": T_local, "timesteps_global": T_global, "world_size": world,
                 "backend": (dist.get_backend() if use_dist else "none"),
                 "parallelism": f"time-sharded x{world}, no data-path collective; RCCL all_reduce of the NaN-level mask (fixed box) + one gather of the "

@@ -48,7 +48,7 @@ extern "C" {
  * lec_chunk_scatter_args.src_bytes (the destination / payload ranges of every descriptor are bounds-checked on the device). */
 #define LEC_ABI_VERSION 9
 /* ABI 9 (round 5): lec_format_csv_rows (host): a per-level table as the text pandas writes for it, one call per table;
- * lec_rowstats_args.tm_d / tp_d: box-packed series of the moving framework (the struct grew by two pointers at its end). */
+ * lec_rowstats_args.tm_d / tp_d: box-packed series of the moving framework (the struct grew by two pointers at its end); lec_dtdt. */
 
 /* number of fp64 values per (time, level, lat) row record written by lec_rowstats */
 #define LEC_NSTAT 32
@@ -379,6 +379,26 @@ typedef struct lec_chunk_scatter_args {
 int lec_inflate(const lec_inflate_args* args);
 const char* lec_inflate_status_text(int code);
 int lec_chunk_scatter(const lec_chunk_scatter_args* args);
+
+/*
+ * dT/dt of a box-packed series as a cube of its own: out[s][e] = tc[s][0] tm[s][e] + tc[s][1] t[s][e] + tc[s][2] tp[s][e] in fp64, evaluated
+ * exactly as lec_rowstats evaluates it per point from tm_d / tp_d (the two outer products rounded, then one fused multiply-add), so a
+ * series handed over as T, u, v, omega, Phi + this cube (dTdt_d) gives the records of the same series handed over with tm_d / tp_d,
+ * bit for bit -- with one streamed operand fewer per point (fp64 storage: 48 instead of 56 bytes; the producer reads its three T
+ * slices once).  Replaces, for a moving box, the np.gradient over time of run_lec_analysis (lorenzcycletoolkit.py:184-186) restricted
+ * to each step's box.  `dtype` is the cubes' (LEC_F64 / LEC_F32); the output is fp64 (as a dTdt_d of lec_rowstats it serves fp64 storage).
+ */
+typedef struct lec_dtdt_args {
+    const void* tm_d;          /* [n_steps][step_elems] T of the previous time step on the step's box */
+    const void* t_d;           /* T */
+    const void* tp_d;          /* T of the next time step */
+    int32_t dtype, n_steps;
+    int64_t step_elems;        /* elements per time step (nl * ny * nx of the packed slabs) */
+    const double* tcoef_d;     /* [n_steps][3] np.gradient coefficients of the steps these cubes hold */
+    double* out_d;             /* [n_steps][step_elems] fp64 */
+    void* stream;
+} lec_dtdt_args;
+int lec_dtdt(const lec_dtdt_args* args);
 
 /*
  * The text of a per-level table (HOST memory in, host memory out; no device work).  Replaces the per-cell formatting inside

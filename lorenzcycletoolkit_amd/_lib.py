@@ -42,7 +42,7 @@ def source_digest() -> str:
 
 EXPORTS = ["lec_version", "lec_last_error", "lec_max_row", "lec_rowstats", "lec_reduce", "lec_dropmask", "lec_ingest", "lec_track_diag",
            "lec_check_boxes", "lec_check_maps", "lec_host_register", "lec_host_unregister", "lec_copy_rows_async",
-           "lec_inflate", "lec_inflate_status_text", "lec_chunk_scatter", "lec_format_csv_rows"]
+           "lec_inflate", "lec_inflate_status_text", "lec_chunk_scatter", "lec_format_csv_rows", "lec_dtdt"]
 
 
 class Tuning(C.Structure):
@@ -109,6 +109,12 @@ class DiagArgs(C.Structure):
                 ("nt", C.c_int32), ("ny", C.c_int32), ("nx", C.c_int32), ("reserved0", C.c_int32),
                 ("box_d", C.c_void_p), ("xcoef_d", C.c_void_p), ("ycoef_d", C.c_void_p), ("curv_d", C.c_void_p),
                 ("val_d", C.c_void_p), ("pos_d", C.c_void_p), ("stream", C.c_void_p)]
+
+
+class DtdtArgs(C.Structure):
+    """struct lec_dtdt_args (include/lec_hip.h)."""
+    _fields_ = [("tm_d", C.c_void_p), ("t_d", C.c_void_p), ("tp_d", C.c_void_p), ("dtype", C.c_int32), ("n_steps", C.c_int32),
+                ("step_elems", C.c_int64), ("tcoef_d", C.c_void_p), ("out_d", C.c_void_p), ("stream", C.c_void_p)]
 
 
 class InflateArgs(C.Structure):
@@ -178,6 +184,8 @@ def load():
     lib.lec_inflate_status_text.argtypes = [C.c_int]
     lib.lec_chunk_scatter.restype = C.c_int
     lib.lec_chunk_scatter.argtypes = [C.POINTER(ChunkScatterArgs)]
+    lib.lec_dtdt.restype = C.c_int
+    lib.lec_dtdt.argtypes = [C.POINTER(DtdtArgs)]
     lib.lec_format_csv_rows.restype = C.c_longlong
     lib.lec_format_csv_rows.argtypes = [C.c_void_p, C.c_longlong, C.c_longlong, C.c_longlong, C.c_char_p, C.c_int, C.c_void_p, C.c_longlong]
     if lib.lec_version() != LEC_ABI_VERSION:

@@ -646,6 +646,36 @@ int launch_tiles(RowParams p, bool uniform, int mode, int tg, hipStream_t st) {
 
 }  // namespace
 
+// ---- dT/dt of a box-packed series as a cube (include/lec_hip.h: lec_dtdt): the kernel above's own per-point expression
+namespace {
+template <typename TIN>
+__global__ void __launch_bounds__(256) lec_dtdt_kernel(const TIN* __restrict__ tm, const TIN* __restrict__ t, const TIN* __restrict__ tp,
+                                                       const double* __restrict__ tcoef, double* __restrict__ out, long long step_elems) {
+    const int s = blockIdx.y;
+    const double ta = tcoef[3 * s], tb = tcoef[3 * s + 1], tc = tcoef[3 * s + 2];
+    const size_t base = (size_t)s * (size_t)step_elems;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < step_elems; e += (long long)gridDim.x * 256)
+        out[base + e] = stencil3(ta, (double)tm[base + e], tc, (double)tp[base + e], tb, (double)t[base + e]);
+}
+}  // namespace
+
+extern "C" int lec_dtdt(const lec_dtdt_args* a) {
+    if (!a) return lec_set_error(LEC_ERR_ARG, "lec_dtdt: null args");
+    if (!a->tm_d || !a->t_d || !a->tp_d || !a->tcoef_d || !a->out_d) return lec_set_error(LEC_ERR_ARG, "lec_dtdt: null pointer argument");
+    if (a->dtype != LEC_F64 && a->dtype != LEC_F32) return lec_set_error(LEC_ERR_ARG, "lec_dtdt: dtype must be LEC_F64 or LEC_F32");
+    if (a->n_steps < 1 || a->n_steps > 65535 || a->step_elems < 1) return lec_set_error(LEC_ERR_ARG, "lec_dtdt: needs 1 <= n_steps <= 65535 and step_elems >= 1");
+    const long long want = (a->step_elems + 255) / 256;
+    dim3 grid((unsigned)(want < 64 ? want : 64), (unsigned)a->n_steps), block(256);
+    hipStream_t st = (hipStream_t)a->stream;
+    if (a->dtype == LEC_F64)
+        hipLaunchKernelGGL(lec_dtdt_kernel<double>, grid, block, 0, st, (const double*)a->tm_d, (const double*)a->t_d, (const double*)a->tp_d, a->tcoef_d, a->out_d, (long long)a->step_elems);
+    else
+        hipLaunchKernelGGL(lec_dtdt_kernel<float>, grid, block, 0, st, (const float*)a->tm_d, (const float*)a->t_d, (const float*)a->tp_d, a->tcoef_d, a->out_d, (long long)a->step_elems);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return lec_set_error(LEC_ERR_LAUNCH, hipGetErrorString(e));
+    return LEC_OK;
+}
+
 // mode: 0 no Q, 1 dT/dt from the cube's time neighbours per point, 2 dT/dt cube; p.tgroup: time steps per tile group, p.jgroup: levels
 // per wave (< 1: chosen here; more than 21: LEC_ERR_ARG); tg: time steps per workgroup (0 = default, 1, 2 or 4; mode 1 with rows of one
 // column chunk only -- other calls run one wave per workgroup)

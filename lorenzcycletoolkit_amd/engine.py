@@ -158,6 +158,38 @@ class LECEngine:
         cols = torch.minimum(up(b[:, 0]) + ii, up(b[:, 1]))
         return torch.where(inside, cube[tt, kk, rows, cols], torch.zeros((), dtype=cube.dtype, device=dev)).contiguous()
 
+    def time_stencil(self, tm: torch.Tensor, t: torch.Tensor, tp: torch.Tensor, tcoef: torch.Tensor) -> torch.Tensor:
+        """dT/dt of a box-packed series as an fp64 cube (``lec_dtdt``): tcoef[s] . (tm[s], t[s], tp[s]) with the bits of stage 1's own
+        per-point evaluation.  ``tcoef``: fp64 [steps, 3] on the device, the rows of the steps the cubes hold."""
+        if tm.shape != t.shape or tp.shape != t.shape or tm.dtype != t.dtype or tp.dtype != t.dtype or not (tm.is_contiguous() and t.is_contiguous() and tp.is_contiguous()):
+            raise ValueError("time_stencil: three contiguous cubes of one shape and dtype")
+        n = int(t.shape[0])
+        if tcoef.shape != (n, 3) or tcoef.dtype != torch.float64 or not tcoef.is_contiguous() or tcoef.device != t.device:
+            raise ValueError("time_stencil: tcoef must be a contiguous fp64 [steps, 3] tensor on the cubes' device")
+        out = torch.empty(t.shape, dtype=torch.float64, device=t.device)
+        for a in range(0, n, 65535):
+            b = min(n, a + 65535)
+            args = _lib.DtdtArgs(tm_d=_ptr(tm[a:b]), t_d=_ptr(t[a:b]), tp_d=_ptr(tp[a:b]), dtype=_lib.LEC_F64 if t.dtype == torch.float64 else _lib.LEC_F32,
+                                 n_steps=b - a, step_elems=int(t[0].numel()), tcoef_d=_ptr(tcoef[a:b]), out_d=_ptr(out[a:b]),
+                                 stream=C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream))
+            with torch.cuda.device(t.device):
+                _lib.check(self.lib.lec_dtdt(C.byref(args)), "lec_dtdt")
+        return out
+
+    def pack_series(self, tair, u, v, omega, geopt, boxes, tcoef: torch.Tensor, ny: Optional[int] = None, nx: Optional[int] = None) -> dict:
+        """The box-packed form of a moving series held as whole cubes (tests, ``bench.py --moving``, host-prepared tracks): the keyword
+        arguments of ``rowstats`` -- the five fields packed per step (``pack_boxes``) and dT/dt as the series' own data: an fp64 cube
+        for fp64 storage (``time_stencil``: one operand fewer per point), T of the two time neighbours on the step's box for fp32
+        storage (the same bytes as a cube would be, and no rounding of dT/dt to the storage dtype).  ``tcoef``: rows of the cubes' steps."""
+        pk = {k: self.pack_boxes(c, boxes, ny=ny, nx=nx) for k, c in (("tair", tair), ("u", u), ("v", v), ("omega", omega), ("geopt", geopt)) if c is not None}
+        tm, tp = self.pack_boxes(tair, boxes, shift=-1, ny=ny, nx=nx), self.pack_boxes(tair, boxes, shift=+1, ny=ny, nx=nx)
+        if tair.dtype == torch.float64:
+            pk["dTdt"] = self.time_stencil(tm, pk["tair"], tp, tcoef)
+        else:
+            pk["tm"], pk["tp"] = tm, tp
+        pk.setdefault("geopt", None)
+        return pk
+
     def _resolve_boxes(self, boxes, nyb_min: int = 0):
         if isinstance(boxes, PreparedBoxes):
             if boxes.bt.nyb_max < nyb_min:
@@ -237,10 +269,10 @@ class LECEngine:
         if tair.dim() != 4:
             raise ValueError("fields must be [time, level, lat, lon]")
         nt, nl, ny, nx = tair.shape
-        packed = tm is not None or tp is not None
+        packed = tm is not None or tp is not None or (isinstance(boxes, PreparedBoxes) and "box_data" in boxes.dev)
         if packed:
-            if tm is None or tp is None or dTdt is not None or not with_q or not isinstance(boxes, PreparedBoxes) or "box_data" not in boxes.dev:
-                raise ValueError("a box-packed series: give tm and tp, no dTdt cube, with_q, and boxes from prepare_boxes(..., packed=True)")
+            if not isinstance(boxes, PreparedBoxes) or "box_data" not in boxes.dev or (with_q and (dTdt is None) == (tm is None or tp is None)):
+                raise ValueError("a box-packed series: boxes from prepare_boxes(..., packed=True) and, with_q, either tm and tp or a dTdt cube")
             if nl != self.level.size or ny < boxes.bt.nyb_max or nx < boxes.bt.nxb_max or ny > self.lat.size or nx > self.lon.size:
                 raise ValueError(f"packed cubes {tuple(tair.shape)}: need {self.level.size} levels and slabs that hold the tallest / widest box")
         elif (nl, ny, nx) != (self.level.size, self.lat.size, self.lon.size):
@@ -248,7 +280,7 @@ class LECEngine:
                              f"({self.level.size} levels, {self.lat.size} lats, {self.lon.size} lons)")
         if tair.dtype not in (torch.float64, torch.float32):
             raise ValueError("fields must be float64 or float32")
-        cubes = [tair, u, v, omega] + ([geopt] if geopt is not None else []) + ([dTdt] if dTdt is not None else []) + ([tm, tp] if packed else [])
+        cubes = [tair, u, v, omega] + ([geopt] if geopt is not None else []) + ([dTdt] if dTdt is not None else []) + ([tm, tp] if tm is not None else [])
         for c in cubes:
             if c.shape != tair.shape or c.dtype != tair.dtype or c.device != tair.device or not c.is_contiguous():
                 raise ValueError("all field cubes must share shape, dtype, device and be contiguous")

@@ -35,7 +35,14 @@ def _both(dom, boxes, ny=None, nx=None, t_range=None):
     pk = [eng.pack_boxes(c, boxes, ny=ny, nx=nx) for c in f]
     tm, tp = eng.pack_boxes(f[0], boxes, shift=-1, ny=ny, nx=nx), eng.pack_boxes(f[0], boxes, shift=+1, ny=ny, nx=nx)
     b = eng.rowstats(*pk, packed_boxes.part(t0, t1), tcoef=tc, t_begin=t0, t_count=t1 - t0, per_step_boxes=True, tm=tm, tp=tp)
+    # ... and as pack_series hands it over: fp64 storage with dT/dt as a cube of its own (lec_dtdt), fp32 with the two neighbours
+    ps = eng.pack_series(*f, boxes, tc, ny=ny, nx=nx)
+    assert ("dTdt" in ps) == (dom.tair.dtype == np.float64) and ("tm" in ps) == (dom.tair.dtype == np.float32)
+    extra = {k: ps[k] for k in ("dTdt", "tm", "tp") if k in ps}
+    c = eng.rowstats(ps["tair"], ps["u"], ps["v"], ps["omega"], ps["geopt"], packed_boxes.part(t0, t1), t_begin=t0, t_count=t1 - t0, per_step_boxes=True,
+                     **({"tcoef": tc} if "tm" in ps else {}), **extra)
     torch.cuda.synchronize()
+    assert torch.equal(c, b), "pack_series (dT/dt cube / neighbours) against the explicit neighbours"
     return eng, a, b, (pk, tm, tp, packed_boxes, tc)
 
 

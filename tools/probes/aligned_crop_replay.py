@@ -58,7 +58,7 @@ def track_boxes(eng):
     return [eng.box_from_limits(lo - 7.5, lo + 7.5, la - 7.5, la + 7.5) for la, lo in zip(clat, clon)]
 
 
-def run_packed(label, nyp, nxp):
+def run_packed(label, nyp, nxp, dtdt_cube=False):
     """The real thing: the bench's cube and track, packed per step (T, u, v, omega, Phi + T(t-1), T(t+1) on the step's box)."""
     lat = -57.75 + 0.25 * np.arange(162)
     lon = -80.25 + 0.25 * np.arange(243)
@@ -78,7 +78,10 @@ def run_packed(label, nyp, nxp):
     ms = []
     for i in range(8):
         tmg = [] if i >= 3 else None
-        eng.rowstats(*pk, pb, tcoef=tc, t_begin=0, t_count=T, timing=tmg, rows_out=rows, per_step_boxes=True, tm=tm, tp=tp)
+        if dtdt_cube:      # (timing only: the cube's VALUES are not the stencil's bits here)
+            eng.rowstats(*pk, pb, dTdt=tm, t_begin=0, t_count=T, timing=tmg, rows_out=rows, per_step_boxes=True)
+        else:
+            eng.rowstats(*pk, pb, tcoef=tc, t_begin=0, t_count=T, timing=tmg, rows_out=rows, per_step_boxes=True, tm=tm, tp=tp)
         torch.cuda.synchronize()
         if tmg:
             ms.append(sum(a.elapsed_time(b) for a, b in tmg))
@@ -95,5 +98,8 @@ a2 = run("aligned crop 61 x 64, dT/dt cube", 61, 64, origin, mode2=True)
 p61 = run("dense crop 61 x 61 (unaligned rows)", 61, 61, origin)
 k61 = run_packed("PACKED series, slabs 61 x 61 (7 cubes)", 61, 61)
 k64 = run_packed("PACKED series, slabs 61 x 64 (7 cubes)", 61, 64)
+d61 = run_packed("PACKED + dT/dt cube, 61 x 61 (6 cubes)", 61, 61, dtdt_cube=True)
+d64 = run_packed("PACKED + dT/dt cube, 61 x 64 (6 cubes)", 61, 64, dtdt_cube=True)
+print(f"packed with a dT/dt cube / today: {base / d61:.3f} x (61 x 61), {base / d64:.3f} x (61 x 64)")
 print(f"packed / today: {base / k61:.3f} x (61 x 61), {base / k64:.3f} x (61 x 64)")
 print(f"aligned / today: {base / a1:.3f} x (MODE 1), {base / a2:.3f} x (MODE 2); dense 61 x 61: {base / p61:.3f} x")
