@@ -158,7 +158,7 @@ class LECEngine:
         cols = torch.minimum(up(b[:, 0]) + ii, up(b[:, 1]))
         return torch.where(inside, cube[tt, kk, rows, cols], torch.zeros((), dtype=cube.dtype, device=dev)).contiguous()
 
-    def time_stencil(self, tm: torch.Tensor, t: torch.Tensor, tp: torch.Tensor, tcoef: torch.Tensor) -> torch.Tensor:
+    def time_stencil(self, tm: torch.Tensor, t: torch.Tensor, tp: torch.Tensor, tcoef: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """dT/dt of a box-packed series as an fp64 cube (``lec_dtdt``): tcoef[s] . (tm[s], t[s], tp[s]) with the bits of stage 1's own
         per-point evaluation.  ``tcoef``: fp64 [steps, 3] on the device, the rows of the steps the cubes hold."""
         if tm.shape != t.shape or tp.shape != t.shape or tm.dtype != t.dtype or tp.dtype != t.dtype or not (tm.is_contiguous() and t.is_contiguous() and tp.is_contiguous()):
@@ -166,7 +166,10 @@ class LECEngine:
         n = int(t.shape[0])
         if tcoef.shape != (n, 3) or tcoef.dtype != torch.float64 or not tcoef.is_contiguous() or tcoef.device != t.device:
             raise ValueError("time_stencil: tcoef must be a contiguous fp64 [steps, 3] tensor on the cubes' device")
-        out = torch.empty(t.shape, dtype=torch.float64, device=t.device)
+        if out is None:
+            out = torch.empty(t.shape, dtype=torch.float64, device=t.device)
+        elif out.shape != t.shape or out.dtype != torch.float64 or not out.is_contiguous() or out.device != t.device:
+            raise ValueError("time_stencil: out must be a contiguous fp64 tensor of the cubes' shape")
         for a in range(0, n, 65535):
             b = min(n, a + 65535)
             args = _lib.DtdtArgs(tm_d=_ptr(tm[a:b]), t_d=_ptr(t[a:b]), tp_d=_ptr(tp[a:b]), dtype=_lib.LEC_F64 if t.dtype == torch.float64 else _lib.LEC_F32,

@@ -643,7 +643,7 @@ def device_cube(var: ds.RawVariable, plan: IngestPlan, device="cuda:0", unit: fl
 def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_limits, *, per_step_boxes: bool = False,
                  device="cuda:0", chunk_steps: Optional[int] = None, with_q: bool = True, stats: Optional[dict] = None,
                  t_range=None, merge_dropmask=None, out=None, staging: str = "auto", inflate: str = "auto",
-                 slots: Optional[int] = None, keep_level: Optional[float] = None) -> LECResult:
+                 slots: Optional[int] = None, keep_level: Optional[float] = None, packed: Optional[bool] = None) -> LECResult:
     """All LEC terms for the whole series, streamed from the memory-mapped file.
 
     ``boxes_limits``: one (west, east, south, north) in degrees (fixed framework, as inputs/box_limits) or one per time step
@@ -657,6 +657,10 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
     "host" (the reader's thread pool), "auto" = device wherever the variable allows it (``_make_stager``).
     ``keep_level`` (Pa): the decoded u, v and geopotential slices of that level are kept on the device for the processed steps (the
     moving framework's 850-hPa diagnostics: no second pass over the file) -- ``stats["level_slices"]`` = {"u", "v", "geopt"} [steps, lat, lon].
+    ``packed`` (default: the moving framework with Q): ``lec_ingest`` gathers, per time step, only that step's BOX out of the raw
+    sub-cube (and T of the two neighbouring steps on it) -- the reference's per-step slice (box_data.py:297-310) done where the data
+    are decoded anyway: a tenth of the decoded bytes of a track-extent crop, and stage 1 reads a dense block per step and level
+    instead of row fragments (include/lec_hip.h "box-packed series"; the same records bit for bit).
     ``t_range`` = (t0, t1): a rank's share of a time-sharded run -- only those steps (and their one-step T halo) are staged, copied
     and computed, so N ranks move 1/N of the bytes each, over N host links; ``merge_dropmask`` / ``out``: see ``LECEngine.reduce``.
     """
@@ -765,14 +769,29 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
     # ... and they hold a SUB-CHUNK of `dec_steps` steps (about 1 GiB per field): a chunk's raw sub-cubes are decoded and row-passed
     # piece by piece (the raw side keeps its large chunks -- the device inflate wants ~13000 streams per batch --, the decoded side
     # does not need them: 8 steps of a 37 x 721 x 1440 grid are 213,000 rows per launch).  Same kernels on the same rows: same bits.
-    dec_steps = min(chunk_steps, max(4, (1 << 30) // (nl * ny * nx * (8 if common == np.float64 else 4))))
-    cubes = {keys[r]: torch.empty((dec_steps + 2, nl, ny, nx), dtype=out_dtype, device=dev) for r in roles}
-    up = lambda a: torch.as_tensor(a, dtype=torch.int32).to(dev)
-    maps = (up(np.searchsorted(file_levels, plan.kmap)), up(plan.jmap - j0), up(plan.imap))   # maps into the staged sub-cube
-    own_boxes = boxes[t0:t1] if per_step_boxes else boxes
     bt, _ = engine._box_tables(boxes)            # the row count of the records is the tallest box of the WHOLE series, on every rank
+    if packed is None:
+        packed = bool(per_step_boxes and with_q)
+    if packed and not (per_step_boxes and with_q):
+        raise ValueError("packed: the moving framework (per_step_boxes) with Q")
+    esize = 8 if common == np.float64 else 4
+    up = lambda a: torch.as_tensor(a, dtype=torch.int32).to(dev)
+    kmap_rel, jmap_rel, imap_rel = np.searchsorted(file_levels, plan.kmap), plan.jmap - j0, plan.imap   # maps into the staged sub-cube
+    if packed:
+        # slabs of the tallest x widest box per step; the maps are lengthened by a slab (their last entry repeated) so that a box
+        # that ends at the domain's edge can be gathered with the slab's extents -- what lies beside a box is never read by stage 1
+        nyp, nxp = bt.nyb_max, bt.nxb_max
+        dec_steps = min(chunk_steps, max(4, (1 << 30) // (nl * nyp * nxp * esize)))
+        cubes = {k: torch.empty((dec_steps, nl, nyp, nxp), dtype=out_dtype, device=dev) for k in list(keys.values()) + ["tm", "tp"]}
+        dtdt = torch.empty((dec_steps, nl, nyp, nxp), dtype=torch.float64, device=dev) if common == np.float64 else None
+        maps = (up(kmap_rel), up(np.concatenate([jmap_rel, np.repeat(jmap_rel[-1:], nyp)])), up(np.concatenate([imap_rel, np.repeat(imap_rel[-1:], nxp)])))
+    else:
+        dec_steps = min(chunk_steps, max(4, (1 << 30) // (nl * ny * nx * esize)))
+        cubes = {keys[r]: torch.empty((dec_steps + 2, nl, ny, nx), dtype=out_dtype, device=dev) for r in roles}
+        maps = (up(kmap_rel), up(jmap_rel), up(imap_rel))
+    own_boxes = boxes[t0:t1] if per_step_boxes else boxes
     if per_step_boxes:
-        own_boxes = engine.prepare_boxes(own_boxes, nyb_min=bt.nyb_max)
+        own_boxes = engine.prepare_boxes(own_boxes, nyb_min=bt.nyb_max, packed=packed)
     else:
         fixed_box = engine.prepare_boxes(boxes, nyb_min=bt.nyb_max)
     # Row records live for one chunk only (6.8 MB per 37 x 721 time step: a month of hourly steps would be 5 GB, 30 k steps all of
@@ -843,7 +862,7 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
                 copied[slot][n].record(up)
             compute.wait_event(copied[slot][n])
         # decode + row pass, sub-chunk by sub-chunk: T with the one-step halo of the SUB-chunk (rows of the raw slot count from h0)
-        for s0 in range(c0, c1, dec_steps):
+        for s0 in (() if packed else range(c0, c1, dec_steps)):
             s1 = min(s0 + dec_steps, c1)
             g0, g1 = (max(s0 - 1, 0), min(s1 + 1, nt)) if with_q else (s0, s1)
             with torch.cuda.device(dev):
@@ -861,6 +880,39 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
                             tcoef=tcoef_all[g0:g1] if with_q else None, t_begin=s0 - g0, t_count=s1 - s0, with_q=with_q,
                             rows_out=rows[: s1 - s0], per_step_boxes=per_step_boxes)
             engine.level_stage(rows[: s1 - s0], part, levraw[s0 - t0: s1 - t0], phi_scale=phi_scale)
+        for s0 in (range(c0, c1, dec_steps) if packed else ()):
+            # the box-packed series: per step, one gather per field of that step's box alone (the maps entered at the box's south-west
+            # corner), T also from the two neighbouring steps (the step itself where the series ends: its coefficient is 0)
+            s1 = min(s0 + dec_steps, c1)
+            geom = (nl_in, ny_in, nx_in, nl, nyp, nxp)
+            with torch.cuda.device(dev):
+                for st in range(s0, s1):
+                    iw, _ie, js, _jn = boxes[st]
+                    mp = (maps[0], maps[1][js:], maps[2][iw:])
+                    for r in roles:
+                        unit = 1.0 if r == geo_role else ds.field_scale(variable_list_df, r)
+                        srcs = [(keys[r], st)] + ([("tm", max(st - 1, 0)), ("tp", min(st + 1, nt - 1))] if r == "Air Temperature" else [])
+                        for key, ft in srcs:
+                            _ingest_call(lib, rvars[r], stagers[r].raw_dev[slot][ft - h0].data_ptr(), 1, geom, mp, unit, decode[r], common,
+                                         cubes[key][st - s0].data_ptr(), compute)
+                if keep is not None:            # the diagnostics' level of u, v, Phi over the whole crop: one gather of that level per field
+                    kmap1 = maps[0][k_keep: k_keep + 1]
+                    for r, k in (("Eastward Wind Component", "u"), ("Northward Wind Component", "v"), (geo_role, "geopt")):
+                        unit = 1.0 if r == geo_role else ds.field_scale(variable_list_df, r)
+                        for st in range(s0, s1):
+                            _ingest_call(lib, rvars[r], stagers[r].raw_dev[slot][st - h0].data_ptr(), 1, (nl_in, ny_in, nx_in, 1, ny, nx),
+                                         (kmap1, maps[1], maps[2]), unit, decode[r], common, keep[k][st - t0].data_ptr(), compute)
+            n = s1 - s0
+            f = {k: t[:n] for k, t in cubes.items()}
+            part = own_boxes.part(s0 - t0, s1 - t0)
+            if dtdt is not None:
+                engine.time_stencil(f["tm"], f["tair"], f["tp"], tcoef_all[s0:s1], out=dtdt[:n])
+                tkw = dict(dTdt=dtdt[:n])
+            else:
+                tkw = dict(tm=f["tm"], tp=f["tp"], tcoef=tcoef_all[s0:s1])
+            engine.rowstats(f["tair"], f["u"], f["v"], f["omega"], f["geopt"], part, t_begin=0, t_count=n, with_q=True,
+                            rows_out=rows[:n], per_step_boxes=True, **tkw)
+            engine.level_stage(rows[:n], part, levraw[s0 - t0: s1 - t0], phi_scale=phi_scale)
         consumed[slot].record(compute)
         used[slot] = True
     t_loop = time.perf_counter()                # (every chunk enqueued)

@@ -252,6 +252,45 @@ def test_moving_framework_streamed_equals_resident(workdir, golden_dir):
     assert torch.isfinite(a.scalars).all()
 
 
+@pytest.mark.parametrize("fill,storage", [(False, "float64"), (True, "float32")])
+def test_moving_framework_packs_each_steps_box(workdir, fill, storage):
+    """The streamed moving framework hands stage 1 a BOX-PACKED series (lec_ingest gathers each step's box alone; include/lec_hip.h):
+    fp64 storage with dT/dt as a cube of its own (lec_dtdt), fp32 storage with T of the two neighbouring steps.  Boxes of several
+    sizes, one at the domain's southern edge, a file that needs the longitude wrap and every sort: the same bits as the same path
+    with whole-crop cubes (packed=False) and as the host-prepared resident path; the 850-hPa slices kept for the diagnostics too."""
+    path = str(workdir / "packed.nc")
+    _write_packed(path, nt=7, fill=fill)                 # int16 + scale + offset: float64 in the reference's xarray without a fill value
+    (workdir / "inputs" / "namelist").write_text(
+        ";Variable;Units\nAir Temperature;t;K\nGeopotential;z;m**2/s**2\nOmega Velocity;w;Pa/s\n"
+        "Eastward Wind Component;u;m/s\nNorthward Wind Component;v;m/s\nLongitude;longitude\nLatitude;latitude\n"
+        "Time;time\nVertical Level;level\n")
+    (workdir / "inputs" / "track").write_text(
+        "time;Lat;Lon;length;width\n" + "".join(f"2020-01-0{1 + t // 4}-{6 * (t % 4):02d}00;{la};{lo};{ln};{wd}\n" for t, (la, lo, ln, wd) in enumerate(
+            [(-30, -20, 30, 40), (-27.5, -15, 30, 40), (-25, -10, 25, 45), (-40, 0, 40, 30), (-20, 5, 30, 40), (-20, 10, 20, 40), (-17.5, 15, 30, 50)])))
+    args = argparse.Namespace(fixed=False, track=True, trackfile="inputs/track", residuals=True, infile=path, cdsapi=False)
+    df = ds.read_namelist("inputs/namelist")
+    host = ds.prepare_data(args, "inputs/namelist")
+    track = ds.read_track("inputs/track")
+    limits = [(lo - w / 2, lo + w / 2, la - ln / 2, la + ln / 2) for la, lo, ln, w in zip(track["Lat"], track["Lon"], track["length"], track["width"])]
+    a = BoxData(host, df, args=args, boxes_limits=limits).result
+    for chunk in (2, 7):
+        got = {}
+        for packed in (True, False):
+            st = ingest.prepare_streamed(args, "inputs/namelist")
+            stats = {}
+            got[packed] = (ingest.lec_streamed(st.raw, st.plan, df, limits, per_step_boxes=True, chunk_steps=chunk, packed=packed, stats=stats,
+                                               keep_level=85000.0), stats)
+            torch.cuda.synchronize()
+            st.raw.close()
+            assert stats["storage"] == storage
+        (p, ps), (c, cs) = got[True], got[False]
+        for r in (p, c):
+            assert torch.equal(a.scalars, r.scalars) and np.array_equal(a.levels.cpu().numpy(), r.levels.cpu().numpy(), equal_nan=True), (chunk, storage)
+        for k in ("u", "v", "geopt"):
+            assert torch.equal(ps["level_slices"][k], cs["level_slices"][k]), k
+    assert torch.isfinite(a.scalars[:, :4]).all()
+
+
 def test_mixed_dtype_file_on_both_paths(workdir):
     """A file that mixes dtypes -- float32 T, u, v, w with an int16-packed geopotential that has an add_offset but no fill value
     (float64 in the reference's decode) -- used to fail in the resident path ('all field cubes must share ... dtype').

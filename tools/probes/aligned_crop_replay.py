@@ -75,6 +75,9 @@ def run_packed(label, nyp, nxp, dtdt_cube=False):
     ref = eng.rowstats(*f, eng.prepare_boxes(boxes, nyb_min=61), tcoef=eng.time_coefs_device(time_s), t_begin=0, t_count=T, per_step_boxes=True)
     del f
     tc = eng.time_coefs_device(time_s)
+    if dtdt_cube == "real":      # lec_dtdt: the stencil's own bits
+        tm = eng.time_stencil(tm, pk[0], tp, tc)
+        print("   boxes (w, h):", sorted({(b[1] - b[0] + 1, b[3] - b[2] + 1) for b in boxes}), "slabs", tuple(pk[0].shape[2:]), flush=True)
     ms = []
     for i in range(8):
         tmg = [] if i >= 3 else None
@@ -100,6 +103,7 @@ k61 = run_packed("PACKED series, slabs 61 x 61 (7 cubes)", 61, 61)
 k64 = run_packed("PACKED series, slabs 61 x 64 (7 cubes)", 61, 64)
 d61 = run_packed("PACKED + dT/dt cube, 61 x 61 (6 cubes)", 61, 61, dtdt_cube=True)
 d64 = run_packed("PACKED + dT/dt cube, 61 x 64 (6 cubes)", 61, 64, dtdt_cube=True)
+dr = run_packed("PACKED + lec_dtdt cube, default slabs", None, None, dtdt_cube="real")
 print(f"packed with a dT/dt cube / today: {base / d61:.3f} x (61 x 61), {base / d64:.3f} x (61 x 64)")
 print(f"packed / today: {base / k61:.3f} x (61 x 61), {base / k64:.3f} x (61 x 64)")
 print(f"aligned / today: {base / a1:.3f} x (MODE 1), {base / a2:.3f} x (MODE 2); dense 61 x 61: {base / p61:.3f} x")
