@@ -329,7 +329,7 @@ extern "C" int lec_rowstats(const lec_rowstats_args* a) {
     if (a->with_q) {
         if (!a->lattab_d || !a->levtab_d) return lec_set_error(LEC_ERR_ARG, "lec_rowstats: with_q needs lattab_d and levtab_d");
         if (!a->dTdt_d && !a->tcoef_d) return lec_set_error(LEC_ERR_ARG, "lec_rowstats: with_q needs dTdt_d or tcoef_d");
-        if (!a->dTdt_d && a->nt < 2) return lec_set_error(LEC_ERR_ARG, "lec_rowstats: dT/dt from the cube needs nt >= 2");
+        if (!a->dTdt_d && !a->tm_d && a->nt < 2) return lec_set_error(LEC_ERR_ARG, "lec_rowstats: dT/dt from the cube needs nt >= 2");
     }
     const bool packed = a->tm_d || a->tp_d;
     if (packed) {      // a box-packed series: per-step boxes at the origin of their slabs, time neighbours in cubes of their own

@@ -301,7 +301,7 @@ class LECEngine:
         if tcoef is not None:
             if tcoef.shape != (nt, 3) or tcoef.dtype != torch.float64 or tcoef.device != tair.device or not tcoef.is_contiguous():
                 raise ValueError("tcoef must be a contiguous fp64 [nt, 3] tensor on the fields' device")
-            if nt < 2:
+            if nt < 2 and tm is None:           # (a box-packed series brings its time neighbours along: one step is a series)
                 raise ValueError("dT/dt by finite differences needs at least 2 time steps")
         elif with_q and dTdt is None:
             if time_s is None:

@@ -89,6 +89,20 @@ def test_packed_series_random_geometries():
             assert torch.all(b[t, :, bx[3] - bx[2] + 1:] == 0), (case, t)
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_one_step_of_a_packed_series_is_a_series(dtype):
+    """A packed cube brings its time neighbours along, so ONE step can be handed over alone (the last rank of a time-sharded track
+    holds a single step; found by the three-rank CLI test): the records of that step of the whole series."""
+    dom = synthetic_domain(4, 5, 30, 50, seed=21, dtype=dtype)
+    boxes = [(3 + t, 40 + t, 2, 25) for t in range(4)]
+    eng, a, b, (pk, tm, tp, pb, tc) = _both(dom, boxes)
+    for t in (0, 2, 3):
+        one = eng.rowstats(*[c[t:t + 1].contiguous() for c in pk], pb.part(t, t + 1), tcoef=tc[t:t + 1].contiguous(), t_begin=0, t_count=1, per_step_boxes=True,
+                           tm=tm[t:t + 1].contiguous(), tp=tp[t:t + 1].contiguous())
+        torch.cuda.synchronize()
+        assert torch.equal(one[0], a[t]), t
+
+
 def test_nan_beside_the_box_does_not_leak_in():
     """What lies outside a step's box never enters its sums: NaNs all around the boxes in the cube, and NaN-filled slab padding in
     the packed series, change nothing (the one-sided stencils at a box's edge multiply nothing by 0)."""
