@@ -95,6 +95,17 @@ def one_case(rng, case, with_oracle):
             r = eng.compute(*f, boxes, tuning={"kernel": "box_tile", "block_shape": tg}, **kw)
             if not (same_bits(r.rows[..., :28], auto.rows[..., :28]) and same_bits(r.scalars, auto.scalars)):
                 fails.append(f"{what}: box_tile with time groups of {tg} is not bit-identical to the default")
+    if moving:      # the box-packed form of the series (each step's box alone, dT/dt as the series' own data; include/lec_hip.h): no bit may move
+        tc = eng.time_coefs_device(dom.time_s)
+        pb = eng.prepare_boxes(boxes, nyb_min=auto.rows.shape[2], packed=True)
+        pad = int(rng.integers(0, 4))
+        hmax, wmax = max(b[3] - b[2] + 1 for b in boxes), max(b[1] - b[0] + 1 for b in boxes)
+        ps = eng.pack_series(*f, boxes, tc, ny=min(ny, hmax + pad), nx=min(nx, wmax + pad))
+        extra = {k: ps[k] for k in ("dTdt", "tm", "tp") if k in ps}
+        r = eng.rowstats(ps["tair"], ps["u"], ps["v"], ps["omega"], ps["geopt"], pb, t_begin=0, t_count=nt, per_step_boxes=True,
+                         **({"tcoef": tc} if "tm" in ps else {}), **extra)
+        if not same_bits(r[..., :28], auto.rows[..., :28]):
+            fails.append(f"{what}: the box-packed series is not bit-identical to the cube")
     # shards of the series: bit-identical
     if nt >= 3:
         a, b = 1, nt - 1
@@ -119,8 +130,54 @@ def one_case(rng, case, with_oracle):
     return fails
 
 
+def config5_case(rng, case, T=512):
+    """BASELINE config 5 at size: a track of 15-degree (61 x 61 point) boxes over a 37 x 162 x 243 crop, T steps (one rank's share of
+    T = 4096 on 8 GPUs), the track's speed and phase random: the shipped box-tile kernel, its time groups of 2 and 4, the box-packed
+    series and a shard in the middle must give the same bits; the one-wave-per-row kernel the same records to rounding."""
+    from lorenzcycletoolkit_amd.synthetic import era5_like_levels, synthetic_cube
+    lat, lon = np.arange(-57.75, -17.5 + 1e-9, 0.25), np.arange(-80.25, -19.75 + 1e-9, 0.25)
+    level = era5_like_levels()
+    eng = LECEngine(lat, lon, level, device=DEV)
+    f = synthetic_cube(T, level, lat, lon, device=DEV, dtype=torch.float64, seed=int(rng.integers(1 << 20)))
+    tg = np.arange(T)
+    pa, pb_ = rng.uniform(150, 700), rng.uniform(200, 900)
+    clat = -37.5 + rng.uniform(4, 12) * np.sin(2 * np.pi * tg / pa + rng.uniform(0, 6))
+    clon = -50.0 + rng.uniform(8, 22) * np.cos(2 * np.pi * tg / pb_ + rng.uniform(0, 6))
+    boxes = [eng.box_from_limits(lo - 7.5, lo + 7.5, la - 7.5, la + 7.5) for la, lo in zip(clat, clon)]
+    time_s = np.arange(T) * 3600.0
+    tc = eng.time_coefs_device(time_s)
+    cubes = (f["tair"], f["u"], f["v"], f["omega"], f["geopt"])
+    what = f"config-5 case {case}: T={T}, track periods {pa:.0f} / {pb_:.0f}"
+    fails = []
+    plain = eng.prepare_boxes(boxes)
+    base = eng.rowstats(*cubes, plain, tcoef=tc, t_begin=0, t_count=T, per_step_boxes=True)
+    for g in (2, 4):
+        r = eng.rowstats(*cubes, plain, tcoef=tc, t_begin=0, t_count=T, per_step_boxes=True, tuning={"kernel": "box_tile", "block_shape": g})
+        if not same_bits(r[..., :28], base[..., :28]):
+            fails.append(f"{what}: time groups of {g} are not bit-identical")
+    sw = eng.rowstats(*cubes, plain, tcoef=tc, t_begin=0, t_count=T, per_step_boxes=True, tuning={"kernel": "row_sweep"})
+    den = base[..., :28].abs().amax(dim=(0, 1, 2)).clamp_min(1e-300)
+    err = float(((sw[..., :28] - base[..., :28]).abs().amax(dim=(0, 1, 2)) / den).max())
+    if not err <= 2e-11:
+        fails.append(f"{what}: one wave per row differs by {err:.3e}")
+    ps = eng.pack_series(*cubes, boxes, tc)
+    pk = eng.prepare_boxes(boxes, packed=True)
+    r = eng.rowstats(ps["tair"], ps["u"], ps["v"], ps["omega"], ps["geopt"], pk, dTdt=ps["dTdt"], t_begin=0, t_count=T, per_step_boxes=True)
+    if not same_bits(r[..., :28], base[..., :28]):
+        fails.append(f"{what}: the box-packed series is not bit-identical")
+    a, b = T // 3, T // 3 + 100
+    r = eng.rowstats(*cubes, plain.part(a, b), tcoef=tc, t_begin=a, t_count=b - a, per_step_boxes=True)
+    if not same_bits(r[..., :28], base[a:b, ..., :28]):
+        fails.append(f"{what}: shard [{a}, {b}) is not bit-identical")
+    if not bool(torch.isfinite(base).all()):
+        fails.append(f"{what}: non-finite records")
+    torch.cuda.synchronize()
+    return fails
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--config5", type=int, default=0, help="run this many BASELINE-config-5-sized cases (T = 512 moving 61 x 61 boxes) instead")
     ap.add_argument("--cases", type=int, default=200)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--oracle-every", type=int, default=2, help="compare every n-th case with the oracle too (it is the slow part)")
@@ -128,6 +185,14 @@ def main():
     rng = np.random.default_rng(args.seed)
     t0 = time.time()
     fails = []
+    if args.config5:
+        for c in range(args.config5):
+            fails += config5_case(rng, c)
+            print(f"config-5 case {c + 1}, {len(fails)} failures, {time.time() - t0:.0f} s", flush=True)
+        for ln in fails:
+            print("FAIL", ln)
+        print(f"soak config 5: {args.config5} cases, seed {args.seed}: {len(fails)} failures")
+        sys.exit(1 if fails else 0)
     for c in range(args.cases):
         fails += one_case(rng, c, with_oracle=(c % args.oracle_every == 0))
         if (c + 1) % 25 == 0:
