@@ -8,8 +8,12 @@ and there only as the checker / the timed CPU baseline.  The shipped engine
 (``lorenzcycletoolkit_amd``) never imports anything from ``oracle/``.
 
 Parity status: PINNED.  ``tests/test_oracle_golden.py`` checks this restatement against
-the reference's committed sample outputs (``tests/golden/Catarina_NCEP-R2_fixed/*.csv`` and
-rows of ``tests/golden/Reg1_*/*.csv``) -- see DESIGN.md "Oracle".  The reference itself
+the reference's committed sample outputs: ``tests/golden/Catarina_NCEP-R2_fixed/*.csv`` (results + ten tables, 36 steps) and every
+cell of the twenty ``tests/golden/Reg1_{fixed,track}/*_lv_ISBL3.csv`` tables that the 5-level / 5-step ``testdata_NCEP-R2.nc``
+reproduces (sigma, the Q stencil, Ca, Ck on a second data set; the MOVING framework's sigma / Q-with-supplied-dT/dt path) -- see
+DESIGN.md "Oracle".  One committed table disagrees with v1.1.11 and is accounted for: the track sample's Ck (an older second piece,
+``ck_term2_of_the_committed_track_sample``).  Restatement-only, nothing in the reference can pin them: BPhiZ / BPhiE and every
+pressure-INTEGRATED value of the moving framework.  The reference itself
 cannot be imported here (xarray / metpy / pint are not installed; ordinary
 ModuleNotFoundError).
 

@@ -26,7 +26,16 @@ NAMELIST_ERA5 = (";Variable;Units\nAir Temperature;t;K\nGeopotential;z;m**2/s**2
                  "Northward Wind Component;v;m/s\nLongitude;longitude\nLatitude;latitude\nTime;time\nVertical Level;level\n")
 
 
+PAUSE = [0.0]
+
+
 def run_case(workdir, argv, label, env_extra=None, timeout=1500):
+    # On some boxes the driver makes a process wait while the device memory the PREVIOUS process freed is being wiped: a run that
+    # allocates tens of GB milliseconds after such a process exited sits 1-1.5 s in its first large allocation (profiles/r05_notes.md
+    # section 4: 0.07 s of `setup` after a 5-s pause, 0.9-1.4 s back to back, on the same box).  A user does not start the product in
+    # the millisecond another 50-GB job ends; the big cases are therefore measured after a pause (recorded in the output).
+    if PAUSE[0] > 0 and not label.startswith(("catarina", "testdata")):
+        time.sleep(PAUSE[0])
     ph = os.path.join(workdir, "phases.json")
     if os.path.exists(ph):
         os.remove(ph)
@@ -80,8 +89,10 @@ def main():
     ap.add_argument("--long-steps", type=int, default=744, help="also time a LONG series on a small grid (a month of hourly steps, 37 x 41 x 80, "
                     "shuffle + deflate: the host phases -- chunk index, CSV writing -- dominate there); 0 = skip")
     ap.add_argument("--classic-steps", type=int, default=24, help="also time an uncompressed CLASSIC NetCDF file of this many ERA5-size steps (0 = skip)")
+    ap.add_argument("--pause", type=float, default=5.0, help="seconds before every big case (the driver wipes the previous process's device memory)")
     a = ap.parse_args()
-    results = {"host": {"cpus": os.cpu_count()}, "cases": []}
+    PAUSE[0] = a.pause
+    results = {"host": {"cpus": os.cpu_count()}, "pause_before_big_cases_s": a.pause, "cases": []}
     golden = os.path.join(ROOT, "tests", "golden")
 
     def save():
