@@ -60,6 +60,9 @@ using namespace lec;
 #ifndef LEC_BT_ABLATE
 #define LEC_BT_ABLATE 0
 #endif
+#ifndef LEC_BT_DEEP2        // 1: fp64 storage with a dT/dt cube (box-packed series) prefetches Phi and dT/dt two passes ahead too (measurement knob)
+#define LEC_BT_DEEP2 0
+#endif
 #ifndef LEC_BT_QUNROLL      // unroll factor of the compute layout's column loop (register pressure against LDS-read latency)
 #define LEC_BT_QUNROLL 2
 #endif
@@ -305,7 +308,7 @@ __global__ void __launch_bounds__(64 * TG, 2) lec_boxtile_kernel(const RowParams
     // The operands that do not depend on the level window are prefetched TWO passes ahead (two register sets, picked by pass parity at
     // compile time): the kernel is bound by how many loads a CU keeps in flight.  u, v, omega always; Phi and the dT/dt operands too where
     // the registers allow it (fp32 storage: 0.65 vs 0.69 ms; with fp64 storage their second set spills 108 B and costs 15 %).
-    constexpr bool DEEP_ALL = sizeof(TIN) == 4;
+    constexpr bool DEEP_ALL = sizeof(TIN) == 4 || (LEC_BT_DEEP2 && MODE == 2);
     TIN Tn[kWR + 2], Tc[kWR + 2], Tm[kWR], En[kWR] = {}, Ec[kWR] = {}, sU[2][kWR], sV[2][kWR], sW[2][kWR], sP[2][kWR], sD0[2][kWR], sD1[2][kWR];
     double rWl = 0.0, rG[3] = {0.0, 0.0, 0.0};            // non-uniform longitudes: the lane's trapezoid weight and d/dlon coefficients
     if (LEC_BT_ABLATE & 2) {
