@@ -113,16 +113,22 @@ REG1_TERMS = {   # term: (skip the 600-hPa column, usable rows of the fixed tabl
 
 
 def reg1_table(golden_dir, kind, term):
-    """(reference cells, level slice into the 5-level axis of testdata, number of rows, sign) for `kind` in fixed / track."""
+    """(reference cells, level slice into the 5-level axis of testdata, number of rows, sign) for `kind` in fixed / track / choose."""
     import os
     import pandas as pd
     skip600, rows_fixed, sign = REG1_TERMS[term]
     hpa = [600.0, 700.0, 850.0, 925.0, 1000.0][1 if skip600 else 0:]
     df = pd.read_csv(os.path.join(golden_dir, f"Reg1_{kind}", f"{term}_lv_ISBL3.csv"), index_col=0)
-    cols = [str(h) if kind == "fixed" else str(h * 100.0) for h in hpa]        # hPa headers (old fixed sample) / Pa (track)
+    cols = [str(h) if kind == "fixed" else str(h * 100.0) for h in hpa]        # hPa headers (old fixed sample) / Pa (track, choose)
     r = df[cols].values
-    rows = min(rows_fixed, len(r)) if kind == "fixed" else len(r)                # the track tables hold 3 (Ge, Gz: 2) rows
+    rows = min(rows_fixed, len(r)) if kind == "fixed" else len(r)                # the track tables hold 3 (Ge, Gz: 2) rows, the choose tables 3
     return r[:rows], slice(1 if skip600 else 0, None), rows, sign
+
+
+# The boxes of the reference's `-c` (interactive chooser) sample, samples/Reg1-Representative_NCEP-R2_choose/: not recorded anywhere in the
+# reference -- recovered in round 5 by searching every box of the grid for the one whose Kz table (no derivative in it) equals the sample's
+# row: one box per step matches at 1.4e-7 (the table's float32 print precision), the next best is 6-12 % off.  (west, east, south, north)
+REG1_CHOOSE_BOXES = [(-65.0, -50.0, -30.0, -20.0), (-67.5, -50.0, -30.0, -20.0), (-62.5, -42.5, -37.5, -25.0)]
 
 
 def reg1_track_limits(golden_dir):

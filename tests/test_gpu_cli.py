@@ -179,6 +179,32 @@ def test_reg1_sample_tables_pin_the_engine(workdir, golden_dir, kind, ingest):
     print(kind, ingest, worst)
 
 
+@pytest.mark.parametrize("ingest", ["host", "device"])
+def test_reg1_choose_sample_tables_pin_the_moving_engine(workdir, golden_dir, ingest):
+    """The reference's `-c` sample (samples/Reg1-Representative_NCEP-R2_choose: the moving framework with a box picked per step) has
+    three steps with three DIFFERENT boxes; its boxes were recovered from its own Kz table (tests/helpers.REG1_CHOOSE_BOXES).  The same
+    boxes as a track with width / length columns (two more steps appended so that the third step's dT/dt is centred, as it was over the
+    chooser's whole file): the engine's tables -- host-prepared and box-packed device ingest -- against the reference's own numbers,
+    float32-noise policy of SURVEY appendix D; Ck left out (the sample predates today's second piece: tests/test_oracle_golden.py)."""
+    from tests.helpers import REG1_CHOOSE_BOXES, REG1_TERMS, reg1_table
+    boxes = REG1_CHOOSE_BOXES + [REG1_CHOOSE_BOXES[-1]] * 2
+    stamps = ["2005-08-08-0000", "2005-08-08-0600", "2005-08-08-1200", "2005-08-08-1800", "2005-08-09-0000"]
+    (workdir / "inputs" / "track").write_text("time;Lat;Lon;length;width\n" + "".join(
+        f"{ts};{(s + n) / 2};{(w + e) / 2};{n - s};{e - w}\n" for ts, (w, e, s, n) in zip(stamps, boxes)))
+    infile = os.path.join(golden_dir, "testdata_NCEP-R2.nc")
+    _main([infile, "-r", "-t", "--ingest", ingest])
+    lvdir = workdir / "LEC_Results" / "testdata_NCEP-R2_track" / "results_vertical_levels"
+    trk = pd.read_csv(workdir / "LEC_Results" / "testdata_NCEP-R2_track" / "testdata_NCEP-R2_track_trackfile", sep=";")
+    assert [tuple(x) for x in trk[["min_lon", "max_lon", "min_lat", "max_lat"]].values[:3]] == [tuple(b) for b in REG1_CHOOSE_BOXES]
+    for term in REG1_TERMS:
+        if term == "Ck":
+            continue
+        r, lev, rows, sign = reg1_table(golden_dir, "choose", term)
+        got = pd.read_csv(lvdir / f"{term}_lv_ISBL3.csv", index_col=0)
+        a = sign * got.values[:rows, lev]
+        assert np.all(np.abs(a - r) <= 2e-4 * np.abs(r) + 1e-4 * np.max(np.abs(r))), term
+
+
 def test_ingest_auto_falls_back_to_the_host_preparation(workdir, monkeypatch):
     """`--ingest auto` (the default) sends a deflated NetCDF-4 file to the streamed device path by itself.  If that path then refuses
     the input (ValueError / NotImplementedError), the run must not fail where the host preparation works: the file is closed, the

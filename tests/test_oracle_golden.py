@@ -13,7 +13,7 @@ import pandas as pd
 import pytest
 
 from oracle import lec_oracle as o
-from tests.helpers import REG1_BOX, REG1_TERMS, reg1_table, reg1_track_limits
+from tests.helpers import REG1_BOX, REG1_CHOOSE_BOXES, REG1_TERMS, reg1_table, reg1_track_limits
 
 CAT_BOX = (-55, -36, -35, -20)      # tests/golden/Catarina_NCEP-R2_fixed/log.txt:3
 
@@ -152,6 +152,39 @@ def test_testdata_moving_ck_is_the_older_term_2(testdata_moving, golden_dir):
 def test_testdata_moving_ck_current_form(testdata_moving, golden_dir):
     r, lev, rows, _ = reg1_table(golden_dir, "track", "Ck")
     assert _scale_err(np.asarray(testdata_moving["f32"]["Ck"], dtype=np.float64)[:rows, lev], r) <= REG1_F32_TOL["Ck"]
+
+
+@pytest.fixture(scope="module")
+def testdata_choose(testdata):
+    """The reference's `-c` sample: the moving framework with a box picked per time step (lec_moving_framework.py:639-745 with
+    `args.choose`; dT/dt over the file's whole time axis, lorenzcycletoolkit.py:184-186).  Boxes: tests/helpers.REG1_CHOOSE_BOXES
+    (recovered from the sample's own Kz table); the last one repeated for the two steps the sample does not hold."""
+    boxes = REG1_CHOOSE_BOXES + [REG1_CHOOSE_BOXES[-1]] * 2
+    extra = lambda b: {"Ck_2_old": o.ck_term2_of_the_committed_track_sample(b)}
+    return {k: o.lec_moving(d, boxes, per_box=extra)[1] for k, d in testdata.items()}
+
+
+@pytest.mark.parametrize("term", [t for t in REG1_TERMS if t != "Ck"])
+def test_testdata_choose_levels(testdata_choose, golden_dir, term):
+    """A third reference-held data set for the moving framework: three steps with three DIFFERENT boxes (7 x 5, 8 x 5 and 9 x 6 points),
+    all ten tables -- Ge / Gz with the centred dT/dt of the third step too."""
+    r, lev, rows, sign = reg1_table(golden_dir, "choose", term)
+    assert rows == 3
+    a = sign * np.asarray(testdata_choose["f32"][term], dtype=np.float64)[:rows, lev]
+    assert _scale_err(a, r) <= max(REG1_F32_TOL[term], 1e-12)          # (boxes of 35-54 points: Ca's two pieces cancel to 3e-13 of its scale)
+    a64 = sign * np.asarray(testdata_choose["f64"][term], dtype=np.float64)[:rows, lev]
+    assert np.all(np.abs(a64 - r) <= 2e-4 * np.abs(r) + 1e-4 * np.max(np.abs(r)))
+
+
+def test_testdata_choose_ck_confirms_the_older_term_2(testdata_choose, golden_dir):
+    """The chooser sample was written in the same era as the track sample: its Ck table, too, carries the second piece that
+    differentiates [v] cos(phi) (5.5e-8 with it, 3-5 % of the scale off with today's) -- an independent confirmation of the finding."""
+    r, lev, rows, _ = reg1_table(golden_dir, "choose", "Ck")
+    lv = testdata_choose["f32"]
+    f = lambda k: np.asarray(lv[k], dtype=np.float64)
+    old = (f("Ck_1") + f("Ck_2_old") + f("Ck_3") + f("Ck_4") + f("Ck_5"))[:rows, lev]
+    assert _scale_err(old, r) <= 2e-7
+    assert 0.02 < _scale_err(f("Ck")[:rows, lev], r) < 0.1
 
 
 @pytest.mark.parametrize("kind,results,hpa", [("fixed", "Reg1-Representative_NCEP-R2_fixed_results.csv", 100.0),
