@@ -4,7 +4,11 @@
  *
  *   gcc -O2 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude lec_c_client.c -o lec_c_client \
  *       -L/opt/rocm/lib -lamdhip64 -Llorenzcycletoolkit_amd -llec_hip
- *   ./lec_c_client bundle.bin out.bin
+ *   ./lec_c_client bundle.bin out.bin [out_packed.bin out_table.csv]
+ *
+ * With the two optional outputs it also walks the ABI-9 additions: the same box handed over as a BOX-PACKED moving series (one box per
+ * time step -- here the same one --, each step's box copied to the origin of its slab with hipMemcpy2D, dT/dt as a cube from lec_dtdt),
+ * run through lec_rowstats (box_per_step) + lec_reduce, and the Az table of the first run as CSV text from lec_format_csv_rows.
  */
 #include <stdint.h>
 #include <stdio.h>
@@ -17,17 +21,28 @@
 
 #define CHECK_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return 2; } } while (0)
 
-static void* upload(FILE* f, size_t bytes) {
+static void* upload_keep(FILE* f, size_t bytes, void** host) {
     void* h = malloc(bytes);
     void* d = NULL;
     if (!h || fread(h, 1, bytes, f) != bytes) { fprintf(stderr, "short bundle\n"); exit(3); }
     if (hipMalloc(&d, bytes) != hipSuccess || hipMemcpy(d, h, bytes, hipMemcpyHostToDevice) != hipSuccess) { fprintf(stderr, "upload failed\n"); exit(4); }
-    free(h);
+    if (host) *host = h; else free(h);
+    return d;
+}
+
+static void* upload(FILE* f, size_t bytes) { return upload_keep(f, bytes, NULL); }
+
+/* `n` copies of a host table, one after the other, on the device (the per-box tables of a series of n identical boxes) */
+static void* replicate(const void* h, size_t bytes, int n) {
+    char* d = NULL;
+    if (hipMalloc((void**)&d, bytes * (size_t)n) != hipSuccess) { fprintf(stderr, "hipMalloc failed\n"); exit(4); }
+    for (int i = 0; i < n; ++i)
+        if (hipMemcpy(d + (size_t)i * bytes, h, bytes, hipMemcpyHostToDevice) != hipSuccess) { fprintf(stderr, "upload failed\n"); exit(4); }
     return d;
 }
 
 int main(int argc, char** argv) {
-    if (argc != 3) { fprintf(stderr, "usage: %s bundle.bin out.bin\n", argv[0]); return 1; }
+    if (argc != 3 && argc != 5) { fprintf(stderr, "usage: %s bundle.bin out.bin [out_packed.bin out_table.csv]\n", argv[0]); return 1; }
     FILE* f = fopen(argv[1], "rb");
     if (!f) { perror(argv[1]); return 1; }
     /* header: nt nl ny nx nxb nyb lon_uniform  (int32 x 7), phi_scale (double) */
@@ -44,15 +59,16 @@ int main(int argc, char** argv) {
     ra.dtype = LEC_F64; ra.with_q = 1;
     ra.nt = nt; ra.nl = nl; ra.ny = ny; ra.nx = nx; ra.t_begin = 0; ra.t_count = nt;
     ra.n_box = 1; ra.box_per_step = 0; ra.nxb_max = nxb; ra.nyb_max = nyb; ra.lon_uniform = uni;
-    ra.box_d = (const int32_t*)upload(f, 4 * sizeof(int32_t));
-    ra.boxtab_d = (const double*)upload(f, 4 * sizeof(double));
-    ra.wlon_d = (const double*)upload(f, (size_t)nxb * sizeof(double));
-    ra.glon_d = (const double*)upload(f, (size_t)nxb * 3 * sizeof(double));
-    ra.lattab_d = (const double*)upload(f, (size_t)nyb * 4 * sizeof(double));
+    void *h_box, *h_boxtab, *h_wlon, *h_glon, *h_lattab, *h_boxtab2, *h_lattab2;      /* host copies: the packed series replicates them per step */
+    ra.box_d = (const int32_t*)upload_keep(f, 4 * sizeof(int32_t), &h_box);
+    ra.boxtab_d = (const double*)upload_keep(f, 4 * sizeof(double), &h_boxtab);
+    ra.wlon_d = (const double*)upload_keep(f, (size_t)nxb * sizeof(double), &h_wlon);
+    ra.glon_d = (const double*)upload_keep(f, (size_t)nxb * 3 * sizeof(double), &h_glon);
+    ra.lattab_d = (const double*)upload_keep(f, (size_t)nyb * 4 * sizeof(double), &h_lattab);
     ra.levtab_d = (const double*)upload(f, (size_t)nl * 3 * sizeof(double));
     ra.tcoef_d = (const double*)upload(f, (size_t)nt * 3 * sizeof(double));
-    const double* boxtab2 = (const double*)upload(f, 4 * sizeof(double));
-    const double* lattab2 = (const double*)upload(f, (size_t)nyb * 8 * sizeof(double));
+    const double* boxtab2 = (const double*)upload_keep(f, 4 * sizeof(double), &h_boxtab2);
+    const double* lattab2 = (const double*)upload_keep(f, (size_t)nyb * 8 * sizeof(double), &h_lattab2);
     const double* levtab2 = (const double*)upload(f, (size_t)nl * 4 * sizeof(double));
     fclose(f);
 
@@ -130,5 +146,87 @@ int main(int argc, char** argv) {
     fwrite(hl, sizeof(double), (size_t)nt * LEC_NLEVTAB * nl, o);
     fclose(o);
     printf("ok: %d time steps, Az[0] = %.17g\n", nt, hs[0]);
+    if (argc != 5) return 0;
+
+    /* ---- ABI 9, part 1: the Az table (first of the 21) as the text the reference's DataFrame.to_csv(header=None) writes ---- */
+    {
+        char* labels = (char*)malloc((size_t)nt * 19 + 1);
+        for (int t = 0; t < nt; ++t) snprintf(labels + (size_t)t * 19, 20, "2005-08-%02d %02d:00:00", 8 + (6 * t) / 24, (6 * t) % 24);
+        const long long cap = (long long)nt * (19 + 27 * nl + 1);
+        char* text = (char*)malloc((size_t)cap);
+        double* az = (double*)malloc((size_t)nt * nl * sizeof(double));
+        for (int t = 0; t < nt; ++t) memcpy(az + (size_t)t * nl, hl + (size_t)t * LEC_NLEVTAB * nl, (size_t)nl * sizeof(double));
+        const long long n = lec_format_csv_rows(az, nt, nl, nl, labels, 19, text, cap);
+        if (n < 0) { fprintf(stderr, "lec_format_csv_rows: %s\n", lec_last_error()); return 20; }
+        FILE* c = fopen(argv[4], "wb");
+        if (!c) { perror(argv[4]); return 1; }
+        fwrite(text, 1, (size_t)n, c);
+        fclose(c);
+        if (lec_format_csv_rows(az, nt, nl, nl, labels, 19, text, 10) != -1) { fprintf(stderr, "lec_format_csv_rows took a short buffer\n"); return 21; }
+    }
+
+    /* ---- ABI 9, part 2: the same box as a BOX-PACKED moving series ---- */
+    {
+        const int32_t* bx = (const int32_t*)h_box;                       /* iw ie js jn */
+        const int iw = bx[0], js = bx[2];
+        const size_t slab = (size_t)nl * nyb * nxb, pcube = (size_t)nt * slab * sizeof(double);
+        const void* src[5] = {ra.tair_d, ra.u_d, ra.v_d, ra.omega_d, ra.geopt_d};
+        double* pk[7];                                                   /* T u v omega Phi, T(t-1), T(t+1): each step's box at its slab's origin */
+        for (int c = 0; c < 7; ++c) CHECK_HIP(hipMalloc((void**)&pk[c], pcube));
+        for (int c = 0; c < 7; ++c)
+            for (int t = 0; t < nt; ++t) {
+                const int ts = c < 5 ? t : (c == 5 ? (t > 0 ? t - 1 : t) : (t < nt - 1 ? t + 1 : t));      /* the step itself where a neighbour does not exist */
+                const double* s0 = (const double*)(c < 5 ? src[c] : ra.tair_d) + (size_t)ts * nl * ny * nx;
+                for (int k = 0; k < nl; ++k)
+                    CHECK_HIP(hipMemcpy2D(pk[c] + (size_t)t * slab + (size_t)k * nyb * nxb, (size_t)nxb * sizeof(double),
+                                          s0 + ((size_t)k * ny + js) * nx + iw, (size_t)nx * sizeof(double),
+                                          (size_t)nxb * sizeof(double), (size_t)nyb, hipMemcpyDeviceToDevice));
+            }
+        double* dtdt;
+        CHECK_HIP(hipMalloc((void**)&dtdt, pcube));
+        lec_dtdt_args da;
+        memset(&da, 0, sizeof da);
+        da.tm_d = pk[5]; da.t_d = pk[0]; da.tp_d = pk[6]; da.dtype = LEC_F64; da.n_steps = nt; da.step_elems = (int64_t)slab;
+        da.tcoef_d = ra.tcoef_d; da.out_d = dtdt; da.stream = NULL;
+        if (lec_dtdt(&da) != LEC_OK) { fprintf(stderr, "lec_dtdt: %s\n", lec_last_error()); return 22; }
+
+        int32_t* origin = (int32_t*)malloc((size_t)nt * 4 * sizeof(int32_t));
+        for (int t = 0; t < nt; ++t) { origin[4 * t] = 0; origin[4 * t + 1] = nxb - 1; origin[4 * t + 2] = 0; origin[4 * t + 3] = nyb - 1; }
+        int32_t* origin_d;
+        CHECK_HIP(hipMalloc((void**)&origin_d, (size_t)nt * 4 * sizeof(int32_t)));
+        CHECK_HIP(hipMemcpy(origin_d, origin, (size_t)nt * 4 * sizeof(int32_t), hipMemcpyHostToDevice));
+
+        lec_rowstats_args rp = ra;
+        rp.tair_d = pk[0]; rp.u_d = pk[1]; rp.v_d = pk[2]; rp.omega_d = pk[3]; rp.geopt_d = pk[4]; rp.dTdt_d = dtdt;
+        rp.ny = nyb; rp.nx = nxb;                                        /* the slabs */
+        rp.n_box = nt; rp.box_per_step = 1;
+        rp.box_d = origin_d;                                             /* the boxes as the cubes hold them ... */
+        rp.boxtab_d = (const double*)replicate(h_boxtab, 4 * sizeof(double), nt);       /* ... every table from the true grid box */
+        rp.wlon_d = (const double*)replicate(h_wlon, (size_t)nxb * sizeof(double), nt);
+        rp.glon_d = (const double*)replicate(h_glon, (size_t)nxb * 3 * sizeof(double), nt);
+        rp.lattab_d = (const double*)replicate(h_lattab, (size_t)nyb * 4 * sizeof(double), nt);
+        rp.tcoef_d = NULL;
+        if (lec_check_boxes(&rp, status) != LEC_OK) { fprintf(stderr, "lec_check_boxes (packed): %s\n", lec_last_error()); return 23; }
+        if (lec_rowstats(&rp) != LEC_OK) { fprintf(stderr, "lec_rowstats (packed): %s\n", lec_last_error()); return 24; }
+        lec_reduce_args r2 = rd;
+        r2.n_box = nt; r2.drop_any_time = 0;                             /* the moving framework: one BoxData per step */
+        r2.box_d = (const int32_t*)replicate(h_box, 4 * sizeof(int32_t), nt);
+        r2.boxtab2_d = (const double*)replicate(h_boxtab2, 4 * sizeof(double), nt);
+        r2.lattab2_d = (const double*)replicate(h_lattab2, (size_t)nyb * 8 * sizeof(double), nt);
+        if (lec_reduce(&r2) != LEC_OK) { fprintf(stderr, "lec_reduce (packed): %s\n", lec_last_error()); return 25; }
+        CHECK_HIP(hipDeviceSynchronize());
+        CHECK_HIP(hipMemcpy(hs, scalars, (size_t)nt * LEC_NSCALAR * sizeof(double), hipMemcpyDeviceToHost));
+        CHECK_HIP(hipMemcpy(hl, levels, (size_t)nt * LEC_NLEVTAB * nl * sizeof(double), hipMemcpyDeviceToHost));
+        FILE* o2 = fopen(argv[3], "wb");
+        if (!o2) { perror(argv[3]); return 1; }
+        fwrite(hs, sizeof(double), (size_t)nt * LEC_NSCALAR, o2);
+        fwrite(hl, sizeof(double), (size_t)nt * LEC_NLEVTAB * nl, o2);
+        fclose(o2);
+        /* one neighbour cube without the other is refused */
+        lec_rowstats_args half = rp;
+        half.dTdt_d = NULL; half.tm_d = pk[5]; half.tcoef_d = ra.tcoef_d;
+        if (lec_rowstats(&half) != LEC_ERR_ARG || strstr(lec_last_error(), "tm_d and tp_d") == NULL) { fprintf(stderr, "packed validation broken\n"); return 26; }
+        printf("ok: the same box as a box-packed series, Az[0] = %.17g\n", hs[0]);
+    }
     return 0;
 }

@@ -42,7 +42,8 @@ def test_plain_c_client_reproduces_the_engine(tmp_path):
         np.ascontiguousarray(bt.box, dtype=np.int32).tofile(f)
         for a in (bt.boxtab, bt.wlon, bt.glon, bt.lattab, levtab, tcoef, bt.boxtab2, bt.lattab2, levtab2):
             np.ascontiguousarray(a, dtype=np.float64).tofile(f)
-    r = subprocess.run([exe, str(tmp_path / "bundle.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=120)
+    r = subprocess.run([exe, str(tmp_path / "bundle.bin"), str(tmp_path / "out.bin"), str(tmp_path / "packed.bin"), str(tmp_path / "az.csv")],
+                       capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr + r.stdout
     out = np.fromfile(tmp_path / "out.bin", dtype=np.float64)
     nt, nl = 5, 6
@@ -53,3 +54,17 @@ def test_plain_c_client_reproduces_the_engine(tmp_path):
     assert np.array_equal(scal, res.scalars.cpu().numpy())
     assert np.array_equal(lev, res.levels.cpu().numpy(), equal_nan=True)
     assert "ok: 5 time steps" in r.stdout
+    # ABI 9 from plain C.  The same box as a BOX-PACKED moving series (hipMemcpy2D crops, lec_dtdt, box_per_step): the moving
+    # framework's numbers for five identical boxes, bit for bit ...
+    mv = eng.compute(dev(dom.tair), dev(dom.u), dev(dom.v), dev(dom.omega), dev(dom.geopt), [box] * nt, time_s=dom.time_s, per_step_boxes=True)
+    pk = np.fromfile(tmp_path / "packed.bin", dtype=np.float64)
+    assert np.array_equal(pk[: nt * _lib.LEC_NSCALAR].reshape(nt, -1), mv.scalars.cpu().numpy())
+    assert np.array_equal(pk[nt * _lib.LEC_NSCALAR:].reshape(nt, _lib.LEC_NLEVTAB, nl), mv.levels.cpu().numpy(), equal_nan=True)
+    assert "box-packed series" in r.stdout
+    # ... and the Az table as the text pandas writes for it (lec_format_csv_rows)
+    import io
+    import pandas as pd
+    want = io.StringIO()
+    idx = pd.date_range("2005-08-08", periods=nt, freq="6h").strftime("%Y-%m-%d %H:%M:%S")
+    pd.DataFrame(lev[:, 0, :], index=idx).to_csv(want, mode="a", header=None)
+    assert open(tmp_path / "az.csv", "rb").read() == want.getvalue().encode()
