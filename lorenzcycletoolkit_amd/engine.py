@@ -233,8 +233,10 @@ class LECEngine:
                 drop_any_time: Optional[bool] = None,
                 merge_dropmask: Optional[Callable[[torch.Tensor], None]] = None,
                 tuning: Optional[dict] = None, per_step_boxes: Optional[bool] = None,
-                out: Optional[torch.Tensor] = None) -> LECResult:
+                out: Optional[torch.Tensor] = None, tm: Optional[torch.Tensor] = None, tp: Optional[torch.Tensor] = None,
+                tcoef: Optional[torch.Tensor] = None) -> LECResult:
         """All LEC terms for time steps [t_begin, t_begin + t_count) of the cubes: ``rowstats`` then ``reduce``.
+        (``tm`` / ``tp`` / ``tcoef``: a box-packed series, see ``rowstats``.)
 
         ``boxes``: one (iw, ie, js, jn) quadruple (fixed framework) or one per processed time step
         (moving framework).  ``per_step_boxes``: True = the moving framework's semantics (default when more than one
@@ -249,7 +251,7 @@ class LECEngine:
         stream around the stage-1 kernel (bench.py's roofline figure).
         """
         rows = self.rowstats(tair, u, v, omega, geopt, boxes, time_s=time_s, dTdt=dTdt, t_begin=t_begin, t_count=t_count,
-                             with_q=with_q, timing=timing, tuning=tuning, per_step_boxes=per_step_boxes)
+                             with_q=with_q, timing=timing, tuning=tuning, per_step_boxes=per_step_boxes, tm=tm, tp=tp, tcoef=tcoef)
         if drop_any_time is None and per_step_boxes:
             drop_any_time = False
         return self.reduce(rows, boxes, phi_scale=phi_scale, drop_any_time=drop_any_time, merge_dropmask=merge_dropmask,

@@ -154,8 +154,10 @@ class BoxData:
         # a file may mix dtypes (float32 T, u, v with an int16-packed z that decodes to float64): the engine wants one storage
         # dtype, the widest of them -- widening is exact, and all arithmetic is fp64 anyway (xarray would promote pairwise)
         common = np.result_type(*[a.dtype for a in arrays])
-        cubes = [torch.as_tensor(np.ascontiguousarray(a, dtype=common)).to(dev) for a in arrays]
         phi_scale = ds.field_scale(variable_list_df, geo_role)
+        if self.per_step_boxes and dTdt is None:
+            return self._compute_resident_packed(arrays, common, data, dev, phi_scale, merge, out)
+        cubes = [torch.as_tensor(np.ascontiguousarray(a, dtype=common)).to(dev) for a in arrays]
         dTdt_dev = None
         if dTdt is not None:
             dTdt = np.asarray(dTdt)
@@ -171,6 +173,32 @@ class BoxData:
                                    time_s=data.time_s[h0:h1] if dTdt is None else None, dTdt=dTdt_dev, phi_scale=phi_scale,
                                    t_begin=t0 - h0, t_count=t1 - t0, per_step_boxes=self.per_step_boxes,
                                    drop_any_time=not self.per_step_boxes, merge_dropmask=merge, out=out)
+
+    def _compute_resident_packed(self, arrays, common, data, dev, phi_scale, merge, out) -> LECResult:
+        """The moving framework on host-prepared data: the reference slices every step's box out of the crop (box_data.py:297-310);
+        here the host does that slice BEFORE the upload -- each step's box to the origin of its slab, T also from the two neighbouring
+        steps -- so a tenth of the crop crosses the link and stage 1 gets the box-packed series the streamed path hands it too
+        (include/lec_hip.h; fp64 storage: dT/dt as a cube, `lec_dtdt`; fp32: the two neighbours).  Same records as the crop, bit for bit."""
+        (t0, t1), (h0, h1) = self.t_own, self.t_held
+        boxes = self.boxes[t0:t1]
+        nyb = max(b[3] - b[2] + 1 for b in self.boxes)       # (the records of every rank have the row count of the tallest box of the WHOLE series)
+        nxb = max(b[1] - b[0] + 1 for b in self.boxes)
+        nl = arrays[0].shape[1]
+
+        def pack(a, shift=0):
+            p = np.zeros((t1 - t0, nl, nyb, nxb), dtype=common)
+            for i, (iw, ie, js, jn) in enumerate(boxes):
+                ts = min(max(t0 + i + shift, h0), h1 - 1) - h0       # the step itself where the series has no neighbour (coefficient 0)
+                p[i, :, : jn - js + 1, : ie - iw + 1] = a[ts, :, js: jn + 1, iw: ie + 1]
+            return torch.as_tensor(p).to(dev)
+
+        f = [pack(a) for a in arrays]
+        tm, tp = pack(arrays[0], -1), pack(arrays[0], +1)
+        tcoef = self.engine.time_coefs_device(data.time_s[h0:h1])[t0 - h0: t1 - h0].contiguous()
+        pb = self.engine.prepare_boxes(boxes, nyb_min=nyb, packed=True)
+        kw = dict(dTdt=self.engine.time_stencil(tm, f[0], tp, tcoef)) if common == np.float64 else dict(tm=tm, tp=tp, tcoef=tcoef)
+        return self.engine.compute(f[0], f[1], f[2], f[3], f[4], pb, phi_scale=phi_scale, t_begin=0, t_count=t1 - t0, per_step_boxes=True,
+                                   drop_any_time=False, merge_dropmask=merge, out=out, **kw)
 
 
 def time_labels(times, method: str):
