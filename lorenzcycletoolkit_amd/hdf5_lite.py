@@ -31,6 +31,75 @@ class Hdf5Error(ValueError):
     pass
 
 
+class ChunkTable:
+    """The chunk index of a large chunked dataset as ARRAYS: origins [n, rank] and three values per chunk (file address, stored size,
+    filter mask -- or, from ``chunk_streams``, offset in the mapped file, stream bytes, deflate skipped).  It answers like the dict
+    {origin tuple: (a, b, c)} the small-file paths use (``[]``, ``get``, ``items``, ``len``, ``in``), but a month of hourly ERA5
+    -- 110,000 chunks per variable, 550,000 per file -- is never turned into Python tuples: ``lookup`` takes an array of origins
+    (round 5: the dict cost 0.3 s of a 1.8-s run, profiles/r05_notes.md section 8)."""
+
+    def __init__(self, offs: np.ndarray, a: np.ndarray, b: np.ndarray, c: np.ndarray, chunk, shape):
+        self.offs = np.ascontiguousarray(offs, dtype=np.int64)
+        self.a, self.b, self.c = (np.asarray(x) for x in (a, b, c))
+        self.chunk = tuple(int(x) for x in chunk)
+        self.counts = tuple(-(-int(s) // c) for s, c in zip(shape, self.chunk))
+        self._index = None
+
+    def __len__(self):
+        return len(self.a)
+
+    def _rows(self, origins: np.ndarray) -> np.ndarray:
+        """Row of every origin ([m, rank], elements), -1 where the chunk was never written or lies outside the dataset."""
+        if self._index is None:
+            idx = np.full(int(np.prod(self.counts, dtype=np.int64)), -1, dtype=np.int64)
+            if len(self.a):
+                idx[np.ravel_multi_index(tuple((self.offs // np.array(self.chunk)).T), self.counts)] = np.arange(len(self.a))
+            self._index = idx
+        o = np.asarray(origins, dtype=np.int64).reshape(-1, len(self.chunk))
+        ch = np.array(self.chunk)
+        g = o // ch
+        ok = ((o % ch) == 0).all(axis=1) & (g >= 0).all(axis=1) & (g < np.array(self.counts)).all(axis=1)
+        rows = np.full(len(o), -1, dtype=np.int64)
+        if ok.any():
+            rows[ok] = self._index[np.ravel_multi_index(tuple(g[ok].T), self.counts)]
+        return rows
+
+    def lookup(self, origins):
+        """(a, b, c) arrays of the chunks at ``origins`` [m, rank]; KeyError if one is not in the index."""
+        rows = self._rows(origins)
+        if (rows < 0).any():
+            raise KeyError(tuple(int(x) for x in np.asarray(origins).reshape(-1, len(self.chunk))[int(np.argmax(rows < 0))]))
+        return self.a[rows], self.b[rows], self.c[rows]
+
+    def __getitem__(self, key):
+        a, b, c = self.lookup(np.asarray(key, dtype=np.int64)[None, :])
+        return (a[0].item(), b[0].item(), c[0].item())
+
+    def get(self, key, default=None):
+        r = int(self._rows(np.asarray(key, dtype=np.int64)[None, :])[0])
+        return default if r < 0 else (self.a[r].item(), self.b[r].item(), self.c[r].item())
+
+    def __contains__(self, key):
+        return int(self._rows(np.asarray(key, dtype=np.int64)[None, :])[0]) >= 0
+
+    def keys(self):
+        return map(tuple, self.offs.tolist())
+
+    __iter__ = keys
+
+    def values(self):
+        return zip(self.a.tolist(), self.b.tolist(), self.c.tolist())
+
+    def items(self):
+        return zip(self.keys(), self.values())
+
+    def with_values(self, a, b, c) -> "ChunkTable":
+        t = ChunkTable.__new__(ChunkTable)
+        t.offs, t.chunk, t.counts, t._index = self.offs, self.chunk, self.counts, self._index
+        t.a, t.b, t.c = np.asarray(a), np.asarray(b), np.asarray(c)
+        return t
+
+
 @dataclass
 class _Dtype:
     kind: str                       # "num", "str", "vlen_str", "vlen", "ref", "other"
@@ -90,7 +159,8 @@ class H5Variable:
         than shuffle / deflate / fletcher32 (a chunked variable WITHOUT deflate -- every record variable of an uncompressed NetCDF-4
         file -- qualifies: its chunks are "stored as they are" and are copied into place):
         ``{"chunk": chunk shape, "shuffle": bool, "table": {chunk origin (elements) -> (offset in the mapped file, stored bytes,
-        deflate skipped for this chunk)}, "fletcher32": bool, "map": the file's memory map}``.  The stored bytes of a chunk are its zlib
+        deflate skipped for this chunk)} -- a dict, or for large v1-B-tree indexes a ``ChunkTable`` (the same mapping kept as arrays,
+        with a vectorised ``lookup``) --, "fletcher32": bool, "map": the file's memory map}``.  The stored bytes of a chunk are its zlib
         stream; with ``fletcher32`` four checksum bytes follow them (not counted in "stored bytes"; ``lec_inflate`` verifies them)."""
         if "streams" not in self._cache:
             self._cache["streams"] = self._chunk_streams()
@@ -116,16 +186,22 @@ class H5Variable:
         if not table:
             return None
         # (one NumPy pass over the table instead of a Python loop per chunk: a month of hourly ERA5 is 10^5 chunks per variable)
-        import itertools
-        rec = np.fromiter(itertools.chain.from_iterable(table.values()), dtype=np.int64, count=3 * len(table)).reshape(-1, 3)    # address, stored size, filter mask
-        addr, size, mask = rec[:, 0], rec[:, 1], rec[:, 2]
+        if isinstance(table, ChunkTable):
+            addr, size, mask = table.a, table.b, table.c
+        else:
+            import itertools
+            rec = np.fromiter(itertools.chain.from_iterable(table.values()), dtype=np.int64, count=3 * len(table)).reshape(-1, 3)    # address, stored size, filter mask
+            addr, size, mask = rec[:, 0], rec[:, 1], rec[:, 2]
         if (size >= (1 << 28)).any():
             return None
         skipped = lambda fid: (mask & (1 << ids.index(fid))) != 0
         if (2 in ids and skipped(2).any()) or (3 in ids and skipped(3).any()):
             return None
-        plain = skipped(1) if 1 in ids else np.ones(len(rec), dtype=bool)
-        out = dict(zip(table.keys(), zip((addr + self._file.base).tolist(), (size - (4 if 3 in ids else 0)).tolist(), plain.tolist())))
+        plain = skipped(1) if 1 in ids else np.ones(len(addr), dtype=bool)
+        if isinstance(table, ChunkTable):
+            out = table.with_values(addr + self._file.base, size - (4 if 3 in ids else 0), plain)
+        else:
+            out = dict(zip(table.keys(), zip((addr + self._file.base).tolist(), (size - (4 if 3 in ids else 0)).tolist(), plain.tolist())))
         return {"chunk": tuple(lay["chunk"]), "shuffle": 2 in ids, "fletcher32": 3 in ids, "table": out, "map": self._file._m}
 
 
@@ -648,6 +724,8 @@ class H5File:
             rec = np.dtype([("size", "<u4"), ("mask", "<u4"), ("offs", "<u8", (rank + 1,)), ("child", "<u8")])
             buf = np.frombuffer(self._m, dtype=np.uint8)
 
+            leaves = []
+
             def walk(addr):
                 a = addr + self.base
                 m = self._m
@@ -659,12 +737,16 @@ class H5File:
                 p = a + 8 + 2 * self.O
                 e = buf[p: p + n * rec.itemsize].view(rec)
                 if level == 0:
-                    table.update(zip(map(tuple, e["offs"][:, :rank].tolist()), zip(e["child"].tolist(), e["size"].tolist(), e["mask"].tolist())))
+                    leaves.append(e)               # (views of the mapped file: nothing is copied until the concatenation below)
                 else:
                     for child in e["child"].tolist():
                         walk(child)
             if lay["addr"] != (1 << (8 * self.O)) - 1:
                 walk(lay["addr"])
+            if leaves:
+                e = np.concatenate(leaves)
+                table = ChunkTable(e["offs"][:, :rank].astype(np.int64), e["child"].astype(np.int64), e["size"].astype(np.int64),
+                                   e["mask"].astype(np.int64), chunk, var.shape)
         elif lay["index"] == "btree1":
             def walk(addr):
                 a = addr + self.base

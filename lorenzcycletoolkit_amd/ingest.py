@@ -417,9 +417,14 @@ class _ChunkStager:
         got = self._tc.get(tc)
         if got is None:
             table, t0 = self.info["table"], tc * self.chunk[0]
-            rows = [table[(t0, int(k), int(j), int(i))] for k, j, i in self.space]
-            got = self._tc[tc] = (np.array([r[0] for r in rows], dtype=np.int64), np.array([r[1] for r in rows], dtype=np.int64),
-                                  np.array([r[2] for r in rows], dtype=bool))
+            if hasattr(table, "lookup"):                   # the index kept as arrays (hdf5_lite.ChunkTable): one vectorised lookup per time-chunk
+                org = np.concatenate([np.full((len(self.space), 1), t0, dtype=np.int64), self.space], axis=1)
+                a, b, c = table.lookup(org)
+                got = self._tc[tc] = (a.astype(np.int64), b.astype(np.int64), c.astype(bool))
+            else:
+                rows = [table[(t0, int(k), int(j), int(i))] for k, j, i in self.space]
+                got = self._tc[tc] = (np.array([r[0] for r in rows], dtype=np.int64), np.array([r[1] for r in rows], dtype=np.int64),
+                                      np.array([r[2] for r in rows], dtype=bool))
         return got
 
     def stage(self, slot: int, file_steps: np.ndarray, at: int):
