@@ -361,3 +361,31 @@ def test_a_refused_metadata_layout_names_the_object_and_leaves_only_the_log(work
         cli.main([str(path), "-r", "-f", "--ingest", "host"])
     assert (out / "earlier_results.csv").read_text() == "kept\n" and (out / "results_vertical_levels").is_dir()
     shutil.rmtree(workdir / "LEC_Results")
+
+
+def test_chunk_table_answers_like_the_dict_it_replaces():
+    """hdf5_lite.ChunkTable keeps a large v1-B-tree chunk index as arrays (a month of hourly ERA5: 550,000 chunks, never turned into
+    Python tuples) and must answer like the {origin: (address, size, mask)} dict of the small-file paths: [], get, in, len, items, and
+    the vectorised lookup the device stager uses; unknown, unaligned and out-of-range origins are absent, not errors."""
+    h = hdf5_lite.H5File(os.path.join(FIX, "packed_unlimited_v18.nc"))
+    v = h.variables["t"]
+    table = h._chunks(v)
+    assert isinstance(table, hdf5_lite.ChunkTable)
+    as_dict = dict(table.items())
+    assert len(as_dict) == len(table) > 1 and set(table.keys()) == set(as_dict)
+    some = list(as_dict)[:: max(1, len(as_dict) // 7)]
+    for k in some:
+        assert table[k] == as_dict[k] and table.get(k) == as_dict[k] and k in table
+    a, b, c = table.lookup(np.array(some))
+    assert [tuple(int(x) for x in r) for r in zip(a, b, c)] == [as_dict[k] for k in some]
+    ch = table.chunk
+    bad = [(ch[0] * 10 ** 6, 0, 0, 0), (1 if ch[0] > 1 else -1, 0, 0, 0), (0, 0, 0, -ch[3])]
+    for k in bad:
+        assert table.get(k) is None and k not in table
+        with pytest.raises(KeyError):
+            table[k]
+    info = v.chunk_streams()
+    st = info["table"]
+    assert isinstance(st, hdf5_lite.ChunkTable) and len(st) == len(table)
+    k = some[-1]
+    assert st[k][0] == as_dict[k][0] + h.base and st[k][1] == as_dict[k][1] - (4 if info["fletcher32"] else 0) and isinstance(st[k][2], bool)
