@@ -48,7 +48,8 @@ extern "C" {
  * lec_chunk_scatter_args.src_bytes (the destination / payload ranges of every descriptor are bounds-checked on the device). */
 #define LEC_ABI_VERSION 9
 /* ABI 9 (round 5): lec_format_csv_rows (host): a per-level table as the text pandas writes for it, one call per table;
- * lec_rowstats_args.tm_d / tp_d: box-packed series of the moving framework (the struct grew by two pointers at its end); lec_dtdt. */
+ * lec_rowstats_args.tm_d / tp_d: box-packed series of the moving framework (the struct grew by two pointers at its end); lec_dtdt;
+ * lec_ingest_args.step_d / step_base: per-step gathers (the struct grew at its end). */
 
 /* number of fp64 values per (time, level, lat) row record written by lec_rowstats */
 #define LEC_NSTAT 32
@@ -247,6 +248,14 @@ typedef struct lec_ingest_args {
     int32_t decode_dtype;       /* LEC_F64 or LEC_F32: the precision the reference's decode gives this variable (see below) */
     void* out_d;                /* [nt][nl][ny][nx] */
     void* stream;
+    /* ABI 9: per-step gathers (a box-packed series of the moving framework: every output step holds another box, possibly of another
+     * source step).  NULL: output step t reads source step t with the maps as they are.  Else step_d[t] = {source step, latitude
+     * offset, longitude offset}: output step t reads source step step_d[t][0] - step_base of src_d through jmap_d[j + step_d[t][1]] and
+     * imap_d[i + step_d[t][2]] -- the maps must be long enough for the largest offset + ny / nx (lengthen them by repeating their last
+     * entry); nt counts OUTPUT steps, the source holds whatever steps the table names. */
+    const int32_t* step_d;      /* [nt][3] or NULL */
+    int32_t step_base;          /* the source step that src_d starts with */
+    int32_t reserved0;          /* must be 0 */
 } lec_ingest_args;
 
 /*

@@ -96,6 +96,7 @@ class IngestArgs(C.Structure):
         ("scale_factor", C.c_double), ("add_offset", C.c_double), ("fill_value", C.c_double), ("unit_scale", C.c_double),
         ("out_dtype", C.c_int32), ("decode_dtype", C.c_int32),
         ("out_d", C.c_void_p), ("stream", C.c_void_p),
+        ("step_d", C.c_void_p), ("step_base", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 

@@ -20,6 +20,7 @@ struct IngestParams {
     const int* kmap; const int* jmap; const int* imap;
     int swap, has_packing, has_fill, decode_f32;
     double scale, offset, fill, unit;
+    const int* step; int step_base;      // per-step gathers: {source step, latitude offset, longitude offset} per output step, or null
 };
 
 __device__ __forceinline__ int16_t load_elem(const int16_t* p, bool swap) {
@@ -51,11 +52,14 @@ __global__ void __launch_bounds__(256) lec_ingest_kernel(const IngestParams p) {
     const int j = row % p.ny;
     const int k = (row / p.ny) % p.nl;
     const int t = row / (p.ny * p.nl);
-    const TSRC* __restrict__ src = (const TSRC*)p.src + (((size_t)t * p.nl_in + p.kmap[k]) * p.ny_in + p.jmap[j]) * (size_t)p.nx_in;
+    // (a box-packed series: this output step's box may start anywhere in the maps and come from another source step)
+    const int ts = p.step ? p.step[3 * t] - p.step_base : t, oj = p.step ? p.step[3 * t + 1] : 0, oi = p.step ? p.step[3 * t + 2] : 0;
+    const TSRC* __restrict__ src = (const TSRC*)p.src + (((size_t)ts * p.nl_in + p.kmap[k]) * p.ny_in + p.jmap[j + oj]) * (size_t)p.nx_in;
     TOUT* __restrict__ out = (TOUT*)p.out + (size_t)row * p.nx;
+    const int* __restrict__ imap = p.imap + oi;
     const bool swap = p.swap != 0;
     for (int i = threadIdx.x; i < p.nx; i += blockDim.x) {
-        const TSRC raw = load_elem(src + p.imap[i], swap);
+        const TSRC raw = load_elem(src + imap[i], swap);
         const bool is_fill = p.has_fill && ((double)raw == p.fill);
         TOUT o;
         if (!p.decode_f32) {
@@ -97,6 +101,8 @@ extern "C" int lec_ingest(const lec_ingest_args* a) {
     p.src = a->src_d; p.out = a->out_d;
     p.nt = a->nt; p.nl_in = a->nl_in; p.ny_in = a->ny_in; p.nx_in = a->nx_in; p.nl = a->nl; p.ny = a->ny; p.nx = a->nx;
     p.kmap = a->kmap_d; p.jmap = a->jmap_d; p.imap = a->imap_d;
+    if (a->reserved0) return lec_set_error(LEC_ERR_ARG, "lec_ingest: reserved0 must be 0");
+    p.step = a->step_d; p.step_base = a->step_base;
     if (a->decode_dtype != LEC_F64 && a->decode_dtype != LEC_F32) return lec_set_error(LEC_ERR_ARG, "lec_ingest: decode_dtype must be LEC_F64 or LEC_F32");
     if (a->decode_dtype == LEC_F32 && (a->src_dtype == LEC_F64 || a->src_dtype == LEC_I32))
         return lec_set_error(LEC_ERR_ARG, "lec_ingest: float64 and int32 data do not decode to float32");

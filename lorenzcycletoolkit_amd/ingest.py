@@ -604,7 +604,10 @@ def storage_dtypes(rvars) -> tuple:
     return dec, np.result_type(*dec.values())
 
 
-def _ingest_call(lib, v: ds.RawVariable, src_ptr: int, nt: int, geom, maps, unit: float, decode_dtype, out_dtype, out_ptr: int, stream):
+def _ingest_call(lib, v: ds.RawVariable, src_ptr: int, nt: int, geom, maps, unit: float, decode_dtype, out_dtype, out_ptr: int, stream,
+                 step: Optional[torch.Tensor] = None, step_base: int = 0):
+    """``step``: int32 [nt, 3] on the device -- per output step {source step, latitude offset, longitude offset} into the maps
+    (``lec_ingest_args.step_d``: a box-packed series); ``step_base``: the source step ``src_ptr`` starts with."""
     nl_in, ny_in, nx_in, nl, ny, nx = geom
     kmap, jmap, imap = maps
     ga = _lib.IngestArgs(
@@ -615,7 +618,8 @@ def _ingest_call(lib, v: ds.RawVariable, src_ptr: int, nt: int, geom, maps, unit
         scale_factor=1.0 if v.scale_factor is None else v.scale_factor, add_offset=0.0 if v.add_offset is None else v.add_offset,
         fill_value=0.0 if v.fill_value is None else v.fill_value, unit_scale=float(unit),
         out_dtype=_lec_code(out_dtype), decode_dtype=_lec_code(decode_dtype),
-        out_d=C.c_void_p(out_ptr), stream=C.c_void_p(stream.cuda_stream))
+        out_d=C.c_void_p(out_ptr), stream=C.c_void_p(stream.cuda_stream),
+        step_d=None if step is None else C.c_void_p(step.data_ptr()), step_base=int(step_base), reserved0=0)
     _lib.check(lib.lec_ingest(C.byref(ga)), "lec_ingest")
 
 
@@ -790,6 +794,12 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
         cubes = {k: torch.empty((dec_steps, nl, nyp, nxp), dtype=out_dtype, device=dev) for k in list(keys.values()) + ["tm", "tp"]}
         dtdt = torch.empty((dec_steps, nl, nyp, nxp), dtype=torch.float64, device=dev) if common == np.float64 else None
         maps = (up(kmap_rel), up(np.concatenate([jmap_rel, np.repeat(jmap_rel[-1:], nyp)])), up(np.concatenate([imap_rel, np.repeat(imap_rel[-1:], nxp)])))
+        # per output step {source step, where its box starts in the latitude / longitude maps}: for the fields, and for T of the two
+        # neighbouring steps on the SAME box (the step itself where the series ends: its coefficient is 0).  Uploaded once, like the
+        # d/dt coefficients: nothing inside the chunk loop makes the host wait for the GPU.
+        org = np.array([(b[2], b[0]) for b in boxes], dtype=np.int64)
+        steps_of = lambda shift: up(np.column_stack([np.clip(np.arange(nt) + shift, 0, nt - 1), org]))
+        step_tab = {0: steps_of(0), -1: steps_of(-1), 1: steps_of(1)}
     else:
         dec_steps = min(chunk_steps, max(4, (1 << 30) // (nl * ny * nx * esize)))
         cubes = {keys[r]: torch.empty((dec_steps + 2, nl, ny, nx), dtype=out_dtype, device=dev) for r in roles}
@@ -886,28 +896,23 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
                             rows_out=rows[: s1 - s0], per_step_boxes=per_step_boxes)
             engine.level_stage(rows[: s1 - s0], part, levraw[s0 - t0: s1 - t0], phi_scale=phi_scale)
         for s0 in (range(c0, c1, dec_steps) if packed else ()):
-            # the box-packed series: per step, one gather per field of that step's box alone (the maps entered at the box's south-west
-            # corner), T also from the two neighbouring steps (the step itself where the series ends: its coefficient is 0)
+            # the box-packed series: every output step holds that step's box alone (lec_ingest enters the maps at the box's south-west
+            # corner, step by step: `step_tab`), T also from the two neighbouring steps' raw slices
             s1 = min(s0 + dec_steps, c1)
             geom = (nl_in, ny_in, nx_in, nl, nyp, nxp)
+            n = s1 - s0
             with torch.cuda.device(dev):
-                for st in range(s0, s1):
-                    iw, _ie, js, _jn = boxes[st]
-                    mp = (maps[0], maps[1][js:], maps[2][iw:])
-                    for r in roles:
-                        unit = 1.0 if r == geo_role else ds.field_scale(variable_list_df, r)
-                        srcs = [(keys[r], st)] + ([("tm", max(st - 1, 0)), ("tp", min(st + 1, nt - 1))] if r == "Air Temperature" else [])
-                        for key, ft in srcs:
-                            _ingest_call(lib, rvars[r], stagers[r].raw_dev[slot][ft - h0].data_ptr(), 1, geom, mp, unit, decode[r], common,
-                                         cubes[key][st - s0].data_ptr(), compute)
+                for r in roles:                 # ONE gather per plane and sub-chunk: every output step's box through lec_ingest's per-step origins
+                    unit = 1.0 if r == geo_role else ds.field_scale(variable_list_df, r)
+                    for key, shift in [(keys[r], 0)] + ([("tm", -1), ("tp", 1)] if r == "Air Temperature" else []):
+                        _ingest_call(lib, rvars[r], stagers[r].raw_dev[slot][0].data_ptr(), n, geom, maps, unit, decode[r], common,
+                                     cubes[key][0].data_ptr(), compute, step=step_tab[shift][s0:s1], step_base=h0)
                 if keep is not None:            # the diagnostics' level of u, v, Phi over the whole crop: one gather of that level per field
                     kmap1 = maps[0][k_keep: k_keep + 1]
                     for r, k in (("Eastward Wind Component", "u"), ("Northward Wind Component", "v"), (geo_role, "geopt")):
                         unit = 1.0 if r == geo_role else ds.field_scale(variable_list_df, r)
-                        for st in range(s0, s1):
-                            _ingest_call(lib, rvars[r], stagers[r].raw_dev[slot][st - h0].data_ptr(), 1, (nl_in, ny_in, nx_in, 1, ny, nx),
-                                         (kmap1, maps[1], maps[2]), unit, decode[r], common, keep[k][st - t0].data_ptr(), compute)
-            n = s1 - s0
+                        _ingest_call(lib, rvars[r], stagers[r].raw_dev[slot][s0 - h0].data_ptr(), n, (nl_in, ny_in, nx_in, 1, ny, nx),
+                                     (kmap1, maps[1], maps[2]), unit, decode[r], common, keep[k][s0 - t0].data_ptr(), compute)
             f = {k: t[:n] for k, t in cubes.items()}
             part = own_boxes.part(s0 - t0, s1 - t0)
             if dtdt is not None:
