@@ -252,7 +252,8 @@ typedef struct lec_ingest_args {
      * source step).  NULL: output step t reads source step t with the maps as they are.  Else step_d[t] = {source step, latitude
      * offset, longitude offset}: output step t reads source step step_d[t][0] - step_base of src_d through jmap_d[j + step_d[t][1]] and
      * imap_d[i + step_d[t][2]] -- the maps must be long enough for the largest offset + ny / nx (lengthen them by repeating their last
-     * entry); nt counts OUTPUT steps, the source holds whatever steps the table names. */
+     * entry; lec_check_maps scans ny / nx entries: give it the maps' full lengths); nt counts OUTPUT steps, the source holds whatever
+     * steps the table names. */
     const int32_t* step_d;      /* [nt][3] or NULL */
     int32_t step_base;          /* the source step that src_d starts with */
     int32_t reserved0;          /* must be 0 */

@@ -651,14 +651,37 @@ int launch_tiles(RowParams p, bool uniform, int mode, int tg, hipStream_t st) {
 
 // ---- dT/dt of a box-packed series as a cube (include/lec_hip.h: lec_dtdt): the kernel above's own per-point expression
 namespace {
-template <typename TIN>
+// a plain stream over the three cubes taken as ONE run of n_steps x step_elems elements: 3 reads + 1 fp64 write per point.  PAIRS: a
+// thread takes two neighbouring elements with 16-byte (fp32: 8-byte) accesses; they may belong to two steps (an odd step size), so each
+// element looks its own step's coefficients up
+template <typename TIN, bool PAIRS>
 __global__ void __launch_bounds__(256) lec_dtdt_kernel(const TIN* __restrict__ tm, const TIN* __restrict__ t, const TIN* __restrict__ tp,
-                                                       const double* __restrict__ tcoef, double* __restrict__ out, long long step_elems) {
-    const int s = blockIdx.y;
-    const double ta = tcoef[3 * s], tb = tcoef[3 * s + 1], tc = tcoef[3 * s + 2];
-    const size_t base = (size_t)s * (size_t)step_elems;
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < step_elems; e += (long long)gridDim.x * 256)
-        out[base + e] = stencil3(ta, (double)tm[base + e], tc, (double)tp[base + e], tb, (double)t[base + e]);
+                                                       const double* __restrict__ tcoef, double* __restrict__ out, long long step_elems, long long total) {
+    const long long stride = (long long)gridDim.x * 256;
+    if (PAIRS) {
+        typedef TIN in2_t __attribute__((ext_vector_type(2)));
+        const in2_t* m2 = reinterpret_cast<const in2_t*>(tm);
+        const in2_t* c2 = reinterpret_cast<const in2_t*>(t);
+        const in2_t* p2 = reinterpret_cast<const in2_t*>(tp);
+        dbl2_t* o2 = reinterpret_cast<dbl2_t*>(out);
+        for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < total / 2; g += stride) {
+            const long long s0 = (2 * g) / step_elems, s1 = (2 * g + 1) / step_elems;
+            const in2_t a = __builtin_nontemporal_load(m2 + g), b = __builtin_nontemporal_load(c2 + g), c = __builtin_nontemporal_load(p2 + g);
+            dbl2_t r;
+            r.x = stencil3(tcoef[3 * s0], (double)a.x, tcoef[3 * s0 + 2], (double)c.x, tcoef[3 * s0 + 1], (double)b.x);
+            r.y = stencil3(tcoef[3 * s1], (double)a.y, tcoef[3 * s1 + 2], (double)c.y, tcoef[3 * s1 + 1], (double)b.y);
+            o2[g] = r;
+        }
+        if ((total & 1) && blockIdx.x == 0 && threadIdx.x == 0) {      // the last element of an odd run
+            const long long e = total - 1, s = e / step_elems;
+            out[e] = stencil3(tcoef[3 * s], (double)tm[e], tcoef[3 * s + 2], (double)tp[e], tcoef[3 * s + 1], (double)t[e]);
+        }
+    } else {
+        for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += stride) {
+            const long long s = e / step_elems;
+            out[e] = stencil3(tcoef[3 * s], (double)tm[e], tcoef[3 * s + 2], (double)tp[e], tcoef[3 * s + 1], (double)t[e]);
+        }
+    }
 }
 }  // namespace
 
@@ -667,13 +690,16 @@ extern "C" int lec_dtdt(const lec_dtdt_args* a) {
     if (!a->tm_d || !a->t_d || !a->tp_d || !a->tcoef_d || !a->out_d) return lec_set_error(LEC_ERR_ARG, "lec_dtdt: null pointer argument");
     if (a->dtype != LEC_F64 && a->dtype != LEC_F32) return lec_set_error(LEC_ERR_ARG, "lec_dtdt: dtype must be LEC_F64 or LEC_F32");
     if (a->n_steps < 1 || a->n_steps > 65535 || a->step_elems < 1) return lec_set_error(LEC_ERR_ARG, "lec_dtdt: needs 1 <= n_steps <= 65535 and step_elems >= 1");
-    const long long want = (a->step_elems + 255) / 256;
-    dim3 grid((unsigned)(want < 64 ? want : 64), (unsigned)a->n_steps), block(256);
+    const size_t esz = a->dtype == LEC_F64 ? 8 : 4;
+    const bool pairs = (((uintptr_t)a->tm_d | (uintptr_t)a->t_d | (uintptr_t)a->tp_d) % (2 * esz)) == 0 && ((uintptr_t)a->out_d % 16) == 0;
+    const long long total = (long long)a->n_steps * a->step_elems;
+    const long long want = ((pairs ? (total + 1) / 2 : total) + 255) / 256;
+    dim3 grid((unsigned)(want < 65536 ? want : 65536)), block(256);
     hipStream_t st = (hipStream_t)a->stream;
-    if (a->dtype == LEC_F64)
-        hipLaunchKernelGGL(lec_dtdt_kernel<double>, grid, block, 0, st, (const double*)a->tm_d, (const double*)a->t_d, (const double*)a->tp_d, a->tcoef_d, a->out_d, (long long)a->step_elems);
-    else
-        hipLaunchKernelGGL(lec_dtdt_kernel<float>, grid, block, 0, st, (const float*)a->tm_d, (const float*)a->t_d, (const float*)a->tp_d, a->tcoef_d, a->out_d, (long long)a->step_elems);
+#define LEC_DTDT(T, P) hipLaunchKernelGGL((lec_dtdt_kernel<T, P>), grid, block, 0, st, (const T*)a->tm_d, (const T*)a->t_d, (const T*)a->tp_d, a->tcoef_d, a->out_d, (long long)a->step_elems, total)
+    if (a->dtype == LEC_F64) { if (pairs) LEC_DTDT(double, true); else LEC_DTDT(double, false); }
+    else { if (pairs) LEC_DTDT(float, true); else LEC_DTDT(float, false); }
+#undef LEC_DTDT
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return lec_set_error(LEC_ERR_LAUNCH, hipGetErrorString(e));
     return LEC_OK;
