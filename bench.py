@@ -21,7 +21,17 @@ Scaling modes.
                                   beside it).
 
 Either way the data path has no collective: one all_reduce of the [28, L] NaN-level mask and one
-all_gather of the per-time-step results per pass.  Prints ONE JSON line on rank 0.
+gather of the per-time-step results per pass.  Prints ONE JSON line on rank 0.
+
+The default N > 1 run (``--gpus N`` and nothing else: what the driver passes) also carries BASELINE configs 4 and 5: after the
+weak-scaling headline and before the CPU leg the same process group runs two short strong-scaling legs -- the fixed box at
+T = 2048 (chunked) and the moving box at T = 4096 -- and attaches them as ``config.strong_scaling`` (``--no-strong-legs`` for A/B runs).
+
+What a ``--moving`` line times.  The reference clocks its whole call, dT/dt and the per-step slice included
+(lorenzcycletoolkit.py:173-199, box_data.py:297-310).  With ``--moving-layout packed`` (the layout every ``-t`` path of the
+product hands stage 1) those two are the PRODUCER's work: ``value`` is the consumer's rate (stage 1 + stage 2 + collectives on the
+packed series), ``config.producer_ms`` the gathers and ``lec_dtdt`` timed on HIP events of their own, ``config.value_incl_producer``
+the rate with both inside.  ``--moving-layout cube`` (rounds 1-4) slices by index and forms dT/dt per point inside the kernel.
 """
 import argparse
 import json
@@ -69,6 +79,13 @@ def parse_args(argv=None):
     ap.add_argument("--write-digest", action="store_true", help="N = 1 only: add this run's series digest to --digest-file")
     ap.add_argument("--nonuniform-lon", action="store_true", help="stretched longitudes (a Gaussian / regridded-MPAS style axis): the kernels "
                     "then carry per-column trapezoid weights and d/dlon coefficient tables instead of the even-spacing fast path")
+    ap.add_argument("--no-strong-legs", action="store_true", help="N > 1 default run: leave out the two strong-scaling legs (BASELINE configs 4 / 5) "
+                    "that otherwise ride in config.strong_scaling")
+    ap.add_argument("--leg-timesteps", type=str, default="2048,4096", help="global series lengths of the two strong-scaling legs (fixed box, "
+                    "moving box); BASELINE configs 4 / 5 are 2048 / 4096 (rehearsals on one GPU use shorter ones)")
+    ap.add_argument("--leg-steps", type=int, default=2, help="timed passes per strong-scaling leg (after one warm-up pass)")
+    ap.add_argument("--n1-file", type=str, default=os.path.join(ROOT, "profiles", "strong_scaling_n1.json"),
+                    help="N = 1 values of the strong-scaling configurations (by layout, with the kernel sources' digest): what speedup_vs_n1 divides by")
     ap.add_argument("--ny", type=int, default=721)
     ap.add_argument("--nx", type=int, default=1440)
     return ap.parse_args(argv)
@@ -173,30 +190,62 @@ def _scale_err(a, r):
     return float(np.max(np.abs(a[ok] - r[ok])) / den) if den > 0 else float(np.max(np.abs(a[ok] - r[ok])))
 
 
-def cpu_baseline_and_parity(kind, eng, held, lat, lon, level, time_s, device):
-    """The CPU leg of the N = 1 line.  The oracle evaluates the FIRST `nt` TIME STEPS OF THE RESIDENT SYNTHETIC CUBE -- the data the
-    GPU has just been timed on -- copied to the host, on the box without the polar rows (the reference divides by
-    cos 90 deg there); the engine runs the same sub-cube and every one of the 16 terms and 21 level tables is compared
-    (`parity`).  The oracle's wall time on exactly that call is the one-thread CPU baseline (`cpu_baseline`, kind "port").
+_TERMS16 = ("Az", "Ae", "Kz", "Ke", "Cz", "Ca", "Ck", "Ce", "BAz", "BAe", "BKz", "BKe", "BΦZ", "BΦE", "Gz", "Ge")      # all 16 (the results
+                                                                                                                       # CSV of lec_fixed drops the two BPhi)
+
+def _compare_with_oracle(got_s, got_l, ref_s, ref_l, n):
+    """Worst |engine - oracle| / max |oracle| over the 16 terms and over the level tables, first `n` steps of both."""
+    worst, worst_term = 0.0, ""
+    for name in _TERMS16:
+        e = _scale_err(np.asarray(got_s[name])[:n], np.asarray(ref_s[name])[:n])
+        if e > worst:
+            worst, worst_term = e, name
+    lworst, lworst_term = 0.0, ""
+    for name, ref in ref_l.items():
+        ref = np.asarray(ref, dtype=np.float64)
+        got = np.asarray(got_l[name])[:n]
+        if ref.ndim == 1:
+            ref = np.broadcast_to(ref, got.shape)
+        e = _scale_err(got, ref[:n])
+        if e > lworst:
+            lworst, lworst_term = e, name
+    return {"worst_rel_to_scale": worst, "term": worst_term, "levels_worst_rel_to_scale": lworst, "levels_term": lworst_term,
+            "steps": int(n), "terms_compared": len(_TERMS16), "level_tables_compared": len(ref_l),
+            "checker": "oracle/lec_oracle.py (NumPy fp64 restatement of the reference's un-factored formulas)", "tolerance": 1e-9,
+            "ok": bool(worst <= 1e-9 and lworst <= 1e-9)}
+
+
+def _host_counts():
+    ncpu = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = ncpu
+    return ncpu, usable
+
+
+def cpu_leg_steps(kind):
+    """Time steps of the fixed-box CPU leg (each 5.4 s of one host thread at 37 x 721 x 1440)."""
+    return 3 if kind in ("full", "single") else 2
+
+
+def cpu_baseline_and_parity(kind, eng, sub, lat, lon, level, ts, device, data_note):
+    """The CPU leg of a fixed-box line.  The oracle evaluates `sub` -- the FIRST TIME STEPS OF THE SYNTHETIC CUBE THE GPU HAS JUST BEEN
+    TIMED ON (device tensors [nt, nl, ny, nx], kept back from the resident cube or the first chunk) -- copied to the host, on the box
+    without the polar rows (the reference divides by cos 90 deg there); the engine runs the same sub-cube and every one of
+    the 16 terms and 21 level tables is compared (`parity`).  The oracle's wall time on exactly that call is the one-thread CPU
+    baseline (`cpu_baseline`, kind "port").
     kind "full": nt = 3 at the benchmark's size, two repetitions (the first also yields the parity), plus a best-effort all-cores figure;
     kind "quick" (tests): nt = 2, one repetition;
     kind "single" (what "full" becomes on rank 0 of an N > 1 run, the peers waiting in the closing barrier): nt = 3, one repetition, no
     all-cores figure -- the other ranks' processes occupy cores and the N = 1 line of the same scaling run carries it."""
     import multiprocessing as mp
     import torch
-    from oracle import lec_oracle as o
-    ncpu = os.cpu_count() or 1
-    try:
-        usable = len(os.sched_getaffinity(0))
-    except AttributeError:
-        usable = ncpu
-    h0, h1, f = held[:3]
-    nt = min(3 if kind in ("full", "single") else 2, h1 - h0)
-    ny, nx = lat.size, lon.size
+    ncpu, usable = _host_counts()
+    nt = int(sub["tair"].shape[0])
+    nx = lon.size
     south, north = (lat[1], lat[-2]) if abs(lat[0]) >= 90.0 - 1e-9 else (lat[0], lat[-1])
     limits = (lon[0], lon[-1], south, north)
-    sub = {k: (None if v is None else v[:nt]) for k, v in f.items()}
-    ts = time_s[h0:h0 + nt]
     box = eng.box_from_limits(*limits)
     res = eng.compute(sub["tair"], sub["u"], sub["v"], sub["omega"], sub["geopt"], [box], time_s=ts)
     torch.cuda.synchronize(device)
@@ -206,30 +255,13 @@ def cpu_baseline_and_parity(kind, eng, held, lat, lon, level, time_s, device):
     for rep in range(2 if kind == "full" else 1):
         dt, ref_s, ref_l = _oracle_run(host, lat, lon, level, ts, limits)
         reps.append(dt)
-    worst, worst_term = 0.0, ""
-    names = ("Az", "Ae", "Kz", "Ke", "Cz", "Ca", "Ck", "Ce", "BAz", "BAe", "BKz", "BKe", "BΦZ", "BΦE", "Gz", "Ge")      # all 16 (the results
-    for name in names:                                                                                                  # CSV of lec_fixed drops the two BPhi)
-        e = _scale_err(got_s[name], ref_s[name])
-        if e > worst:
-            worst, worst_term = e, name
-    lworst, lworst_term = 0.0, ""
-    for name, ref in ref_l.items():
-        ref = np.asarray(ref, dtype=np.float64)
-        if ref.ndim == 1:
-            ref = np.broadcast_to(ref, got_l[name].shape)
-        e = _scale_err(got_l[name], ref)
-        if e > lworst:
-            lworst, lworst_term = e, name
-    parity = {"worst_rel_to_scale": worst, "term": worst_term, "levels_worst_rel_to_scale": lworst, "levels_term": lworst_term,
-              "steps": nt, "terms_compared": len(names), "level_tables_compared": len(ref_l),
-              "box": f"lon [{limits[0]}, {limits[1]}] lat [{limits[2]}, {limits[3]}] ({box[3] - box[2] + 1} x {box[1] - box[0] + 1} points)",
-              "data": "the first %d time steps of the resident synthetic cube the GPU was timed on, copied to the host" % nt,
-              "checker": "oracle/lec_oracle.py (NumPy fp64 restatement of the reference's un-factored formulas)", "tolerance": 1e-9,
-              "ok": bool(worst <= 1e-9 and lworst <= 1e-9)}
+    parity = _compare_with_oracle(got_s, got_l, ref_s, ref_l, nt)
+    parity.update(box=f"lon [{limits[0]}, {limits[1]}] lat [{limits[2]}, {limits[3]}] ({box[3] - box[2] + 1} x {box[1] - box[0] + 1} points)",
+                  data=data_note % nt)
     best = float(np.median(reps))
     out = {"value": nt / best, "unit": "timesteps/s", "cores": 1, "kind": "port", "host_cpu_count": ncpu, "usable_cores": usable,
            "seconds_per_timestep": best / nt,
-           "sample": f"NumPy fp64 oracle (the reference's eager op order), 1 thread, {nt} time steps of the resident cube at 37x{box[3] - box[2] + 1}x{nx} "
+           "sample": f"NumPy fp64 oracle (the reference's eager op order), 1 thread, {nt} time steps of the cube the GPU was timed on at 37x{box[3] - box[2] + 1}x{nx} "
                      f"(box without the polar rows), {len(reps)} repetition(s): {', '.join(f'{r:.1f}' for r in reps)} s, median; the same call gives `parity`"}
     if kind == "full":
         workers = max(1, min(usable, 32))
@@ -247,47 +279,136 @@ def cpu_baseline_and_parity(kind, eng, held, lat, lon, level, time_s, device):
     return out, parity
 
 
+def cpu_leg_steps_moving(kind, t_local):
+    """Boxes of the moving CPU leg: a 61 x 61 x 37 box takes the oracle tens of milliseconds, so the full leg takes 32 of them."""
+    return max(1, min(32 if kind == "full" else 3, t_local))
+
+
+def cpu_baseline_and_parity_moving(kind, crop, limits, lat, lon, level, ts, got_s, got_l, n):
+    """The CPU leg of a --moving line.  `crop`: the first n (+ 1: the time neighbour of the last one) steps of the track-extent crop
+    rank 0's series was produced from (device tensors), `limits`: the boxes' (west, east, south, north) per held step.  The oracle
+    runs the reference's moving framework on it -- dT/dt over the crop's time axis INSIDE the clock, as the reference's own clock has
+    it (lorenzcycletoolkit.py:173,184-186), then one BoxData per step (lec_moving_framework.py:639-745) -- on one thread; `got_s` /
+    `got_l`: the 16 terms and 21 tables of the same steps as the TIMED GPU pass delivered them (the packed or the cube layout,
+    whichever was timed).  The held steps beyond `n` exist only so that step n - 1 is differentiated as the series differentiates it."""
+    from oracle import lec_oracle as o
+    ncpu, usable = _host_counts()
+    held = int(crop["tair"].shape[0])
+    host = {k: np.ascontiguousarray(v.double().cpu().numpy()) for k, v in crop.items()}
+    dom = o.Domain(host["tair"], host["u"], host["v"], host["omega"], host["geopt"], lat, lon, level, np.asarray(ts[:held], dtype=np.float64))
+    reps = []
+    for rep in range(2 if kind == "full" else 1):
+        t0 = time.perf_counter()
+        with np.errstate(all="ignore"):
+            ref_s, ref_l = o.lec_moving(dom, limits[:held], residuals=False)
+        reps.append(time.perf_counter() - t0)
+    parity = _compare_with_oracle(got_s, got_l, ref_s, ref_l, n)
+    parity.update(box="one 15 x 15 degree box (61 x 61 points) per time step, on the synthetic track",
+                  data=f"the first {n} time steps of the track-extent crop the timed series was produced from, copied to the host "
+                       f"({held} steps held: the last one's time neighbour)", compared_with="the records of the timed GPU pass")
+    best = float(np.median(reps))
+    out = {"value": held / best, "unit": "timesteps/s", "cores": 1, "kind": "port", "host_cpu_count": ncpu, "usable_cores": usable,
+           "seconds_per_timestep": best / held,
+           "sample": f"NumPy fp64 oracle of the moving framework (dT/dt over the crop's time axis, then one box per step: the reference's eager op "
+                     f"order and what its own clock spans), 1 thread, {held} time steps of the 37x{lat.size}x{lon.size} crop with 61x61 boxes, "
+                     f"{len(reps)} repetition(s): {', '.join(f'{r:.2f}' for r in reps)} s, median; the same call gives `parity`"}
+    return out, parity
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # one rank
 # ---------------------------------------------------------------------------------------------------------------------
-def run_rank(args):
+class RankContext:
+    """This process's place in the job: rank, GPU, process group (created once; the headline and the strong-scaling legs share it)."""
+
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.backend = os.environ.get("LEC_DIST_BACKEND", "nccl")   # nccl == RCCL on ROCm; gloo only rehearses the N > 1 path on one GPU
+        ndev = torch.cuda.device_count()
+        if ndev < 1:
+            raise SystemExit("bench.py: no GPU visible: the HIP path is the only path")
+        if self.backend == "nccl" and self.world > ndev:
+            raise SystemExit(f"bench.py: {self.world} ranks but {ndev} GPU(s): RCCL needs one GPU per rank")
+        self.local_rank = local_rank % ndev
+        torch.cuda.set_device(self.local_rank)
+        self.device = torch.device("cuda", self.local_rank)
+        self.force_dist = bool(args.force_dist)
+        self.use_dist = self.world > 1 or self.force_dist      # --force-dist: the N > 1 code path (process group, collectives) with ONE rank
+        self.stdout_fd = None
+        if self.use_dist:
+            # RCCL and gloo print their banners ("RCCL version : ...", "[Gloo] Rank 0 is connected to ...") on STDOUT: the contract is ONE
+            # JSON line there, so everything the libraries write goes to stderr until the line itself is printed
+            sys.stdout.flush()
+            self.stdout_fd = os.dup(1)
+            os.dup2(2, 1)
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.world == 1:
+                os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            dist.init_process_group(backend=self.backend, rank=self.rank, world_size=self.world)      # the rank's GPU is already current
+        # who is really there: ranks the backend connected, the GPU each one drives (N > 1 runs happen on nodes nobody watches)
+        from lorenzcycletoolkit_amd.parallel import ranks_and_devices
+        self.who = ranks_and_devices(self.device) if self.use_dist else None
+        if self.who is not None and (self.who["ranks_seen"] != self.world or (self.backend == "nccl" and not self.who["devices_distinct"])):
+            raise SystemExit(f"bench.py: rank {self.rank}: the process group is not what was asked for: {json.dumps(self.who)}")
+
+    def barrier(self):
+        import torch.distributed as dist
+        if self.backend == "nccl":
+            dist.barrier(device_ids=[self.local_rank])
+        else:
+            dist.barrier()
+
+    def sync(self, with_barrier=True):
+        import torch
+        if self.use_dist and with_barrier:
+            self.barrier()
+        torch.cuda.synchronize()
+
+    def reduce_max(self, values):
+        """Element-wise maximum over the ranks of a short list of floats."""
+        import torch
+        import torch.distributed as dist
+        if not self.use_dist:
+            return [float(v) for v in values]
+        t = torch.tensor(list(values), dtype=torch.float64, device=self.device)
+        if self.backend == "gloo":
+            t = t.cpu()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(v) for v in t]
+
+    def print_line(self, out):
+        if self.stdout_fd is not None:
+            sys.stdout.flush()
+            os.dup2(self.stdout_fd, 1)
+        print(json.dumps(out, ensure_ascii=False), flush=True)
+        if self.stdout_fd is not None:
+            os.dup2(2, 1)
+
+
+def n1_key(args, T_global, packed):
+    """Key of a strong-scaling configuration in --n1-file: the series' layout is part of it (a packed and a cube series are different work)."""
+    kind = ("moving_" + ("packed" if packed else "cube")) if args.moving else "fixed"
+    return f"{kind}_{args.storage}_{'noq' if args.no_q else 'all'}_T{T_global}"
+
+
+def measure(args, ctx, cpu_kind="none"):
+    """One bench configuration on the job's process group: generation, warm-up, the timed passes, the instrumented passes and the
+    self-checks.  Returns (out, cpu_leg): rank 0's JSON object (None elsewhere) and -- rank 0, cpu_kind != "none" -- a callable
+    that runs the CPU leg and fills out["cpu_baseline"] / out["parity"]; it holds only the few time steps it needs, so the caller
+    may run other configurations in between (the strong-scaling legs of the default N > 1 line)."""
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    backend = os.environ.get("LEC_DIST_BACKEND", "nccl")   # nccl == RCCL on ROCm; gloo only rehearses the N > 1 path on one GPU
-    ndev = torch.cuda.device_count()
-    if ndev < 1:
-        raise SystemExit("bench.py: no GPU visible: the HIP path is the only path")
-    if backend == "nccl" and world > ndev:
-        raise SystemExit(f"bench.py: {world} ranks but {ndev} GPU(s): RCCL needs one GPU per rank")
-    local_rank = local_rank % ndev
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    use_dist = world > 1 or args.force_dist          # --force-dist: the N > 1 code path (process group, collectives) with ONE rank
-    stdout_fd = None
-    if use_dist:
-        # RCCL and gloo print their banners ("RCCL version : ...", "[Gloo] Rank 0 is connected to ...") on STDOUT: the contract is ONE
-        # JSON line there, so everything the libraries write goes to stderr until the line itself is printed
-        sys.stdout.flush()
-        stdout_fd = os.dup(1)
-        os.dup2(2, 1)
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if world == 1:
-            os.environ.setdefault("MASTER_PORT", str(_free_port()))
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)      # the rank's GPU is already current
-
     from lorenzcycletoolkit_amd.engine import LECEngine
-    from lorenzcycletoolkit_amd.parallel import (SeriesGatherer, halo_range, merge_dropmask, ranks_and_devices, record_checksums,
-                                                 shard_range, verify_gather)
+    from lorenzcycletoolkit_amd.parallel import (SeriesGatherer, halo_range, merge_dropmask, record_checksums, shard_range, verify_gather)
     from lorenzcycletoolkit_amd.synthetic import era5_like_levels, synthetic_cube
 
-    # who is really there: ranks the backend connected, the GPU each one drives (N > 1 runs happen on nodes nobody watches)
-    who = ranks_and_devices(device) if use_dist else None
-    if who is not None and (who["ranks_seen"] != world or (backend == "nccl" and not who["devices_distinct"])):
-        raise SystemExit(f"bench.py: rank {rank}: the process group is not what was asked for: {json.dumps(who)}")
+    world, rank, device, backend, use_dist, who = ctx.world, ctx.rank, ctx.device, ctx.backend, ctx.use_dist, ctx.who
+    barrier, sync = ctx.barrier, ctx.sync
 
     level = era5_like_levels()
     lat = np.linspace(-90.0, 90.0, args.ny)
@@ -315,13 +436,17 @@ def run_rank(args):
     eng = LECEngine(lat, lon, level, device=device)
     box = eng.box_from_limits(lon[0], lon[-1], lat[0], lat[-1])
 
-    def boxes_of(a, b):
-        if not args.moving:
-            return [box]
+    def limits_of(a, b):
+        """(west, east, south, north) of the moving box at the global steps [a, b): 15 x 15 degrees about the synthetic track."""
         tg = np.arange(a, b)
         clat = -37.5 + 12.0 * np.sin(2 * np.pi * tg / 400.0)
         clon = -50.0 + 22.0 * np.cos(2 * np.pi * tg / 700.0)
-        return [eng.box_from_limits(lo - 7.5, lo + 7.5, la - 7.5, la + 7.5) for la, lo in zip(clat, clon)]
+        return [(lo - 7.5, lo + 7.5, la - 7.5, la + 7.5) for la, lo in zip(clat, clon)]
+
+    def boxes_of(a, b):
+        if not args.moving:
+            return [box]
+        return [eng.box_from_limits(*lim) for lim in limits_of(a, b)]
 
     # chunks of the shard: resident (one chunk, generated before the timed region) or streamed through HBM
     step_bytes = 5 * nl * lat.size * lon.size * esz
@@ -335,14 +460,28 @@ def run_rank(args):
     chunk_boxes = {c: boxes_of(*c) for c in chunks}      # host work (nearest-grid-point boxes of a chunk's steps): once, outside the timed region
     all_boxes = [bx for c in chunks for bx in chunk_boxes[c]] if args.moving else [box]
     nyb_max = max(b[3] - b[2] + 1 for b in all_boxes) if args.moving else lat.size
+    nxb_max = max(b[1] - b[0] + 1 for b in all_boxes) if args.moving else lon.size
     packed = bool(args.moving and args.moving_layout == "packed" and with_q)
     if args.moving:        # thousands of boxes: build and upload their tables once (PreparedBoxes), not at every call
         chunk_boxes = {c: eng.prepare_boxes(bx, nyb_min=nyb_max, packed=packed) for c, bx in chunk_boxes.items()}
         all_boxes = eng.prepare_boxes(all_boxes, nyb_min=nyb_max, packed=packed)
     tc_all = eng.time_coefs_device(time_s) if with_q else None      # d/dt coefficients of the whole axis on the device: no upload per call
-    check_cube = {}
+    crop = {}                      # a packed series: the crop it was produced from (resident runs keep it: the producer is timed on it)
+    producer_ms = {"pack": [], "dtdt": []}
 
-    def generate(a, b):
+    def pack(f, h0, h1, timing=None):
+        """The box-packed series of the held steps [h0, h1) of the crop `f`: every step's box gathered out of it (the reference's
+        per-step slice, box_data.py:297-310 -- done by whoever produces the data: here pack_series, in the product lec_ingest), dT/dt over
+        the series' time axis formed on each step's own box (fp64 storage: as a cube, lec_dtdt; fp32: the two neighbours' T).  Slabs of the
+        tallest / widest box of the WHOLE series: every chunk's cubes have one shape."""
+        return eng.pack_series(f["tair"], f["u"], f["v"], f["omega"], f["geopt"], boxes_of(h0, h1), tc_all[h0:h1], ny=nyb_max, nx=nxb_max, timing=timing)
+
+    def note_producer(tm):
+        torch.cuda.synchronize()
+        producer_ms["pack"].append(tm["pack"][0].elapsed_time(tm["pack"][1]))
+        producer_ms["dtdt"].append(tm["dtdt"][0].elapsed_time(tm["dtdt"][1]) if "dtdt" in tm else 0.0)
+
+    def generate(a, b, keep_crop=False):
         """(first held step, end, fields, the call's dT/dt arguments) of the steps [a, b) as they lie in HBM for the timed passes."""
         h0, h1 = halo_range(a, b, T_global)                  # one-step halo for dT/dt (thermodynamics.py:109-110)
         f = synthetic_cube(h1 - h0, level, lat, lon, device=device, dtype=tdtype, seed=1234, t0_global=h0)
@@ -350,13 +489,11 @@ def run_rank(args):
             f["geopt"] = None
         if not packed:
             return h0, h1, f, ({"tcoef": tc_all[h0:h1]} if with_q else {})
-        # the box-packed series: each step's box gathered out of the track-extent cube (the reference's per-step slice,
-        # box_data.py:297-310 -- done by whoever produces the data: here the generator, in the product lec_ingest), dT/dt over the
-        # series' time axis formed on each step's own box (fp64 storage: as a cube, lec_dtdt; fp32: the two neighbours' T)
-        if rank == 0 and not check_cube:                     # the first steps of the cube stay, for the cross-check after the timed passes
-            n = min(b - a, 8) + 1
-            check_cube.update(h0=h0, f={k: (None if v is None else v[:n + (a - h0)].clone()) for k, v in f.items()})
-        ps = eng.pack_series(f["tair"], f["u"], f["v"], f["omega"], f["geopt"], boxes_of(h0, h1), tc_all[h0:h1])
+        tm = {}
+        ps = pack(f, h0, h1, timing=tm)
+        note_producer(tm)
+        if keep_crop:
+            crop.update(h0=h0, h1=h1, f=f)
         del f
         cut = lambda x: None if x is None else x[a - h0: b - h0].contiguous()
         kw = {k: cut(ps[k]) for k in ("dTdt", "tm", "tp") if k in ps}
@@ -364,13 +501,14 @@ def run_rank(args):
             kw["tcoef"] = tc_all[a:b]
         return a, b, {k: cut(ps[k]) for k in ("tair", "u", "v", "omega", "geopt")}, kw
 
-    held = generate(*chunks[0]) if resident else None
+    held = generate(*chunks[0], keep_crop=True) if resident else None
+    producer_ms["pack"].clear(); producer_ms["dtdt"].clear()          # (the first call pays torch's one-time costs: not a measurement)
     # Everything a pass writes is allocated ONCE, here: the row records, the NaN counters, and (SeriesGatherer) the send / receive
     # buffers of the gather in two pipeline slots.  lec_reduce writes its packed [T_local, 16 + 21 nl] records straight into the
     # slot's send buffer; the gather of pass i is waited for when its slot comes round again, so it overlaps the kernels of pass i + 1.
     rows = torch.empty((T_local, nl, nyb_max, 32), dtype=torch.float64, device=device)
     nanflag = torch.empty((T_local,), dtype=torch.int32, device=device)
-    gat = SeriesGatherer(T_global, LECEngine.packed_width(nl), device, dst=0, slots=2, force=args.force_dist)
+    gat = SeriesGatherer(T_global, LECEngine.packed_width(nl), device, dst=0, slots=2, force=ctx.force_dist)
     merge = (lambda m: merge_dropmask(m)) if (use_dist and not args.moving) else None
     kernel_ms = []
     gen_s = [0.0]
@@ -378,17 +516,6 @@ def run_rank(args):
     if args.tuning:
         tuning = {k: (v if k in ("kernel", "order") else int(v)) for k, v in (kv.split("=") for kv in args.tuning.split(","))}
     stage1 = dict(with_q=with_q, tuning=tuning, per_step_boxes=bool(args.moving))
-
-    def barrier():
-        if backend == "nccl":
-            dist.barrier(device_ids=[local_rank])
-        else:
-            dist.barrier()
-
-    def sync(with_barrier=True):
-        if use_dist and with_barrier:
-            barrier()
-        torch.cuda.synchronize()
 
     pass_no = [0]
     last = {}
@@ -482,6 +609,7 @@ def run_rank(args):
     drain()
     sync()
     gen_s[0] = 0.0
+    producer_ms["pack"].clear(); producer_ms["dtdt"].clear()
     tic = time.perf_counter()
     timed_total = 0.0
     for _ in range(args.steps):
@@ -493,12 +621,7 @@ def run_rank(args):
     wall = time.perf_counter() - tic
     elapsed = wall if resident else timed_total
     elapsed_own = elapsed
-    if use_dist:
-        el = torch.tensor([elapsed, wall], dtype=torch.float64, device=device)
-        if backend == "gloo":
-            el = el.cpu()
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        elapsed, wall = float(el[0]), float(el[1])
+    elapsed, wall = ctx.reduce_max([elapsed, wall])
     res = last["res"]
     series = last.get("series")
     # every rank's block of the gathered series against the checksums of what that rank sent (not only rank 0's own block)
@@ -508,6 +631,36 @@ def run_rank(args):
         mine = torch.tensor([elapsed_own], dtype=torch.float64, device=device)
         from lorenzcycletoolkit_amd.parallel import _all_gather_small
         per_rank = [float(x) / args.steps * 1e3 for x in _all_gather_small(mine).view(-1)]
+
+    # The PRODUCER of a packed series (the per-step slice and dT/dt, which the reference's clock spans: lorenzcycletoolkit.py:173-199,
+    # box_data.py:297-310), per pass over this rank's shard, on HIP events of its own.  Streamed runs produce every chunk inside every
+    # pass (generate(): the events were taken there); a resident run re-produces its series from the crop it kept, three times.
+    producer = None
+    if packed:
+        repack_same = None
+        if resident:
+            for i in range(3):
+                tm = {}
+                ps = pack(crop["f"], crop["h0"], crop["h1"], timing=tm)
+                note_producer(tm)
+                if i == 0:      # and it is the series the timed passes read
+                    a0 = t0 - crop["h0"]
+                    repack_same = bool(torch.equal(ps["tair"][a0:a0 + T_local], held[2]["tair"]) and
+                                       all(torch.equal(ps[k][a0:a0 + T_local], held[3][k]) for k in ("dTdt", "tm", "tp") if k in held[3]))
+                del ps
+            per_pass = [float(np.median(producer_ms["pack"])), float(np.median(producer_ms["dtdt"]))]
+        else:       # one entry per chunk and pass: the sum over a pass's chunks
+            per_pass = [float(np.sum(producer_ms["pack"])) / args.steps, float(np.sum(producer_ms["dtdt"])) / args.steps]
+        per_pass = ctx.reduce_max(per_pass)
+        producer = {"pack": per_pass[0], "dtdt": per_pass[1], "total": per_pass[0] + per_pass[1],
+                    "unit": "ms per pass over a rank's shard, HIP events, max over ranks",
+                    "pack_is": "the per-step gathers out of the crop (5 fields + T of the two time neighbours; torch advanced indexing here, lec_ingest's "
+                               "gather in the product's streamed path)",
+                    "dtdt_is": ("lec_dtdt: dT/dt of the packed series as an fp64 cube" if args.storage == "f64" else "none: fp32 storage hands T of the two neighbours over"),
+                    "how": ("re-produced 3 times from the resident crop after the timed passes (median)" if resident else
+                            "taken inside every timed pass's generation of every chunk (sum over a pass's chunks, mean over passes)")}
+        if repack_same is not None:
+            producer["reproduced_series_is_the_timed_one"] = repack_same
 
     # Where a pass's time goes: three instrumented passes (every segment closed by a device synchronisation, the gather completed
     # inside its pass), median per segment.  Reported beside the timed figure, never inside it.
@@ -561,9 +714,9 @@ def run_rank(args):
     # resident shard -- record by record and term by term (finite is not a check: wrong coefficients give finite numbers too)
     moving_check = None
     if rank == 0 and resident and args.moving:
-        # (a box-packed series: the check runs on the CUBE the series was packed from -- its first steps were kept --, so it also says
-        # that packing changed no bit: the timed pass read the packed series, `a` reads the cube)
-        h0, h1, f = (check_cube["h0"], None, check_cube["f"]) if packed else held[:3]
+        # (a box-packed series: the check runs on the CROP the series was produced from, so it also says that packing changed no
+        # value: the timed pass read the packed series, `a` reads the crop)
+        h0, f = (crop["h0"], crop["f"]) if packed else held[:3:2]
         n = min(T_local, 8)
         bx = [all_boxes.boxes[i] for i in range(n)]
         nheld = f["tair"].shape[0]
@@ -575,11 +728,15 @@ def run_rank(args):
         rec = float(((ra - rb).abs().amax(dim=(0, 1, 2)) / rb.abs().amax(dim=(0, 1, 2)).clamp_min(1e-300)).max())
         sc = float(((a.scalars - b.scalars).abs().amax(dim=0) / b.scalars.abs().amax(dim=0).clamp_min(1e-300)).max())
         same = bool(torch.equal(a.scalars, res.scalars[:n]))       # and the timed pass produced exactly these numbers
+        worst_vs_timed = float(((a.scalars - res.scalars[:n]).abs().amax(dim=0) / a.scalars.abs().amax(dim=0).clamp_min(1e-300)).max())
         moving_check = {"steps": n, "row_records_max_rel_diff_vs_row_sweep": rec, "terms_max_rel_diff_vs_row_sweep": sc,
-                        "timed_pass_bit_identical": same, "ok": bool(rec <= 1e-10 and sc <= 1e-9 and same),
-                        "checked_on": ("the track-extent cube the packed series was gathered from" if packed else "the resident cube")}
+                        "timed_pass_bit_identical": same, "timed_pass_max_rel_diff": worst_vs_timed,
+                        "ok": bool(rec <= 1e-10 and sc <= 1e-9 and worst_vs_timed <= 1e-11),
+                        "checked_on": ("the track-extent crop the packed series was gathered from" if packed else "the resident crop")}
 
+    out, cpu_leg = None, None
     if rank == 0:
+        from lorenzcycletoolkit_amd._lib import source_digest
         finite = bool(torch.isfinite(res.scalars).all().item())
         gathered_ok = None
         if series is not None and gat.active:       # rank 0's block of the gathered series is what its own stage 2 wrote
@@ -592,7 +749,6 @@ def run_rank(args):
         steps_per_launch = T_local if resident else float(np.mean([b - a for a, b in chunks]))
         achieved = bytes_per_step_t * steps_per_launch / (avg_launch_ms * 1e-3) / 1e9
         traffic, traffic_src, traffic_sha = None, None, None
-        from lorenzcycletoolkit_amd._lib import source_digest
         csrc_sha = source_digest()
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if os.path.exists(pmc) and (args.ny, args.nx) == (721, 1440):
@@ -607,7 +763,9 @@ def run_rank(args):
             except Exception:
                 traffic = None
         if args.moving:
-            kname = "lec_boxtile_kernel (one wave per four box rows x a chunk of levels of a time step; six values per point transposed through LDS)"
+            kname = ("one lec_rowstats call on a box-packed series (lec_boxplane_kernel where the call is fp64, even longitudes, rows of one column chunk; "
+                     "else lec_boxtile_kernel)" if packed else
+                     "lec_boxtile_kernel (one wave per four box rows x a chunk of levels of a time step; six values per point transposed through LDS)")
         elif args.no_q or args.storage == "f32":
             kname = "lec_rowsweep_kernel (one wave per row)" + ("" if args.no_q else " + lec_qtime_kernel")
         else:
@@ -616,8 +774,9 @@ def run_rank(args):
         if args.moving:
             workload = (f"synthetic 0.25-degree {nl} lev x {lat.size} x {lon.size} track-extent crop, moving 15x15-degree box "
                         f"(61 x 61 points) per time step, storage {args.storage}, terms = {terms}"
-                        + ("; the series lies in HBM BOX-PACKED (every step's box gathered out of the crop before the timed region, as the streamed "
-                           "moving framework's ingest writes it: 5 field slabs + " + ("dT/dt as an fp64 cube" if args.storage == "f64" else "T of the two time neighbours")
+                        + ("; the series lies in HBM BOX-PACKED (every step's box gathered out of the crop and dT/dt formed by the PRODUCER, outside the "
+                           "timed region -- config.producer_ms --, as the streamed moving framework's ingest writes it: 5 field slabs + "
+                           + ("dT/dt as an fp64 cube" if args.storage == "f64" else "T of the two time neighbours")
                            + " per step; --moving-layout cube = the whole crop, rounds 1-4)" if packed else "; the series lies in HBM as the whole crop"))
         else:
             workload = (f"synthetic ERA5-res {nl} lev x {args.ny} x {args.nx}" + (" on STRETCHED longitudes" if args.nonuniform_lon else "") +
@@ -639,6 +798,16 @@ def run_rank(args):
             bcfg = {"id": 4, "exact": bool(T_global == 2048 and world in (2, 4, 8)),
                     "note": (f"T={T_global} time-sharded over {world} GPU(s)" + (" (strong scaling)" if strong else f" (weak scaling: T={T_local} per GPU)")
                              + "; BASELINE config 4 is T=2048 over 2/4/8 GPUs (--timesteps-global 2048)")}
+        if resident:
+            timed_region = "wall clock around all passes (stage 1 + stage 2 + collectives, every pass's series delivered to rank 0), inputs resident in HBM"
+        else:
+            timed_region = "lec_rowstats per chunk + lec_reduce + collectives (synchronised segments); synthetic generation excluded"
+        if packed:
+            timed_region += ("; the series is resident BOX-PACKED: the per-step slice (box_data.py:297-310) and dT/dt (lorenzcycletoolkit.py:184-186) -- both "
+                             "inside the reference's own clock -- are the producer's work and OUTSIDE this region: config.producer_ms times them, "
+                             "config.value_incl_producer is the rate with them inside")
+        elif args.moving:
+            timed_region += "; the kernel slices every step's box by index and forms dT/dt per point: both inside this region"
         out = {
             "metric": ("LEC timesteps/sec (all terms), moving 61x61x37 box per time step" if args.moving else
                        "LEC timesteps/sec (all energy+conversion+boundary+generation terms) at 37x721x1440"),
@@ -655,9 +824,7 @@ def run_rank(args):
                 "parallelism": f"time-sharded x{world}, no data-path collective; RCCL all_reduce of the NaN-level mask (fixed box) + one gather of the "
                                "packed per-time-step records to rank 0 (a send per peer, each over its own xGMI link), double-buffered: "
                                "the gather of pass i overlaps the kernels of pass i + 1",
-                "timed_region": ("wall clock around all passes (stage 1 + stage 2 + collectives, every pass's series delivered to rank 0), inputs resident in HBM"
-                                 if resident else
-                                 "lec_rowstats per chunk + lec_reduce + collectives (synchronised segments); synthetic generation excluded"),
+                "timed_region": timed_region,
                 "results_finite": finite, "csrc_sha": csrc_sha,
                 **({"gathered_series_ok": gathered_ok} if gathered_ok is not None else {}),
                 **({"peer_blocks_ok": peers["peer_blocks_ok"], "peer_blocks": peers["blocks_ok"],
@@ -676,6 +843,10 @@ def run_rank(args):
                 "algorithmic_bytes_per_launch": bytes_per_step_t * steps_per_launch,
             },
         }
+        if producer is not None:
+            out["config"]["producer_ms"] = producer
+            out["config"]["value_incl_producer"] = T_global * args.steps / (elapsed + args.steps * producer["total"] * 1e-3)
+            out["config"]["ms_per_step_incl_producer"] = elapsed / args.steps * 1e3 + producer["total"]
         if segments is not None:
             k1 = avg_launch_ms
             pass_ms = elapsed / args.steps * 1e3
@@ -728,32 +899,125 @@ def run_rank(args):
                 os.makedirs(os.path.dirname(os.path.abspath(args.digest_file)), exist_ok=True)
                 json.dump(book, open(args.digest_file, "w"), indent=1)
         if strong:
-            ref = os.path.join(ROOT, "profiles", "strong_scaling_n1.json")
+            # the N = 1 value of this configuration (profiles/strong_scaling_n1.json, keyed by the series' layout, stamped with the kernel
+            # sources it was measured on; tools/update_n1.py writes it from one-GPU lines).  A one-GPU run IS the N = 1 value.
+            nkey = n1_key(args, T_global, packed)
             try:
-                n1 = json.load(open(ref)).get(f"{'moving' if args.moving else 'fixed'}_{args.storage}_{'noq' if args.no_q else 'all'}_T{T_global}")
+                n1 = json.load(open(args.n1_file)).get(nkey)
             except Exception:
                 n1 = None
-            out["config"]["speedup_vs_n1"] = None if not n1 else out["value"] / n1
-            out["config"]["n1_value"] = n1
+            n1 = n1 if isinstance(n1, dict) else None
+            cfg = out["config"]
+            cfg["n1_key"] = nkey
+            cfg["n1_stored"] = None if n1 is None else {k: n1.get(k) for k in ("value", "csrc_sha", "source")}
+            cfg["n1_stale"] = None if n1 is None else bool(n1.get("csrc_sha") != csrc_sha)
+            if world == 1:
+                cfg["speedup_vs_n1"], cfg["n1_value"] = 1.0, out["value"]
+            else:
+                cfg["speedup_vs_n1"] = None if n1 is None else out["value"] / n1["value"]
+                cfg["n1_value"] = None if n1 is None else n1["value"]
+                if producer is not None and n1 is not None and n1.get("value_incl_producer"):
+                    cfg["speedup_vs_n1_incl_producer"] = cfg["value_incl_producer"] / n1["value_incl_producer"]
+
         # The CPU leg runs AFTER the timed region and the verification collectives, on rank 0 only; at N > 1 the peers wait for it in the
         # closing barrier (17 s for "single"; the process group's timeout is 10 min for RCCL, 30 for gloo).  north_star: the N-GPU
         # throughput "next to the reference CPU path timed on the node's own host cores in the same run" (the reference clocks its whole
         # call: lorenzcycletoolkit.py:173,180,199).  `parity` at N > 1 is rank 0's shard: its first steps against the oracle.
-        kind = "none" if args.no_cpu_baseline else args.cpu_baseline
-        if kind != "none" and resident and with_q and not args.moving:
-            leg = kind if world == 1 or kind == "quick" else "single"
-            out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(leg, eng, held, lat, lon, level, time_s, device)
+        if cpu_kind != "none" and with_q:
+            leg = cpu_kind if world == 1 or cpu_kind == "quick" else "single"
+            if args.moving:
+                # the first steps of the crop rank 0's series came from (a streamed run: generated again -- seeded per global step)
+                n = cpu_leg_steps_moving(leg, T_local)
+                hold = min(n + 1, T_global)
+                if packed and resident:
+                    keep = {k: v[:hold].clone() for k, v in crop["f"].items()}
+                elif resident:
+                    keep = {k: v[:hold].clone() for k, v in held[2].items()}
+                else:
+                    keep = synthetic_cube(hold, level, lat, lon, device=device, dtype=tdtype, seed=1234, t0_global=0)
+                got_s = {k: v[:n] for k, v in res.scalars_dict().items()}
+                got_l = {k: v[:n] for k, v in res.levels_dict().items()}
+                lims = limits_of(0, hold)
+
+                def cpu_leg():
+                    out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity_moving(leg, keep, lims, lat, lon, level, time_s, got_s, got_l, n)
+            else:
+                n = min(cpu_leg_steps(leg), T_local)
+                if resident:
+                    keep = {k: (None if v is None else v[:n].clone()) for k, v in held[2].items()}
+                else:
+                    keep = synthetic_cube(n, level, lat, lon, device=device, dtype=tdtype, seed=1234, t0_global=0)
+                note = ("the first %d time steps of the resident synthetic cube the GPU was timed on, copied to the host" if resident else
+                        "the first %d time steps of the first chunk of the streamed series (generated again from the per-step seeds), copied to the host")
+
+                def cpu_leg():
+                    out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(leg, eng, keep, lat, lon, level, time_s[:n], device, note)
             if world > 1:
-                out["cpu_baseline"]["ranks_waiting_in_the_closing_barrier"] = world - 1
-                out["parity"]["shard"] = f"rank 0 of {world}: global time steps {t0}..{t1 - 1}"
-        if stdout_fd is not None:
-            sys.stdout.flush()
-            os.dup2(stdout_fd, 1)
-        print(json.dumps(out, ensure_ascii=False), flush=True)
-        if stdout_fd is not None:
-            os.dup2(2, 1)
-    if use_dist:
-        barrier()
+                inner = cpu_leg
+
+                def cpu_leg():
+                    inner()
+                    out["cpu_baseline"]["ranks_waiting_in_the_closing_barrier"] = world - 1
+                    out["parity"]["shard"] = f"rank 0 of {world}: global time steps {t0}..{t1 - 1}"
+    return out, cpu_leg
+
+
+def strong_legs(args, ctx):
+    """BASELINE configs 4 and 5 inside the default N > 1 run (the driver passes --gpus N and nothing else): the fixed box at T = 2048
+    (sharded, streamed through HBM in chunks) and the moving box at T = 4096, one warm-up pass and --leg-steps timed passes each, on
+    the job's own process group.  Returns rank 0's summary for config.strong_scaling (None elsewhere)."""
+    import copy
+    import gc
+    import torch
+    t4, t5 = (int(x) for x in args.leg_timesteps.split(","))
+    legs = {}
+    for name, T, moving in (("config4", t4, False), ("config5", t5, True)):
+        la = copy.copy(args)
+        la.timesteps_global, la.moving, la.steps, la.warmup, la.chunk = T, moving, args.leg_steps, 1, 0
+        la.write_digest = False
+        tic = time.perf_counter()
+        o, _ = measure(la, ctx, cpu_kind="none")
+        gc.collect()
+        torch.cuda.empty_cache()
+        if o is None:
+            continue
+        c = o["config"]
+        legs[name] = {"value": o["value"], "unit": "timesteps/s", "ms_per_pass": o["ms_per_step"], "timesteps_global": T, "passes": la.steps,
+                      "speedup_vs_n1": c.get("speedup_vs_n1"), "n1_value": c.get("n1_value"), "n1_stale": c.get("n1_stale"), "n1_key": c.get("n1_key"),
+                      "per_gpu_roofline_frac": o["roofline"]["frac"], "series_equals_n1": c.get("series_equals_n1"),
+                      "baseline_config": c["baseline_config"], "workload": c["workload"], "timed_region": c["timed_region"],
+                      "results_finite": c["results_finite"], "peer_blocks_ok": c.get("peer_blocks_ok"),
+                      "leg_wall_s": time.perf_counter() - tic}
+        for k in ("chunk", "generation_ms_per_step", "producer_ms", "value_incl_producer", "speedup_vs_n1_incl_producer", "moving_layout", "moving_check"):
+            if k in c:
+                legs[name][k] = c[k]
+    return legs or None
+
+
+def run_rank(args):
+    import gc
+    import torch
+    import torch.distributed as dist
+    ctx = RankContext(args)
+    kind = "none" if args.no_cpu_baseline else args.cpu_baseline
+    out, cpu_leg = measure(args, ctx, cpu_kind=kind)
+    # the default N > 1 line: BASELINE configs 4 and 5 as two short strong-scaling legs, after the headline and before the CPU leg
+    default_line = not (args.moving or args.timesteps_global > 0 or args.no_q or args.storage != "f64" or args.nonuniform_lon or args.tuning)
+    if ctx.world > 1 and default_line and not args.no_strong_legs:
+        gc.collect()
+        torch.cuda.empty_cache()                # the headline's resident cube makes room for the legs' chunks
+        legs = strong_legs(args, ctx)
+        if out is not None:
+            out["config"]["strong_scaling"] = legs
+            out["config"]["strong_scaling_note"] = ("BASELINE configs 4 (fixed box) and 5 (moving box) as strong-scaling legs of this job, one warm-up and "
+                                                    f"{args.leg_steps} timed passes each; speedup_vs_n1 divides by the stored one-GPU value of the same "
+                                                    "configuration and layout (n1_stale: the kernel sources have changed since it was measured)")
+    if ctx.rank == 0:
+        if cpu_leg is not None:
+            cpu_leg()
+        ctx.print_line(out)
+    if ctx.use_dist:
+        ctx.barrier()
         dist.destroy_process_group()
 
 

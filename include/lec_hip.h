@@ -46,8 +46,11 @@ extern "C" {
 
 /* ABI 8 (round 4): lec_reduce_args.stage (the two halves of stage 2 run apart; no 65535-step limit), lec_inflate_args.dst_bytes and
  * lec_chunk_scatter_args.src_bytes (the destination / payload ranges of every descriptor are bounds-checked on the device). */
-#define LEC_ABI_VERSION 9
-/* ABI 9 (round 5): lec_format_csv_rows (host): a per-level table as the text pandas writes for it, one call per table;
+#define LEC_ABI_VERSION 10
+/* ABI 10 (round 6): lec_ingest_args.nt_src (was reserved0) / jmap_len / imap_len: a per-step gather table (step_d) is bounds-checked --
+ * lec_ingest refuses one without them, its kernel writes NaN rows for an entry that points outside the source or the maps instead of
+ * reading there, and lec_check_maps scans the table and names the first bad entry.
+ * ABI 9 (round 5): lec_format_csv_rows (host): a per-level table as the text pandas writes for it, one call per table;
  * lec_rowstats_args.tm_d / tp_d: box-packed series of the moving framework (the struct grew by two pointers at its end); lec_dtdt;
  * lec_ingest_args.step_d / step_base: per-step gathers (the struct grew at its end). */
 
@@ -252,11 +255,15 @@ typedef struct lec_ingest_args {
      * source step).  NULL: output step t reads source step t with the maps as they are.  Else step_d[t] = {source step, latitude
      * offset, longitude offset}: output step t reads source step step_d[t][0] - step_base of src_d through jmap_d[j + step_d[t][1]] and
      * imap_d[i + step_d[t][2]] -- the maps must be long enough for the largest offset + ny / nx (lengthen them by repeating their last
-     * entry; lec_check_maps scans ny / nx entries: give it the maps' full lengths); nt counts OUTPUT steps, the source holds whatever
-     * steps the table names. */
+     * entry); nt counts OUTPUT steps, the source holds nt_src steps.
+     * ABI 10: the table lives in device memory, where argument validation cannot see it (the reference bounds-checks its track against
+     * the data on the host, lec_moving_framework.py:112-154), so the call carries what bounds it: nt_src, jmap_len, imap_len.  An entry
+     * with a source step outside [step_base, step_base + nt_src) or an offset outside [0, jmap_len - ny] / [0, imap_len - nx] never
+     * reads: lec_ingest writes NaN into that output step's rows, and lec_check_maps names the first such entry. */
     const int32_t* step_d;      /* [nt][3] or NULL */
     int32_t step_base;          /* the source step that src_d starts with */
-    int32_t reserved0;          /* must be 0 */
+    int32_t nt_src;             /* time steps src_d holds (step_d given: >= 1; else ignored -- the source then holds nt steps) */
+    int32_t jmap_len, imap_len; /* entries of jmap_d / imap_d (step_d given: >= ny / nx; else 0 = ny / nx) */
 } lec_ingest_args;
 
 /*

@@ -182,25 +182,36 @@ def main(argv=None):
         analyse = lambda d: run_lec_analysis(d, args, results_subdirectory, figures_directory, results_subdirectory_vertical_levels, app_logger)
         data = None
         if args.device_ingest:
-            from lorenzcycletoolkit_amd.ingest import prepare_streamed
+            from lorenzcycletoolkit_amd.ingest import StreamedRefusal, prepare_streamed, refusals
+            refused = None
             try:
-                data = prepare_streamed(args, "inputs/namelist", app_logger, raw=opened)
+                with refusals():
+                    data = prepare_streamed(args, "inputs/namelist", app_logger, raw=opened)
                 phases.mark("open_and_plan")
                 try:
                     analyse(data)
                 finally:
                     data.raw.close()
-            except (ValueError, NotImplementedError) as e:
-                # A streamed path that --ingest auto chose BY ITSELF must not fail a run the host preparation can do: the
-                # file is closed, the reason logged, and the data are prepared on the host.  The frameworks write their files only
-                # after the engine has returned and create the header files anew (mode "w"), so nothing half-done is left.  Asked for explicitly
-                # (--ingest device / --device-ingest) the error stands.
+            except StreamedRefusal as e:
+                # A streamed path that --ingest auto chose BY ITSELF must not fail a run the host preparation can do: the file is closed, the
+                # reason logged, and the data are prepared on the host.  Only a REFUSAL of the streamed path counts (raised around
+                # prepare_streamed / lec_streamed: before the engine has produced anything) -- an error later in the run (CSV writing,
+                # plotting) is an error, not a reason to analyse everything a second time.  Asked for explicitly (--ingest device /
+                # --device-ingest) the refusal stands.
                 if not auto_chose or args.shard is not None:       # (ranks of a sharded run must not part ways)
-                    raise
+                    raise e.__cause__ if e.__cause__ is not None else e
+                refused = str(e)
+            if refused is not None:
+                # (outside the handler: the traceback -- and through its frames the failed attempt's device buffers -- is released first)
                 if data is None and opened is not None:
                     opened.close()
-                app_logger.warning(f"--ingest auto: the streamed path refused this input ({type(e).__name__}: {e}); preparing the data on the host instead")
+                app_logger.warning(f"--ingest auto: the streamed path refused this input ({refused}); preparing the data on the host instead")
                 args.device_ingest, data = False, None
+                import gc
+                import torch
+                gc.collect()
+                if torch.cuda.is_available():
+                    torch.cuda.empty_cache()
         if not args.device_ingest:
             data = prepare_data(args, "inputs/namelist", app_logger)
             phases.mark("open_decode_and_prepare")

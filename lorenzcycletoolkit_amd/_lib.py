@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # LEC_LIB: alternative build of the same ABI (kernel experiments only)
 LIB_PATH = os.environ.get("LEC_LIB") or os.path.join(_HERE, "liblec_hip.so")
 
-LEC_ABI_VERSION = 9
+LEC_ABI_VERSION = 10
 LEC_NSTAT = 32
 LEC_NLEVRAW = 40
 LEC_NSCALAR = 16
@@ -96,7 +96,7 @@ class IngestArgs(C.Structure):
         ("scale_factor", C.c_double), ("add_offset", C.c_double), ("fill_value", C.c_double), ("unit_scale", C.c_double),
         ("out_dtype", C.c_int32), ("decode_dtype", C.c_int32),
         ("out_d", C.c_void_p), ("stream", C.c_void_p),
-        ("step_d", C.c_void_p), ("step_base", C.c_int32), ("reserved0", C.c_int32),
+        ("step_d", C.c_void_p), ("step_base", C.c_int32), ("nt_src", C.c_int32), ("jmap_len", C.c_int32), ("imap_len", C.c_int32),
     ]
 
 

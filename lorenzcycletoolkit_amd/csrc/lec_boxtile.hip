@@ -143,8 +143,9 @@ __device__ __forceinline__ void lds_barrier() {           // LDS write -> workgr
     else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// (the bound says what the kernel is: four-wave groups on table longitudes carry a seventh LDS tile -- 90 KB per workgroup, one per CU)
 template <typename TIN, bool UNIFORM, int MODE, bool WINDOW, int TG>
-__global__ void __launch_bounds__(64 * TG, 2) lec_boxtile_kernel(const RowParams p) {
+__global__ void __launch_bounds__(64 * TG, (TG == 4 && !UNIFORM) ? 1 : 2) lec_boxtile_kernel(const RowParams p) {
     static_assert(TG == 1 || (MODE == 1 && WINDOW), "time groups: per-point dT/dt from the cube's time neighbours, rows of one column chunk");
     constexpr bool WITH_Q = MODE != 0;
     constexpr int NT = n_tiles<UNIFORM, MODE>();

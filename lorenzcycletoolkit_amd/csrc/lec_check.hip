@@ -41,6 +41,19 @@ __global__ void __launch_bounds__(256) lec_check_maps_kernel(const int* __restri
     }
 }
 
+// the per-step gather table of a box-packed series (lec_ingest_args.step_d): {source step, latitude offset, longitude offset} per
+// output step.  status[0] += bad entries, status[1] = lowest (table 3, step)
+__global__ void __launch_bounds__(256) lec_check_steps_kernel(const int* __restrict__ step, int nt, int step_base, int nt_src, int ny, int jmap_len, int nx,
+                                                              int imap_len, int* __restrict__ status) {
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nt; t += gridDim.x * blockDim.x) {
+        const int ts = step[3 * t] - step_base, oj = step[3 * t + 1], oi = step[3 * t + 2];
+        if ((unsigned)ts >= (unsigned)nt_src || oj < 0 || oj > jmap_len - ny || oi < 0 || oi > imap_len - nx) {
+            atomicAdd(&status[0], 1);
+            atomicMin(&status[1], 3 * 0x1000000 + min(t, 0xffffff));
+        }
+    }
+}
+
 int fetch_status(int32_t* status_d, int (&h)[4], hipStream_t st) {
     if (hipMemcpyAsync(h, status_d, sizeof(int) * 4, hipMemcpyDeviceToHost, st) != hipSuccess) return 1;
     if (hipStreamSynchronize(st) != hipSuccess) return 1;
@@ -75,18 +88,32 @@ extern "C" int lec_check_maps(const lec_ingest_args* a, int32_t* status_d) {
     if (!a || !status_d) return lec_set_error(LEC_ERR_ARG, "lec_check_maps: null args / status_d");
     if (!a->kmap_d || !a->jmap_d || !a->imap_d) return lec_set_error(LEC_ERR_ARG, "lec_check_maps: null map pointer");
     if (a->nl < 1 || a->ny < 1 || a->nx < 1 || a->nl_in < 1 || a->ny_in < 1 || a->nx_in < 1) return lec_set_error(LEC_ERR_ARG, "lec_check_maps: extents must be >= 1");
+    // the maps are scanned over their full lengths (a per-step gather enters them at an offset: they are longer than ny / nx then)
+    const int nj = a->jmap_len > 0 ? a->jmap_len : a->ny, ni = a->imap_len > 0 ? a->imap_len : a->nx;
+    if (nj < a->ny || ni < a->nx) return lec_set_error(LEC_ERR_ARG, "lec_check_maps: jmap_len / imap_len must be 0 or >= ny / nx");
+    if (a->step_d && (a->nt < 1 || a->nt_src < 1)) return lec_set_error(LEC_ERR_ARG, "lec_check_maps: a step_d table needs nt >= 1 and nt_src >= 1");
     hipStream_t st = (hipStream_t)a->stream;
     if (reset_status(status_d, st)) return lec_set_error(LEC_ERR_LAUNCH, "lec_check_maps: could not initialise status_d");
-    const long long n = (long long)a->nl + a->ny + a->nx;
+    const long long n = (long long)a->nl + nj + ni;
     const int blocks = n < 256 * 64 ? (int)((n + 255) / 256) : 64;
-    hipLaunchKernelGGL(lec_check_maps_kernel, dim3(blocks), dim3(256), 0, st, a->kmap_d, a->nl, a->nl_in, a->jmap_d, a->ny, a->ny_in, a->imap_d, a->nx,
+    hipLaunchKernelGGL(lec_check_maps_kernel, dim3(blocks), dim3(256), 0, st, a->kmap_d, a->nl, a->nl_in, a->jmap_d, nj, a->ny_in, a->imap_d, ni,
                        a->nx_in, status_d);
+    if (a->step_d) {
+        const int sb = a->nt < 256 * 64 ? (a->nt + 255) / 256 : 64;
+        hipLaunchKernelGGL(lec_check_steps_kernel, dim3(sb), dim3(256), 0, st, a->step_d, a->nt, a->step_base, a->nt_src, a->ny, nj, a->nx, ni, status_d);
+    }
     int h[4];
     if (hipGetLastError() != hipSuccess || fetch_status(status_d, h, st)) return lec_set_error(LEC_ERR_LAUNCH, "lec_check_maps: kernel or copy failed");
     if (h[0] == 0) return LEC_OK;
-    static const char* names[3] = {"kmap_d", "jmap_d", "imap_d"};
-    char msg[256];
-    snprintf(msg, sizeof msg, "lec_check_maps: %d map entries point outside the source cube (%d x %d x %d); first: %s[%d]", h[0], a->nl_in, a->ny_in, a->nx_in,
-             names[(h[1] >> 24) % 3], h[1] & 0xffffff);
+    static const char* names[4] = {"kmap_d", "jmap_d", "imap_d", "step_d"};
+    const int which = (h[1] >> 24) & 3;
+    char msg[384];
+    if (which < 3)
+        snprintf(msg, sizeof msg, "lec_check_maps: %d table entries are out of range; first: %s[%d] points outside the source cube (%d x %d x %d)", h[0],
+                 names[which], h[1] & 0xffffff, a->nl_in, a->ny_in, a->nx_in);
+    else
+        snprintf(msg, sizeof msg, "lec_check_maps: %d table entries are out of range (the maps themselves are fine); first: step_d[%d]: its source step must lie in "
+                 "[%d, %d), its latitude offset in [0, %d], its longitude offset in [0, %d]", h[0], h[1] & 0xffffff, a->step_base, a->step_base + a->nt_src,
+                 nj - a->ny, ni - a->nx);
     return lec_set_error(LEC_ERR_ARG, msg);
 }

@@ -21,6 +21,7 @@ struct IngestParams {
     int swap, has_packing, has_fill, decode_f32;
     double scale, offset, fill, unit;
     const int* step; int step_base;      // per-step gathers: {source step, latitude offset, longitude offset} per output step, or null
+    int nt_src, jmap_len, imap_len;      // ... and what bounds that table's entries
 };
 
 __device__ __forceinline__ int16_t load_elem(const int16_t* p, bool swap) {
@@ -54,6 +55,12 @@ __global__ void __launch_bounds__(256) lec_ingest_kernel(const IngestParams p) {
     const int t = row / (p.ny * p.nl);
     // (a box-packed series: this output step's box may start anywhere in the maps and come from another source step)
     const int ts = p.step ? p.step[3 * t] - p.step_base : t, oj = p.step ? p.step[3 * t + 1] : 0, oi = p.step ? p.step[3 * t + 2] : 0;
+    if (p.step && ((unsigned)ts >= (unsigned)p.nt_src || oj < 0 || oj > p.jmap_len - p.ny || oi < 0 || oi > p.imap_len - p.nx)) {
+        // an entry of the device-resident table that points outside the source or the maps: nothing is read, the step's rows say so
+        TOUT* __restrict__ bad = (TOUT*)p.out + (size_t)row * p.nx;
+        for (int i = threadIdx.x; i < p.nx; i += blockDim.x) bad[i] = (TOUT)__builtin_nan("");
+        return;
+    }
     const TSRC* __restrict__ src = (const TSRC*)p.src + (((size_t)ts * p.nl_in + p.kmap[k]) * p.ny_in + p.jmap[j + oj]) * (size_t)p.nx_in;
     TOUT* __restrict__ out = (TOUT*)p.out + (size_t)row * p.nx;
     const int* __restrict__ imap = p.imap + oi;
@@ -101,8 +108,14 @@ extern "C" int lec_ingest(const lec_ingest_args* a) {
     p.src = a->src_d; p.out = a->out_d;
     p.nt = a->nt; p.nl_in = a->nl_in; p.ny_in = a->ny_in; p.nx_in = a->nx_in; p.nl = a->nl; p.ny = a->ny; p.nx = a->nx;
     p.kmap = a->kmap_d; p.jmap = a->jmap_d; p.imap = a->imap_d;
-    if (a->reserved0) return lec_set_error(LEC_ERR_ARG, "lec_ingest: reserved0 must be 0");
     p.step = a->step_d; p.step_base = a->step_base;
+    p.nt_src = a->nt_src; p.jmap_len = a->jmap_len; p.imap_len = a->imap_len;
+    if (a->step_d) {
+        if (a->nt_src < 1 || a->jmap_len < a->ny || a->imap_len < a->nx)
+            return lec_set_error(LEC_ERR_ARG, "lec_ingest: a step_d table needs nt_src >= 1, jmap_len >= ny and imap_len >= nx (what bounds its entries)");
+    } else if ((a->jmap_len != 0 && a->jmap_len != a->ny) || (a->imap_len != 0 && a->imap_len != a->nx)) {
+        return lec_set_error(LEC_ERR_ARG, "lec_ingest: without step_d the maps have ny / nx entries (jmap_len / imap_len: 0 or exactly that)");
+    }
     if (a->decode_dtype != LEC_F64 && a->decode_dtype != LEC_F32) return lec_set_error(LEC_ERR_ARG, "lec_ingest: decode_dtype must be LEC_F64 or LEC_F32");
     if (a->decode_dtype == LEC_F32 && (a->src_dtype == LEC_F64 || a->src_dtype == LEC_I32))
         return lec_set_error(LEC_ERR_ARG, "lec_ingest: float64 and int32 data do not decode to float32");

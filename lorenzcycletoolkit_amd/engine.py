@@ -179,17 +179,36 @@ class LECEngine:
                 _lib.check(self.lib.lec_dtdt(C.byref(args)), "lec_dtdt")
         return out
 
-    def pack_series(self, tair, u, v, omega, geopt, boxes, tcoef: torch.Tensor, ny: Optional[int] = None, nx: Optional[int] = None) -> dict:
+    def pack_series(self, tair, u, v, omega, geopt, boxes, tcoef: torch.Tensor, ny: Optional[int] = None, nx: Optional[int] = None,
+                    timing: Optional[dict] = None) -> dict:
         """The box-packed form of a moving series held as whole cubes (tests, ``bench.py --moving``, host-prepared tracks): the keyword
         arguments of ``rowstats`` -- the five fields packed per step (``pack_boxes``) and dT/dt as the series' own data: an fp64 cube
         for fp64 storage (``time_stencil``: one operand fewer per point), T of the two time neighbours on the step's box for fp32
-        storage (the same bytes as a cube would be, and no rounding of dT/dt to the storage dtype).  ``tcoef``: rows of the cubes' steps."""
-        pk = {k: self.pack_boxes(c, boxes, ny=ny, nx=nx) for k, c in (("tair", tair), ("u", u), ("v", v), ("omega", omega), ("geopt", geopt)) if c is not None}
-        tm, tp = self.pack_boxes(tair, boxes, shift=-1, ny=ny, nx=nx), self.pack_boxes(tair, boxes, shift=+1, ny=ny, nx=nx)
-        if tair.dtype == torch.float64:
-            pk["dTdt"] = self.time_stencil(tm, pk["tair"], tp, tcoef)
-        else:
-            pk["tm"], pk["tp"] = tm, tp
+        storage (the same bytes as a cube would be, and no rounding of dT/dt to the storage dtype).  ``tcoef``: rows of the cubes' steps.
+        ``timing``: a dict that receives HIP events recorded on the current stream -- "pack" = (start, end) around the gathers (the
+        per-step slice, box_data.py:297-310), "dtdt" = (start, end) around ``lec_dtdt`` (fp64 storage only): what the PRODUCER of a
+        packed series spends, which ``bench.py --moving`` reports beside the consumer's rate."""
+        def ev():
+            if timing is None:
+                return None
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            return e
+
+        with torch.cuda.device(tair.device):
+            e0 = ev()
+            pk = {k: self.pack_boxes(c, boxes, ny=ny, nx=nx) for k, c in (("tair", tair), ("u", u), ("v", v), ("omega", omega), ("geopt", geopt)) if c is not None}
+            tm, tp = self.pack_boxes(tair, boxes, shift=-1, ny=ny, nx=nx), self.pack_boxes(tair, boxes, shift=+1, ny=ny, nx=nx)
+            e1 = ev()
+            if tair.dtype == torch.float64:
+                pk["dTdt"] = self.time_stencil(tm, pk["tair"], tp, tcoef)
+            else:
+                pk["tm"], pk["tp"] = tm, tp
+            e2 = ev()
+        if timing is not None:
+            timing["pack"] = (e0, e1)
+            if "dTdt" in pk:
+                timing["dtdt"] = (e1, e2)
         pk.setdefault("geopt", None)
         return pk
 

@@ -91,7 +91,8 @@ class BoxData:
             out = gat.send(0)[:, :width]
             merge = shard.merge_dropmask if not self.per_step_boxes else None
 
-        from .ingest import StreamedDataset, lec_streamed
+        from . import ingest
+        from .ingest import StreamedDataset
         if isinstance(data, StreamedDataset):
             # device ingest: the file bytes are streamed, decoded, sorted and cropped on the GPU (ingest.py); in the moving
             # framework dT/dt is differentiated on the device over the (track-selected) time axis
@@ -102,9 +103,10 @@ class BoxData:
             # file); only where the namelist's units leave the values as they are in the file, so that both paths see the same numbers
             plain_units = all(ds.field_scale(variable_list_df, r) == 1.0 for r in ("Eastward Wind Component", "Northward Wind Component"))
             keep = 85000.0 if (boxes_limits is not None and plain_units and 85000.0 in data.level) else None
-            self.result: LECResult = lec_streamed(data.raw, data.plan, variable_list_df, limits, per_step_boxes=boxes_limits is not None,
-                                                  device=dev, chunk_steps=data.chunk_steps, stats=self.ingest_stats, inflate=data.inflate,
-                                                  t_range=None if shard is None else (t0, t1), merge_dropmask=merge, out=out, keep_level=keep)
+            with ingest.refusals():       # (what --ingest auto may fall back from: an input the streamed path declines, nothing later)
+                self.result: LECResult = ingest.lec_streamed(data.raw, data.plan, variable_list_df, limits, per_step_boxes=boxes_limits is not None,
+                                                             device=dev, chunk_steps=data.chunk_steps, stats=self.ingest_stats, inflate=data.inflate,
+                                                             t_range=None if shard is None else (t0, t1), merge_dropmask=merge, out=out, keep_level=keep)
             self.level_slices = self.ingest_stats.pop("level_slices", None)
         else:
             self.result = self._compute_resident(data, variable_list_df, dev, dTdt, merge, out)

@@ -39,10 +39,19 @@ class ChunkTable:
     (round 5: the dict cost 0.3 s of a 1.8-s run, profiles/r05_notes.md section 8)."""
 
     def __init__(self, offs: np.ndarray, a: np.ndarray, b: np.ndarray, c: np.ndarray, chunk, shape):
-        self.offs = np.ascontiguousarray(offs, dtype=np.int64)
-        self.a, self.b, self.c = (np.asarray(x) for x in (a, b, c))
         self.chunk = tuple(int(x) for x in chunk)
         self.counts = tuple(-(-int(s) // c) for s, c in zip(shape, self.chunk))
+        offs = np.asarray(offs, dtype=np.int64).reshape(-1, len(self.chunk))
+        a, b, c = (np.asarray(x) for x in (a, b, c))
+        # a B-tree may still list chunks beyond the dataset's CURRENT extent (an unlimited dimension that was shrunk): they hold no
+        # element of the dataset and are ignored, as the dict of the small-file paths never looked them up (and they do not count as
+        # "written" chunks: __len__)
+        g = offs // np.array(self.chunk, dtype=np.int64) if len(offs) else offs
+        inside = ((g >= 0) & (g < np.array(self.counts, dtype=np.int64))).all(axis=1) if len(offs) else np.zeros(0, dtype=bool)
+        if not inside.all():
+            offs, a, b, c = offs[inside], a[inside], b[inside], c[inside]
+        self.offs = np.ascontiguousarray(offs, dtype=np.int64)
+        self.a, self.b, self.c = a, b, c
         self._index = None
 
     def __len__(self):

@@ -63,6 +63,24 @@ class StreamedDataset:
     names = property(lambda self: self.raw.names)
 
 
+class StreamedRefusal(ValueError):
+    """The streamed device path declined an input (a layout it does not read, a framework it does not serve ...): raised by
+    ``refusals()`` around ``prepare_streamed`` / ``lec_streamed`` only, so that ``--ingest auto`` can fall back to the host preparation
+    for exactly these and for nothing that goes wrong later in a run (engine, CSV writing).  ``__cause__`` is the original error."""
+
+
+class refusals:
+    """Context manager: a ValueError / NotImplementedError raised inside becomes a ``StreamedRefusal`` (same message, chained)."""
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, etype, e, tb):
+        if etype is not None and issubclass(etype, (ValueError, NotImplementedError)) and not issubclass(etype, StreamedRefusal):
+            raise StreamedRefusal(f"{etype.__name__}: {e}") from e
+        return False
+
+
 def prepare_streamed(args, varlist: str = "inputs/namelist", app_logger=None, chunk_steps: Optional[int] = None, raw=None) -> StreamedDataset:
     """prepare_data (preprocessing.py:374-413) for the device ingest: validates the file against the namelist and builds
     the index maps; no field data is read here.  ``raw``: the file already opened (``prefers_device_ingest(..., keep_open=True)``: the
@@ -605,9 +623,11 @@ def storage_dtypes(rvars) -> tuple:
 
 
 def _ingest_call(lib, v: ds.RawVariable, src_ptr: int, nt: int, geom, maps, unit: float, decode_dtype, out_dtype, out_ptr: int, stream,
-                 step: Optional[torch.Tensor] = None, step_base: int = 0):
+                 step: Optional[torch.Tensor] = None, step_base: int = 0, nt_src: int = 0):
     """``step``: int32 [nt, 3] on the device -- per output step {source step, latitude offset, longitude offset} into the maps
-    (``lec_ingest_args.step_d``: a box-packed series); ``step_base``: the source step ``src_ptr`` starts with."""
+    (``lec_ingest_args.step_d``: a box-packed series); ``step_base``: the source step ``src_ptr`` starts with, ``nt_src``: the steps it
+    holds (with the maps' lengths: what bounds the table's entries on the device).  ``LEC_CHECK_TABLES=1`` (debug runs of the Python
+    host): ``lec_check_maps`` scans the maps and the table before every call -- synchronous, so not the default."""
     nl_in, ny_in, nx_in, nl, ny, nx = geom
     kmap, jmap, imap = maps
     ga = _lib.IngestArgs(
@@ -619,7 +639,11 @@ def _ingest_call(lib, v: ds.RawVariable, src_ptr: int, nt: int, geom, maps, unit
         fill_value=0.0 if v.fill_value is None else v.fill_value, unit_scale=float(unit),
         out_dtype=_lec_code(out_dtype), decode_dtype=_lec_code(decode_dtype),
         out_d=C.c_void_p(out_ptr), stream=C.c_void_p(stream.cuda_stream),
-        step_d=None if step is None else C.c_void_p(step.data_ptr()), step_base=int(step_base), reserved0=0)
+        step_d=None if step is None else C.c_void_p(step.data_ptr()), step_base=int(step_base), nt_src=int(nt_src),
+        jmap_len=0 if step is None else int(jmap.numel()), imap_len=0 if step is None else int(imap.numel()))
+    if os.environ.get("LEC_CHECK_TABLES", "0") == "1":
+        status = torch.empty(4, dtype=torch.int32, device=kmap.device)
+        _lib.check(lib.lec_check_maps(C.byref(ga), C.c_void_p(status.data_ptr())), "lec_check_maps")
     _lib.check(lib.lec_ingest(C.byref(ga)), "lec_ingest")
 
 
@@ -906,7 +930,8 @@ def lec_streamed(raw: ds.RawDataset, plan: IngestPlan, variable_list_df, boxes_l
                     unit = 1.0 if r == geo_role else ds.field_scale(variable_list_df, r)
                     for key, shift in [(keys[r], 0)] + ([("tm", -1), ("tp", 1)] if r == "Air Temperature" else []):
                         _ingest_call(lib, rvars[r], stagers[r].raw_dev[slot][0].data_ptr(), n, geom, maps, unit, decode[r], common,
-                                     cubes[key][0].data_ptr(), compute, step=step_tab[shift][s0:s1], step_base=h0)
+                                     cubes[key][0].data_ptr(), compute, step=step_tab[shift][s0:s1], step_base=h0,
+                                     nt_src=int(stagers[r].raw_dev[slot].shape[0]))
                 if keep is not None:            # the diagnostics' level of u, v, Phi over the whole crop: one gather of that level per field
                     kmap1 = maps[0][k_keep: k_keep + 1]
                     for r, k in (("Eastward Wind Component", "u"), ("Northward Wind Component", "v"), (geo_role, "geopt")):

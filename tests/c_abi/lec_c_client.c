@@ -115,6 +115,20 @@ int main(int argc, char** argv) {
         maps[4] = 3;
         CHECK_HIP(hipMemcpy(maps_d, maps, sizeof maps, hipMemcpyHostToDevice));
         if (lec_check_maps(&ga, status) != LEC_OK) { fprintf(stderr, "lec_check_maps: %s\n", lec_last_error()); return 13; }
+        /* ABI 10: a per-step gather table (step_d: {source step, latitude offset, longitude offset} per output step) is device memory
+         * too; the call carries what bounds it (nt_src, jmap_len, imap_len) and the same scan walks it: a good table, then one whose
+         * second step names a source step the source does not hold */
+        int32_t steps[6] = {7, 0, 0,   8, 1, 0};        /* two output steps of one row x one column out of a 2-step source that starts with step 7 */
+        int32_t* steps_d;
+        CHECK_HIP(hipMalloc((void**)&steps_d, sizeof steps));
+        CHECK_HIP(hipMemcpy(steps_d, steps, sizeof steps, hipMemcpyHostToDevice));
+        ga.nt = 2; ga.ny = 1; ga.step_d = steps_d; ga.step_base = 7; ga.nt_src = 2; ga.jmap_len = 2; ga.imap_len = 1;
+        if (lec_check_maps(&ga, status) != LEC_OK) { fprintf(stderr, "lec_check_maps (step table): %s\n", lec_last_error()); return 14; }
+        steps[3] = 9;
+        CHECK_HIP(hipMemcpy(steps_d, steps, sizeof steps, hipMemcpyHostToDevice));
+        if (lec_check_maps(&ga, status) != LEC_ERR_ARG || strstr(lec_last_error(), "step_d[1]") == NULL) {
+            fprintf(stderr, "lec_check_maps missed a bad step entry: %s\n", lec_last_error()); return 15;
+        }
     }
     if (lec_rowstats(&ra) != LEC_OK) { fprintf(stderr, "lec_rowstats: %s\n", lec_last_error()); return 6; }
 

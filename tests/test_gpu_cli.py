@@ -233,6 +233,22 @@ def test_ingest_auto_falls_back_to_the_host_preparation(workdir, monkeypatch):
     assert "whose chunks the GPU can inflate" in log and "simulated refusal" in log and "preparing the data on the host instead" in log
     with pytest.raises(ValueError, match="simulated refusal"):
         _main([src, "-r", "-f", "--ingest", "device"])
+    # ... but only a REFUSAL of the streamed path falls back: an error later in the run (here: while the tables are written, after the
+    # engine has returned) is an error -- no second analysis on the host
+    monkeypatch.undo()
+    import lorenzcycletoolkit as cli
+    from lorenzcycletoolkit_amd import frameworks
+    host_runs = []
+    real_prepare = cli.prepare_data
+    monkeypatch.setattr(cli, "prepare_data", lambda *a, **k: (host_runs.append(1), real_prepare(*a, **k))[1])
+
+    def broken(*a, **k):
+        raise ValueError("simulated failure while writing the tables")
+    monkeypatch.setattr(frameworks, "format_level_table", broken)
+    shutil.rmtree(out)
+    with pytest.raises(ValueError, match="while writing the tables"):
+        _main([src, "-r", "-f"])
+    assert not host_runs
 
 
 def _write_era5_style(path, nt=6):

@@ -157,3 +157,52 @@ def test_device_side_index_checks_through_ctypes():
     assert lib.lec_check_maps(C.byref(ga), status.data_ptr()) == 0
     ga.ny_in = 5
     assert lib.lec_check_maps(C.byref(ga), status.data_ptr()) == 1 and b"jmap_d[0]" in lib.lec_last_error()
+
+
+def test_a_per_step_gather_table_is_bounds_checked_on_the_device():
+    """ABI 10: lec_ingest_args.step_d lives in device memory, where argument validation cannot see it (the reference bounds-checks its
+    track against the data on the host: lec_moving_framework.py:112-154).  lec_check_maps scans it and names the first bad entry;
+    lec_ingest itself never reads through a bad entry -- that output step's rows come out NaN, the others are gathered as always."""
+    lib = _lib.load()
+    status = torch.zeros(4, dtype=torch.int32, device=DEV)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    nt_src, nl, ny_in, nx_in, ny, nx = 3, 2, 6, 7, 2, 3
+    src = torch.arange(nt_src * nl * ny_in * nx_in, dtype=torch.float32, device=DEV).reshape(nt_src, nl, ny_in, nx_in)
+    up = lambda a: torch.tensor(a, dtype=torch.int32, device=DEV)
+    kmap, jmap, imap = up([0, 1]), up([0, 1, 2, 3, 4, 5]), up([0, 1, 2, 3, 4, 5, 6])
+    good = [[10, 0, 0], [11, 4, 4], [12, 2, 1], [10, 3, 2]]              # {source step (the source starts with step 10), latitude offset, longitude offset}
+    out = torch.zeros((4, nl, ny, nx), dtype=torch.float32, device=DEV)
+
+    def args(table):
+        t = up(table)
+        return t, _lib.IngestArgs(src_d=src.data_ptr(), src_dtype=_lib.LEC_F32, nt=len(table), nl_in=nl, ny_in=ny_in, nx_in=nx_in, nl=nl, ny=ny, nx=nx,
+                                  kmap_d=kmap.data_ptr(), jmap_d=jmap.data_ptr(), imap_d=imap.data_ptr(), unit_scale=1.0, out_dtype=_lib.LEC_F32,
+                                  decode_dtype=_lib.LEC_F32, out_d=out.data_ptr(), stream=stream, step_d=t.data_ptr(), step_base=10, nt_src=nt_src,
+                                  jmap_len=6, imap_len=7)
+
+    t, ga = args(good)
+    assert lib.lec_check_maps(C.byref(ga), status.data_ptr()) == 0, lib.lec_last_error()
+    assert lib.lec_ingest(C.byref(ga)) == 0
+    torch.cuda.synchronize()
+    for i, (ts, oj, oi) in enumerate(good):
+        assert torch.equal(out[i], src[ts - 10, :, oj:oj + ny, oi:oi + nx])
+    for bad, what in (([[10, 0, 0], [13, 0, 0]], b"step_d[1]"),           # a source step past the source
+                      ([[9, 0, 0], [10, 0, 0]], b"step_d[0]"),            # ... before it
+                      ([[10, 0, 0], [10, 1, 0], [10, 5, 0]], b"step_d[2]"),      # latitude offset + ny past the map
+                      ([[10, 0, 5]], b"step_d[0]"), ([[10, -1, 0]], b"step_d[0]")):
+        t, ga = args(bad)
+        assert lib.lec_check_maps(C.byref(ga), status.data_ptr()) == 1 and what in lib.lec_last_error() and b"maps themselves are fine" in lib.lec_last_error(), bad
+        out.fill_(7.0)
+        assert lib.lec_ingest(C.byref(ga)) == 0
+        torch.cuda.synchronize()
+        nbad = int(what[7:-1])
+        for i, (ts, oj, oi) in enumerate(bad):
+            if i == nbad:
+                assert bool(torch.isnan(out[i]).all())
+            else:
+                assert torch.equal(out[i], src[ts - 10, :, oj:oj + ny, oi:oi + nx])
+    # a bad MAP entry is still named before the table
+    jbad = up([0, 1, 2, 3, 4, 6])
+    t, ga = args(good)
+    ga.jmap_d = jbad.data_ptr()
+    assert lib.lec_check_maps(C.byref(ga), status.data_ptr()) == 1 and b"jmap_d[5]" in lib.lec_last_error()

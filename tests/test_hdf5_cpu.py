@@ -389,3 +389,17 @@ def test_chunk_table_answers_like_the_dict_it_replaces():
     assert isinstance(st, hdf5_lite.ChunkTable) and len(st) == len(table)
     k = some[-1]
     assert st[k][0] == as_dict[k][0] + h.base and st[k][1] == as_dict[k][1] - (4 if info["fletcher32"] else 0) and isinstance(st[k][2], bool)
+
+
+def test_chunk_table_ignores_entries_beyond_the_datasets_extent():
+    """A v1 B-tree may still list chunks past the dataset's current extent (an unlimited dimension that was shrunk; an index that was
+    never compacted).  They hold no element of the dataset: the table drops them -- no error from the index construction, and they do
+    not count as written chunks -- exactly as the dict of the small-file paths never looked them up."""
+    offs = np.array([[0, 0], [0, 4], [2, 0], [2, 4], [4, 0], [0, 8], [-2, 0]])          # the last three lie outside a 4 x 8 dataset cut in 2 x 4 chunks
+    t = hdf5_lite.ChunkTable(offs, np.arange(7) + 100, np.arange(7) + 200, np.zeros(7, dtype=np.int64), (2, 4), (4, 8))
+    assert len(t) == 4 and set(t.keys()) == {(0, 0), (0, 4), (2, 0), (2, 4)}
+    assert t[(2, 4)] == (103, 203, 0) and t.get((4, 0)) is None and (0, 8) not in t
+    a, b, c = t.lookup(np.array([[2, 0], [0, 4]]))
+    assert a.tolist() == [102, 101] and b.tolist() == [202, 201]
+    empty = hdf5_lite.ChunkTable(np.zeros((0, 2), dtype=np.int64), np.zeros(0), np.zeros(0), np.zeros(0), (2, 4), (4, 8))
+    assert len(empty) == 0 and empty.get((0, 0)) is None
