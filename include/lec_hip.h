@@ -75,7 +75,9 @@ enum lec_kernel {
     LEC_KERNEL_TWO_SWEEP = 1,  /* lec_rowstats.hip: the reference's own order (deviation from the zonal mean, then products); rows <= lec_max_row() */
     LEC_KERNEL_ROW_SWEEP = 2,  /* lec_rowsweep.hip: one wave per row, one sweep */
     LEC_KERNEL_ROW_BLOCK = 3,  /* lec_rowblock.hip: blocks of neighbouring rows exchange T through LDS (all terms, one fixed box, dT/dt from the cube) */
-    LEC_KERNEL_BOX_TILE = 4    /* lec_boxtile.hip: one wave per four box rows walks the levels; six values per point transposed through LDS */
+    LEC_KERNEL_BOX_TILE = 4,   /* lec_boxtile.hip: one wave per four box rows walks the levels; six values per point transposed through LDS */
+    LEC_KERNEL_BOX_PLANE = 5   /* lec_boxplane.hip (ABI 10): the same rows and sums with the planes brought into LDS by DMA -- a box-packed fp64 series with a
+                                  dT/dt cube on even longitudes, slabs of at most 64 columns (what LEC_KERNEL_AUTO picks there; bit-identical records) */
 };
 
 /* workgroup -> row order of the row kernels (speed only) */

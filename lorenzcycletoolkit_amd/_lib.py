@@ -19,7 +19,7 @@ LEC_NLEVFUN = 28
 LEC_F64, LEC_F32, LEC_I16, LEC_I32, LEC_I8 = 0, 1, 2, 3, 4
 
 # enum lec_kernel / enum lec_order (include/lec_hip.h)
-KERNEL_AUTO, KERNEL_TWO_SWEEP, KERNEL_ROW_SWEEP, KERNEL_ROW_BLOCK, KERNEL_BOX_TILE = 0, 1, 2, 3, 4
+KERNEL_AUTO, KERNEL_TWO_SWEEP, KERNEL_ROW_SWEEP, KERNEL_ROW_BLOCK, KERNEL_BOX_TILE, KERNEL_BOX_PLANE = 0, 1, 2, 3, 4, 5
 ORDER_AUTO, ORDER_MEMORY, ORDER_XCD_LAT, ORDER_XCD_TILED = 0, 1, 2, 7
 
 

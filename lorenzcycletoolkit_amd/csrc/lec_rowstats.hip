@@ -305,6 +305,8 @@ int lec_launch_rowsweep(const lec::RowParams& p, int dtype, bool aligned, bool a
 int lec_launch_rowblock(lec::RowParams p, int dtype, bool aligned, bool aligned8, bool uniform, int bt, int bk, int bj, hipStream_t st);
 int lec_launch_boxtile(const lec::RowParams& p, int dtype, bool uniform, int mode, int tg, hipStream_t st);
 int lec_launch_qtime(const lec::RowParams& p, hipStream_t st);
+bool lec_boxplane_serves(const lec::RowParams& p, int dtype, bool uniform, int mode);
+int lec_launch_boxplane(lec::RowParams p, hipStream_t st);
 
 extern "C" int lec_max_row(int dtype, int aligned, int kernel) {
     (void)dtype;
@@ -338,14 +340,14 @@ extern "C" int lec_rowstats(const lec_rowstats_args* a) {
             return lec_set_error(LEC_ERR_ARG, "lec_rowstats: tm_d / tp_d go with box_per_step, with_q, tcoef_d and no dTdt_d");
     }
     const lec_tuning& tu = a->tuning;
-    if (tu.kernel < LEC_KERNEL_AUTO || tu.kernel > LEC_KERNEL_BOX_TILE) return lec_set_error(LEC_ERR_ARG, "lec_rowstats: tuning.kernel is not an enum lec_kernel value");
+    if (tu.kernel < LEC_KERNEL_AUTO || tu.kernel > LEC_KERNEL_BOX_PLANE) return lec_set_error(LEC_ERR_ARG, "lec_rowstats: tuning.kernel is not an enum lec_kernel value");
     if (tu.order != LEC_ORDER_AUTO && tu.order != LEC_ORDER_MEMORY && tu.order != LEC_ORDER_XCD_LAT && tu.order != LEC_ORDER_XCD_TILED)
         return lec_set_error(LEC_ERR_ARG, "lec_rowstats: tuning.order is not an enum lec_order value");
     if (tu.tile_t < 0 || tu.tile_j < 0) return lec_set_error(LEC_ERR_ARG, "lec_rowstats: tuning.tile_t / tile_j must be >= 0 (0 = default)");
     if (tu.f32_vec != 0 && tu.f32_vec != 2) return lec_set_error(LEC_ERR_ARG, "lec_rowstats: tuning.f32_vec must be 0 or 2");
     if (tu.reserved[0] || tu.reserved[1]) return lec_set_error(LEC_ERR_ARG, "lec_rowstats: tuning.reserved must be 0");
     int bt = 2, bk = 1, bj = 2;
-    const bool tile_call = tu.kernel == LEC_KERNEL_BOX_TILE || (tu.kernel == LEC_KERNEL_AUTO && a->box_per_step);
+    const bool tile_call = tu.kernel == LEC_KERNEL_BOX_TILE || tu.kernel == LEC_KERNEL_BOX_PLANE || (tu.kernel == LEC_KERNEL_AUTO && a->box_per_step);
     if (tile_call) {         // the box-tile kernel reads block_shape as the time steps per workgroup (0 = default)
         if (tu.block_shape != 0 && tu.block_shape != 1 && tu.block_shape != 2 && tu.block_shape != 4)
             return lec_set_error(LEC_ERR_ARG, "lec_rowstats: tuning.block_shape of a box-tile call (time steps per workgroup) must be 0, 1, 2 or 4");
@@ -424,13 +426,21 @@ extern "C" int lec_rowstats(const lec_rowstats_args* a) {
         if (nblocks > 0x7fffffffLL) { p.order = 0; nblocks = nrows; }
         if (a->dtype == LEC_F64) rc = aligned ? launch_vec<double, 2>(p, uni, wq, (int)nblocks, st) : launch_vec<double, 1>(p, uni, wq, (int)nblocks, st);
         else                     rc = aligned ? launch_vec<float, 4>(p, uni, wq, (int)nblocks, st) : launch_vec<float, 1>(p, uni, wq, (int)nblocks, st);
-    } else if (kernel == LEC_KERNEL_BOX_TILE) {
+    } else if (kernel == LEC_KERNEL_BOX_TILE || kernel == LEC_KERNEL_BOX_PLANE) {
         // Q per point (modes 1 / 2): the time neighbours of a moving box sum over other boxes, so the cross-time covariance
         // form of mode 3 does not apply
         RowParams pt = p;
         pt.tgroup = tu.tile_t;                              // time steps per tile group; 0 = the kernel's default (8)
         pt.jgroup = tu.tile_j;                              // levels per wave; 0 = chosen from the launch size
-        rc = lec_launch_boxtile(pt, a->dtype, uni, wq, tu.block_shape, st);
+        // a box-packed fp64 series with its dT/dt cube (what every -t path of the product hands over for fp64 data): the planes come into
+        // LDS by DMA (lec_boxplane.hip).  Decided by the kind of call and the slabs' shape, so every shard and chunk of a series agrees;
+        // the records are bit-identical to the box-tile kernel's anyway (tested)
+        const bool plane_ok = a->box_per_step && tu.block_shape <= 1 && lec_boxplane_serves(pt, a->dtype, uni, wq);
+        if (kernel == LEC_KERNEL_BOX_PLANE && !plane_ok)
+            return lec_set_error(LEC_ERR_ARG, "lec_rowstats: LEC_KERNEL_BOX_PLANE serves per-step boxes in fp64 storage with a dT/dt cube and geopotential on even "
+                                              "longitudes, cubes at most 64 columns wide");
+        if (plane_ok && (kernel == LEC_KERNEL_BOX_PLANE || tu.kernel == LEC_KERNEL_AUTO)) rc = lec_launch_boxplane(pt, st);
+        else rc = lec_launch_boxtile(pt, a->dtype, uni, wq, tu.block_shape, st);
     } else {
         // Single-sweep row kernels.  All terms with dT/dt from the cube on one fixed box (the headline configuration, mode 3): a
         // row reads T(t+1) only and the time-derivative parts of [Q], [Q'T'] are completed from the records afterwards
@@ -445,7 +455,7 @@ extern "C" int lec_rowstats(const lec_rowstats_args* a) {
         }
         if (rc == LEC_OK && mode == 3) rc = lec_launch_qtime(p, st);
     }
-    if (rc == LEC_ERR_ARG) return lec_set_error(rc, "lec_rowstats: tuning.tile_j: the box-tile kernel walks at most 21 levels per wave");
+    if (rc == LEC_ERR_ARG) return lec_set_error(rc, "lec_rowstats: tuning.tile_j: the box-tile / box-plane kernels walk at most 21 levels per wave");
     if (rc != LEC_OK) return lec_set_error(rc, "lec_rowstats: row too long for the compiled kernels");
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return lec_set_error(LEC_ERR_LAUNCH, hipGetErrorString(e));

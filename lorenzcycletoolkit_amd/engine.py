@@ -43,12 +43,12 @@ def _ptr(t: Optional[torch.Tensor]):
 
 
 _KERNELS = {"auto": _lib.KERNEL_AUTO, "two_sweep": _lib.KERNEL_TWO_SWEEP, "row_sweep": _lib.KERNEL_ROW_SWEEP,
-            "row_block": _lib.KERNEL_ROW_BLOCK, "box_tile": _lib.KERNEL_BOX_TILE}
+            "row_block": _lib.KERNEL_ROW_BLOCK, "box_tile": _lib.KERNEL_BOX_TILE, "box_plane": _lib.KERNEL_BOX_PLANE}
 _ORDERS = {"auto": _lib.ORDER_AUTO, "memory": _lib.ORDER_MEMORY, "xcd_lat": _lib.ORDER_XCD_LAT, "xcd_tiled": _lib.ORDER_XCD_TILED}
 
 
 def make_tuning(tuning: Optional[dict]) -> "_lib.Tuning":
-    """``lec_tuning`` from a dict with any of: kernel ("auto" | "two_sweep" | "row_sweep" | "row_block" | "box_tile"),
+    """``lec_tuning`` from a dict with any of: kernel ("auto" | "two_sweep" | "row_sweep" | "row_block" | "box_tile" | "box_plane"),
     block_shape (e.g. 212), order ("auto" | "memory" | "xcd_lat" | "xcd_tiled"), tile_t, tile_j, f32_vec.
     None / {} = the library's defaults (what is measured and shipped); the rest is for cross-checks and A/B runs."""
     t = _lib.Tuning()

@@ -6,7 +6,7 @@ NAME=$1; DEFS=$2
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 B=/tmp/lec_variant_$NAME; rm -rf $B; mkdir -p $B
 cd $ROOT/lorenzcycletoolkit_amd/csrc
-for f in lec_common lec_rowstats lec_rowsweep lec_rowblock lec_boxtile lec_reduce lec_ingest lec_diag lec_check lec_hostio lec_inflate lec_format; do
+for f in lec_common lec_rowstats lec_rowsweep lec_rowblock lec_boxtile lec_boxplane lec_reduce lec_ingest lec_diag lec_check lec_hostio lec_inflate lec_format; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -Werror=pass-failed $DEFS -c $f.hip -o $B/$f.o &
 done
 wait

@@ -1,0 +1,28 @@
+"""Where do lec_boxplane's records differ from lec_boxtile's?  (debug tool)"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np, torch
+from tests.helpers import synthetic_domain
+from lorenzcycletoolkit_amd.engine import LECEngine
+
+nt, nl = int(sys.argv[1]) if len(sys.argv) > 1 else 3, int(sys.argv[2]) if len(sys.argv) > 2 else 7
+dom = synthetic_domain(nt, nl, 100, 140, seed=61)
+boxes = [(20 + t, 80 + t, 15 + (t // 2), 75 + (t // 2)) for t in range(nt)]
+eng = LECEngine(dom.lat, dom.lon, dom.level, device="cuda:0")
+f = [torch.as_tensor(np.ascontiguousarray(a)).to("cuda:0") for a in (dom.tair, dom.u, dom.v, dom.omega, dom.geopt)]
+tc = eng.time_coefs_device(dom.time_s)
+ps = eng.pack_series(*f, boxes, tc)
+pb = eng.prepare_boxes(boxes, packed=True)
+kw = dict(dTdt=ps["dTdt"], per_step_boxes=True)
+a = eng.rowstats(ps["tair"], ps["u"], ps["v"], ps["omega"], ps["geopt"], pb, tuning={"kernel": "box_tile"}, **kw)
+b = eng.rowstats(ps["tair"], ps["u"], ps["v"], ps["omega"], ps["geopt"], pb, tuning={"kernel": "box_plane"}, **kw)
+torch.cuda.synchronize()
+d = (a != b) & ~(torch.isnan(a) & torch.isnan(b))
+print("shape", tuple(a.shape), "differing", int(d.sum()), "of", d.numel())
+print("by stat :", d.sum(dim=(0, 1, 2)).tolist())
+print("by level:", d.sum(dim=(0, 2, 3)).tolist())
+print("by row  :", d.sum(dim=(0, 1, 3)).tolist())
+print("by step :", d.sum(dim=(1, 2, 3)).tolist())
+idx = d.nonzero()[:12]
+for t, k, j, s in idx.tolist():
+    print((t, k, j, s), float(a[t, k, j, s]), float(b[t, k, j, s]), "rel", abs(float(a[t, k, j, s]) - float(b[t, k, j, s])) / max(abs(float(a[t, k, j, s])), 1e-300))

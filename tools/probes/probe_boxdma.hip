@@ -24,6 +24,21 @@ __device__ __forceinline__ void dma16(const void* gbase, unsigned voff, unsigned
     const unsigned long long sb = ((unsigned long long)hi << 32) | lo;
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(lds_addr), "v"(voff), "s"(sb) : "memory");
 }
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4_t run_resource(const void* first_byte, unsigned bytes) {
+    const unsigned long long b = (unsigned long long)first_byte;
+    u32x4_t r;
+    r.x = __builtin_amdgcn_readfirstlane((unsigned)b);
+    r.y = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32)) & 0xffffu;
+    r.z = __builtin_amdgcn_readfirstlane(bytes);
+    r.w = 0x00020000u;
+    return r;
+}
+template <bool NTB>
+__device__ __forceinline__ void bdma16(u32x4_t run, unsigned voff, unsigned soff, unsigned lds_addr) {
+    if (NTB) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen nt lds" :: "s"(lds_addr), "v"(voff), "s"(run), "s"(soff) : "memory");
+    else     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(lds_addr), "v"(voff), "s"(run), "s"(soff) : "memory");
+}
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
 template <int RB> constexpr int pieces_T() { return ((RB + 2) * NB * 8 + 1023) / 1024; }
@@ -67,6 +82,54 @@ __global__ void __launch_bounds__(64) probe(const P p) {
 #pragma unroll
             for (int i = 0; i < NR; ++i) acc += b[i];
         }
+    } else if (MODE == 4) {
+        static_assert(MODE != 4 || RB == 4, "the compute layout is 4 rows x 16 column groups");
+        constexpr int kT = pieces_T<RB>() * 1024;
+        const unsigned lds0 = (unsigned)(uintptr_t)sm;
+        const int ci = lane >> 4, cg = lane & 15;
+        const int rowc = min(r0 + ci, NB - 1), c0 = min(4 * cg, NB - 4);        // (the last group reads columns 57..60)
+        dbl2 a[10], b[10];
+        auto issue_T = [&](int buf, int k) {
+            const size_t pl = ((size_t)tl * NL + k) * kPlane;
+            const u32x4_t rt = run_resource(p.f[0] + pl + (size_t)h0 * NB, (unsigned)((h1 - h0) * NB * 8));
+#pragma unroll
+            for (int i = 0; i < pieces_T<RB>(); ++i) bdma16<false>(rt, 16u * lane, 1024u * i, lds0 + buf * kT + 1024u * i);
+        };
+        auto issue_F = [&](dbl2 (&d)[10], int k) {
+            const size_t pl = ((size_t)tl * NL + k) * kPlane + (size_t)rowc * NB + c0;
+#pragma unroll
+            for (int f = 1; f < NF; ++f) {
+                const dbl2* g = reinterpret_cast<const dbl2*>(p.f[f] + pl);
+                d[2 * (f - 1)] = NT ? __builtin_nontemporal_load(g) : *g;
+                d[2 * (f - 1) + 1] = NT ? __builtin_nontemporal_load(g + 1) : g[1];
+            }
+        };
+        // vmcnt bookkeeping is ours for the DMA pieces; the register loads are the compiler's: keep the two apart by draining the
+        // DMA of a level before the compiler-visible loads of the next are consumed (in order: DMA(k+1), loads(k+1) issued together)
+        issue_T(0, k0); issue_F(a, k0);
+        for (int kk = 0; kk < nk; kk += 2) {
+            issue_T(1, min(k0 + kk + 1, k0 + nk - 1)); issue_F(b, min(k0 + kk + 1, k0 + nk - 1));
+            {
+                const double* s = sm;
+#pragma unroll
+                for (int i = 0; i < 10; ++i) acc += a[i].x + a[i].y;
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(pieces_T<RB>() + 10) : "memory");
+#pragma unroll
+                for (int i = 0; i < 6; ++i) acc += s[i * 64 + lane];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            }
+            issue_T(0, min(k0 + kk + 2, k0 + nk - 1)); issue_F(a, min(k0 + kk + 2, k0 + nk - 1));
+            {
+                const double* s = sm + kT / 8;
+#pragma unroll
+                for (int i = 0; i < 10; ++i) acc += b[i].x + b[i].y;
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(pieces_T<RB>() + 10) : "memory");
+#pragma unroll
+                for (int i = 0; i < 6; ++i) acc += s[i * 64 + lane];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            }
+        }
+        wait_vm<0>();
     } else if (MODE == 1) {
         constexpr int NP = pieces_level<RB>();
         dbl2 a[NP], b[NP];
@@ -105,6 +168,18 @@ __global__ void __launch_bounds__(64) probe(const P p) {
             const size_t pl = ((size_t)tl * NL + k) * kPlane;
             const int bT = (h1 - h0) * NB * 8, bF = (r1 - r0) * NB * 8;      // bytes
             unsigned dst = lds0 + buf * kBuf;
+            if (MODE == 3) {        // lec_boxplane.hip's form: buffer loads whose resource is the run (no clamping; T default policy, the rest nt)
+                const u32x4_t rt = run_resource(p.f[0] + pl + (size_t)h0 * NB, (unsigned)bT);
+#pragma unroll
+                for (int i = 0; i < pieces_T<RB>(); ++i) { bdma16<false>(rt, 16u * lane, 1024u * i, dst); dst += 1024; }
+#pragma unroll
+                for (int f = 1; f < NF; ++f) {
+                    const u32x4_t rf = run_resource(p.f[f] + pl + (size_t)r0 * NB, (unsigned)bF);
+#pragma unroll
+                    for (int i = 0; i < pieces_F<RB>(); ++i) { bdma16<NT>(rf, 16u * lane, 1024u * i, dst); dst += 1024; }
+                }
+                return;
+            }
             const char* gT = reinterpret_cast<const char*>(p.f[0] + pl + (size_t)h0 * NB);
 #pragma unroll
             for (int i = 0; i < pieces_T<RB>(); ++i) {
@@ -143,7 +218,7 @@ void run(const P& p, int waves_per_cu) {
     const int tchunk = (p.T + 7) / 8, nrb = (NB + RB - 1) / RB, nkc = (NL + KC - 1) / KC;
     dim3 grid(8 * tchunk * nrb * nkc), block(64);
     size_t lds = (size_t)(160 * 1024 / waves_per_cu) - 512;
-    const size_t need = MODE == 2 ? (size_t)2 * pieces_level<RB>() * 1024 : 8;
+    const size_t need = MODE == 4 ? (size_t)2 * pieces_T<RB>() * 1024 : MODE >= 2 ? (size_t)2 * pieces_level<RB>() * 1024 : 8;
     if (lds < need) { printf("  mode %d rows %2d: %d waves per CU do not fit (%zu B of LDS per wave needed)\n", MODE, RB, waves_per_cu, need); return; }
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&probe<MODE, RB, KC, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -157,7 +232,7 @@ void run(const P& p, int waves_per_cu) {
     ms /= reps;
     const double gb6 = (double)p.T * NL * NB * NB * 8 * 6 / 1e9, gb5 = gb6 * 5 / 6;
     hipFuncAttributes fa; CK(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&probe<MODE, RB, KC, NT>)));
-    static const char* names[] = {"rows 8 B/lane -> regs", "flat 16 B/lane -> regs", "flat 16 B/lane LDS-DMA"};
+    static const char* names[] = {"rows 8 B/lane -> regs", "flat 16 B/lane -> regs", "flat 16 B/lane LDS-DMA", "flat LDS-DMA, buffer loads", "T by DMA, rest -> regs (compute layout)"};
     printf("  %-24s %s rows %2d x levels %2d  waves/CU %2d [%3d VGPRs]: %.3f ms  %5.0f GB/s of the six planes  (algorithmic five: %.3f of 8 TB/s)\n",
            names[MODE], NT ? "nt   " : "plain", RB, KC, waves_per_cu, fa.numRegs, ms, gb6 / ms * 1e3, gb5 / ms * 1e3 / 8000.0);
 }
@@ -177,6 +252,10 @@ int main(int argc, char** argv) {
         printf("-- flat pieces by LDS-DMA\n");
         run<2, 4, 19>(p, 4); run<2, 4, 19>(p, 5); run<2, 4, 19>(p, 6);
         run<2, 8, 19>(p, 3); run<2, 8, 10>(p, 3); run<2, 16, 19>(p, 1); run<2, 4, 19, false>(p, 5); run<2, 4, 37>(p, 5); run<2, 4, 10>(p, 5);
+        printf("-- the same by buffer loads (the run as the resource: range-checked, nothing clamped)\n");
+        run<3, 4, 19>(p, 4); run<3, 4, 19>(p, 5); run<3, 4, 19, false>(p, 5); run<3, 4, 10>(p, 5); run<3, 8, 19>(p, 3);
+        printf("-- T by DMA, u v omega Phi dT/dt straight into the compute layout's registers (32 bytes per lane and plane)\n");
+        run<4, 4, 19>(p, 6); run<4, 4, 19>(p, 8); run<4, 4, 19, false>(p, 8); run<4, 4, 19>(p, 12); run<4, 4, 10>(p, 8);
     }
     return 0;
 }
