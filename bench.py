@@ -763,8 +763,9 @@ def measure(args, ctx, cpu_kind="none"):
             except Exception:
                 traffic = None
         if args.moving:
-            kname = ("one lec_rowstats call on a box-packed series (lec_boxplane_kernel where the call is fp64, even longitudes, rows of one column chunk; "
-                     "else lec_boxtile_kernel)" if packed else
+            kname = (("lec_boxplane_kernel (a box-packed fp64 series: one wave per four box rows x a chunk of levels, the planes' rows straight into the "
+                      "layout the sums are taken in)" if (args.storage == "f64" and not args.nonuniform_lon and "box_tile" not in args.tuning)
+                      else "lec_boxtile_kernel on a box-packed series") if packed else
                      "lec_boxtile_kernel (one wave per four box rows x a chunk of levels of a time step; six values per point transposed through LDS)")
         elif args.no_q or args.storage == "f32":
             kname = "lec_rowsweep_kernel (one wave per row)" + ("" if args.no_q else " + lec_qtime_kernel")

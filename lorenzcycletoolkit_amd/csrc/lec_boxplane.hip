@@ -1,36 +1,43 @@
 // lec_boxplane.hip -- stage 1 for a BOX-PACKED series of the moving framework in fp64 storage (include/lec_hip.h: cubes
-// [nt][nl][ny][nx] whose step t holds box t alone, dT/dt as the series' own cube): the data come into LDS by DMA.
+// [nt][nl][ny][nx] whose step t holds box t alone, dT/dt as the series' own cube): the planes' rows go STRAIGHT into the layout the
+// sums are taken in.
 //
 // lec_boxtile.hip was built for row fragments of a track-extent crop: lanes along longitude, one 488-byte box row per wave
-// instruction into registers, the diabatic-heating residual formed there, six values per point transposed through LDS into the
-// compute layout.  On a packed series that kernel is bound by its own instruction stream (profiles/r06_notes.md: 0.82 ms per 512
-// steps, 0.55 without its global loads, 0.48 without loads AND compute layout -- the load layout, the transpose and the sums' hand-over
-// are most of it), while the layout itself streams at 6.2 TB/s (tools/probes/probe_boxdma.hip: 0.54 ms).  In a packed series the rows
-// a wave needs of one (step, level) plane are ONE contiguous run of bytes, so here:
+// instruction, the diabatic-heating residual formed in that layout, six values per point transposed through LDS into the compute
+// layout.  On a packed series that kernel is bound by its own instruction stream (profiles/r06_notes.md: 0.82 ms per 512 steps, 0.55
+// without its global loads, 0.48 without loads AND compute layout: the load layout, the transpose and the hand-over of the sums are
+// most of it), while the layout itself streams at 6.2 TB/s (tools/probes/probe_boxdma.hip: 0.52-0.55 ms).  Here a lane has ONE role
+// -- (row r of the wave's four, columns 4 g .. 4 g + 3), the compute layout of lec_boxtile.hip -- and:
 //
-//   loads          buffer_load_dwordx4 ... lds: 1-KiB pieces of the run straight into LDS (no registers, no ds_write, no address
-//                  arithmetic per row), 13 wave instructions per level -- T with one halo row either side (6 rows), u, v, omega, Phi
-//                  and dT/dt (4 rows each) -- in THREE buffers: the sets of levels k + 1 and k + 2 are in flight while level k is
-//                  computed, waited for with a counted vmcnt.  This access shape needs ~100 KB in flight per CU to stream at the
-//                  part's rate (the probes; double buffering -- one set in flight while a wave computes -- ran at 0.79 ms where the
-//                  bare DMA stream takes 0.52): 4 waves x 2 sets x 13 KB.  The LDS image of a tile IS the memory image (row pitch =
-//                  the slab's nx); a wave's 40 KB of LDS is a quarter of the CU's: one wave per SIMD, registers are plentiful;
-//   one layout     lane (r, g) owns row r of the wave's four and columns 4 g + (0..3) -- the compute layout of lec_boxtile.hip -- and
-//                  reads everything a point needs from the tiles: its five operands, T at i +- 1 and j +- 1 of the SAME tile.  T at
-//                  k +- 1 are the lane's own points one level back and ahead: the T tile runs one level AHEAD of the other five
-//                  (set k = {T(k + 1), u v omega Phi dT/dt (k)}), T(k), T(k - 1) and the horizontal stencils of level k (formed while
-//                  T(k)'s tile was in LDS) wait in registers -- 16 values per lane;
-//   sums           the 20 shifted sums per point, the 16-way hand-over through LDS (in the set that has just been consumed) and the
-//                  row epilogue are lec_boxtile.hip's, expression by expression and in its order.
+//   u v omega Phi dT/dt   need no neighbour: the lane's four points of a plane are 32 contiguous bytes, fetched as two 16-byte buffer
+//                  loads straight into its registers (default cache policy: the two loads of a lane touch the same lines, the second
+//                  hits in L1; with nt the probe runs 18 % slower).  No LDS, no transpose, no load-layout arithmetic.  The resource of
+//                  a load is the run of the wave's rows in that plane, so what lies past it -- the next plane, or nothing at all at the
+//                  cube's end -- reads as zero and is never touched (tools/probes/probe_dma_range.hip);
+//   T              needs i +- 1, j +- 1, k +- 1.  The wave's rows with one halo row either side are ONE contiguous run of the plane
+//                  (6 x 488 bytes): three flat 16-byte-per-lane loads, written to an LDS tile as they lie in memory.  Two tiles
+//                  alternate: T(k) -- a lane reads its points and their four horizontal neighbours -- and T(k + 1) -- its points; T(k - 1)
+//                  at its points waits in four registers, so every T row is loaded once per level chunk;
+//   prefetch       the five planes of level k + 1 are requested before level k's are waited for (two register sets, picked by the level's
+//                  parity at compile time), T's run of level k + 2 as soon as that of k + 1 is in its tile; 8 waves per CU as
+//                  lec_boxtile.hip (the access shape needs ~100 KB in flight per CU to stream at the part's rate: 8 x 13 KB and more);
+//   sums           the 20 shifted sums per point, the 16-way hand-over through LDS and the row epilogue are lec_boxtile.hip's,
+//                  expression by expression and in its order.
+//
+// A first form of this kernel brought all six planes into LDS by LDS-DMA (buffer_load ... lds), three sets deep: bit-identical and no
+// faster than lec_boxtile.hip -- 40 KB of LDS per wave leave one wave per SIMD, and a lone wave cannot hide its own hand-over and
+// epilogue behind its arithmetic (git history, profiles/r06_notes.md section 3).
 //
 // Every expression that decides a bit is the one of lec_boxtile.hip (same products, same rounding points, same summation groups and
 // order: groups of four columns, sixteen groups in order, end points in the epilogue), so the records are BIT-IDENTICAL to that
 // kernel's and results still do not depend on how a series is sharded, chunked or which of the two kernels ran (tested).
 //
-// Serves: fp64 storage, even longitudes, dT/dt as a cube, Phi present, slabs at most 64 columns wide.  Everything else of a
+// Serves: fp64 storage, even longitudes, dT/dt as a cube, Phi present, cubes at most 64 columns wide.  Everything else of a
 // per-step-box call runs on lec_boxtile.hip.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <type_traits>
 
 #include "../../include/lec_hip.h"
 #include "lec_internal.h"
@@ -39,67 +46,50 @@
 
 using namespace lec;
 
-#ifndef LEC_BP_ABLATE       // measurement builds only (tools/build_variant.sh), bit mask: 1 = no arithmetic on the tiles, 2 = no DMA
+#ifndef LEC_BP_ABLATE       // measurement builds only (tools/build_variant.sh), bit mask: 1 = no arithmetic on the points, 2 = no global loads
 #define LEC_BP_ABLATE 0
 #endif
-#ifndef LEC_BP_NT           // cache policy of the once-read planes (u, v, omega, Phi, dT/dt): 1 = nontemporal
-#define LEC_BP_NT 1
+#ifndef LEC_BP_NT           // cache policy of the once-read planes (u, v, omega, Phi, dT/dt): 1 = nontemporal (measured: slower)
+#define LEC_BP_NT 0
 #endif
 
 namespace {
 
 constexpr int kWR = 4;                    // box rows per wave
-constexpr int kMaxW = 64;                 // widest slab (columns) the tiles hold
+constexpr int kMaxW = 64;                 // widest cube (columns) the T tile holds
 constexpr int kSide = 16;                 // per-row side values (lec_boxtile.hip): 5 shifts, f of the first point, a..f and T u v of the last
-constexpr int kLB = 2;                    // levels whose rows are finished together (8 lanes: 2 levels x 4 rows)
-#ifndef LEC_BP_AHEAD
-#define LEC_BP_AHEAD 2                    // sets in flight behind the one being computed (measurement knob: 1 = double buffering)
-#endif
-constexpr int kAhead = LEC_BP_AHEAD;
-constexpr int kBufs = kAhead + 1;
+constexpr int kLB = 4;                    // levels whose rows are finished together (16 lanes: 4 levels x 4 rows)
 constexpr int kPS = 65;                   // stride between the statistics of the partial-sum array
-constexpr int kMaxLevels = 21;            // a wave keeps its chunk's static-stability coefficients one per lane (3 per level)
+constexpr int kMaxLevels = 42;            // a wave keeps its chunk's static-stability coefficients one per lane (3 per level) in two registers
 constexpr int kMinLevels = 5;
-constexpr int kTileT = (kWR + 2) * kMaxW * 8;     // bytes: T with its two halo rows
-constexpr int kTileF = kWR * kMaxW * 8;           // bytes: one of the five other planes
-constexpr int kPiecesT = kTileT / 1024, kPiecesF = kTileF / 1024;
-constexpr int kSet = kTileT + 5 * kTileF;         // one level's set: 13,312 B
-constexpr int kPieces = kPiecesT + 5 * kPiecesF;  // DMA instructions per set: 13
-constexpr int kStashOff = kNA * kPS * 8;          // row totals of kLB levels, behind the partial sums in the consumed set
-constexpr int kLdsBytes = kBufs * kSet + kLB * kWR * kSide * 8;      // three sets + the side values of two levels: 40,960 B = a quarter of a CU's LDS
-static_assert(kTileT % 1024 == 0 && kTileF % 1024 == 0, "tiles are whole 1-KiB pieces");
-static_assert(kStashOff + kLB * kWR * kNA * 8 <= kSet, "the partial sums and the row totals must fit the (consumed) set they alias");
-static_assert(kAhead >= 1 && kAhead <= 2 && kPieces * kAhead + 13 <= 63, "the counted waits must fit vmcnt");
-static_assert(3 * kMaxLevels <= 64, "the level coefficients of a wave's chunk must fit one value per lane");
+constexpr int kTileT = (kWR + 2) * kMaxW;         // doubles: T with its two halo rows, row pitch = the cube's nx
+constexpr int kPiecesT = kTileT * 8 / 1024;       // flat 1-KiB pieces of the T run: 3
+constexpr int kHalf = kNA / 2;                    // the sums are handed over ten statistics at a time
+constexpr int kLdsDoubles = 2 * kTileT + kHalf * kPS + kLB * kWR * (kNA + kSide);       // 15,952 B
+static_assert(kTileT * 8 % 1024 == 0, "the T tile is whole 1-KiB pieces");
+static_assert(3 * kMaxLevels <= 128, "the level coefficients of a wave's chunk must fit one value per lane of two registers");
 
 __device__ __forceinline__ double lane_value(double v, int src) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
 }
 
-// One 1-KiB piece of a run of box rows: lane l's 16 bytes at (run start + soff + 16 l) -> LDS lds_addr + 16 l, by a BUFFER load whose
-// resource is the run itself (base = its first byte, num_records = its length).  The range check is per dword: the piece that straddles
-// the run's end (a run of an odd number of doubles ends in the middle of a lane's 16 bytes) delivers its in-range half and zeros, lanes
-// past the end deliver zeros and touch no memory (tools/probes/probe_dma_range.hip) -- so every lane issues every piece (the vmcnt
-// arithmetic needs a fixed count), nothing is clamped and nothing beyond the run is ever read.  M0 carries the LDS address; the
-// compiler does not see a vector-memory instruction here, so the waits are ours (wait_vm) -- its own counted waits can only over-wait
-// (the counter is in issue order).
+// 16 bytes at (run start + byte_off), as two doubles.  The resource of the load is the run itself (base = its first byte, num_records =
+// its length) and the range check is per dword: what lies past the run reads as zero and is never touched.
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ u32x4_t run_resource(const void* first_byte, unsigned bytes) {
-    const unsigned long long b = (unsigned long long)first_byte;
-    u32x4_t r;
-    r.x = __builtin_amdgcn_readfirstlane((unsigned)b);
-    r.y = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32)) & 0xffffu;      // 48-bit base, stride 0: a raw buffer
-    r.z = __builtin_amdgcn_readfirstlane(bytes);
-    r.w = 0x00020000u;
+template <bool NT>
+__device__ __forceinline__ dbl2_t load16(__amdgpu_buffer_rsrc_t run, unsigned byte_off) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(run, (int)byte_off, 0, NT ? 2 : 0);
+    dbl2_t r;
+    r.x = __hiloint2double((int)v.y, (int)v.x);
+    r.y = __hiloint2double((int)v.w, (int)v.z);
     return r;
 }
-template <bool NT>
-__device__ __forceinline__ void dma16(u32x4_t run, unsigned voff, unsigned soff, unsigned lds_addr) {
-    if (NT) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen nt lds" :: "s"(lds_addr), "v"(voff), "s"(run), "s"(soff) : "memory");
-    else    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(lds_addr), "v"(voff), "s"(run), "s"(soff) : "memory");
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t run_resource(const double* first, unsigned bytes) {
+    // (wave-uniform, and said so: a resource the compiler cannot prove uniform costs a waterfall loop around every load)
+    const unsigned long long b = (unsigned long long)first;
+    const unsigned long long u = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)b);
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<double*>(u), (short)0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
 }
-template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
-__device__ __forceinline__ void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // centred row statistics from the 20 shifted sums: lec_boxtile.hip's finish_lane (the formulas of finish_row, lec_sweep.h)
 __device__ __forceinline__ void finish_lane(const double (&tot)[kNA], double cT, double cU, double cV, double cW, double cP, double (&o)[22]) {
@@ -126,10 +116,12 @@ __device__ __forceinline__ void finish_lane(const double (&tot)[kNA], double cT,
     o[21] = tot[19] - 2 * db * tot[12] + db * db * dd - 2 * dc * tot[13] + dc * dc * dd + cW * (sUU + sVV);
 }
 
-__global__ void __launch_bounds__(64, 1) lec_boxplane_kernel(const RowParams p) {
-    __shared__ __attribute__((aligned(1024))) unsigned char sm_raw[kLdsBytes];
-    const unsigned lds0 = (unsigned)(uintptr_t)sm_raw;
-    double* const side = reinterpret_cast<double*>(sm_raw + kBufs * kSet);   // [kLB levels][kWR rows][kSide]
+__global__ void __launch_bounds__(64, 2) lec_boxplane_kernel(const RowParams p) {
+    __shared__ __attribute__((aligned(16))) double sm[kLdsDoubles];
+    double* const tiles = sm;                              // 2 x [6 rows][W]: T of this level and of the next, each as it lies in memory
+    double* const part = sm + 2 * kTileT;                  // [kHalf][kPS]: the lanes' partial sums of a level, ten statistics at a time
+    double* const stash = part + kHalf * kPS;              // [kLB levels][kWR rows][kNA]: row totals waiting for their finishing lane
+    double* const side = stash + kLB * kWR * kNA;          // [kLB levels][kWR rows][kSide]
     const int lane = threadIdx.x & 63;
 
     // block -> (time step, level chunk, row block of 4): lec_boxtile.hip's order (every XCD a contiguous chunk of time steps, row
@@ -145,7 +137,9 @@ __global__ void __launch_bounds__(64, 1) lec_boxplane_kernel(const RowParams p) 
     if (tin >= p.jchunk || tl >= p.t_count) return;
 
     const int bi = (p.n_box == 1) ? 0 : tl;
-    const int iw = p.box[4 * bi + 0], ie = p.box[4 * bi + 1], js = p.box[4 * bi + 2], jn = p.box[4 * bi + 3];
+    // (wave-uniform, and said so: everything derived from the box -- the loads' resources above all -- must live in scalar registers)
+    const int iw = __builtin_amdgcn_readfirstlane(p.box[4 * bi + 0]), ie = __builtin_amdgcn_readfirstlane(p.box[4 * bi + 1]);
+    const int js = __builtin_amdgcn_readfirstlane(p.box[4 * bi + 2]), jn = __builtin_amdgcn_readfirstlane(p.box[4 * bi + 3]);
     const int nxb = ie - iw + 1, nyb = jn - js + 1;
     const int k0 = kc * kchunk, k1 = min(k0 + kchunk, p.nl);
     const int jb0 = rbi * kWR;
@@ -158,7 +152,7 @@ __global__ void __launch_bounds__(64, 1) lec_boxplane_kernel(const RowParams p) 
         return;
     }
 
-    const int W = p.nx;                   // the slab's row pitch = the tiles' row pitch (<= 64)
+    const int W = p.nx;                   // the cube's row pitch = the T tile's row pitch (<= 64)
     const int t = p.t_begin + tl;
     const size_t plane = (size_t)p.ny * W;
     const size_t cube = plane * p.nl;
@@ -173,181 +167,180 @@ __global__ void __launch_bounds__(64, 1) lec_boxplane_kernel(const RowParams p) 
     const double* const gW = (const double*)p.W + fbase;
     const double* const gP = (const double*)p.P + fbase;
     const double* const gD = (const double*)p.DT + fbase;
-    const unsigned voff = 16u * lane;
-    auto issue_T = [&](int k, unsigned set) {
-        if (LEC_BP_ABLATE & 2) return;
-        const u32x4_t run = run_resource(gT + lev(k), bytesT);
-#pragma unroll
-        for (int i = 0; i < kPiecesT; ++i) dma16<false>(run, voff, 1024u * i, set + 1024u * i);      // (halo rows are the neighbouring wave's own rows: default policy)
-    };
-    auto issue_F = [&](int k, unsigned set) {
-        if (LEC_BP_ABLATE & 2) return;
-        const size_t lk = lev(k);
-        const double* g5[5] = {gU + lk, gV + lk, gW + lk, gP + lk, gD + lk};
-#pragma unroll
-        for (int f = 0; f < 5; ++f) {
-            const u32x4_t run = run_resource(g5[f], bytesF);
-#pragma unroll
-            for (int i = 0; i < kPiecesF; ++i) dma16<LEC_BP_NT != 0>(run, voff, 1024u * i, set + kTileT + kTileF * f + 1024u * i);
-        }
-    };
 
     // ---- lane roles: (row ci of the wave's four, column group cg of sixteen), columns 4 cg + q.  Lanes 0..31 hold groups 0..7 of all
     // four rows, lanes 32..63 groups 8..15: the 32 lanes that an LDS read serves together then touch 32 different 8-byte banks
     // whenever the row pitch is odd (61 columns) -- with (row, group) = (lane / 16, lane % 16) groups g and g + 8 would collide
     const int ci = (lane >> 3) & 3, cg = (lane & 7) | ((lane >> 5) << 3);
-    const int slot16 = ci * 16 + cg;                       // the lane's slot in the hand-over arrays: (row, group) as lec_boxtile.hip numbers them
+    // (the hand-over array is indexed by LANE -- contiguous writes --, and the lane that adds row ci's sixteen partials walks that row's
+    // lanes in group order: group g of row ci is lane (g & 7) + 8 ci + 32 (g >> 3); every LDS access of the hand-over is conflict-free)
     const int jb = jb0 + ci, jbc = min(jb, nyb - 1);       // (rows past the box's last one walk along on it and store nothing)
-    // element offsets inside the tiles (doubles).  T tile: row 0 = box row h0; the other tiles: row 0 = box row jb0
+    // element offsets inside the T tile (doubles): its row 0 = box row h0
     const int rT = (jbc - h0) * W + iw, rTm = (max(jbc - 1, 0) - h0) * W + iw, rTp = (min(jbc + 1, nyb - 1) - h0) * W + iw;
-    const int rF = (jbc - jb0) * W + iw;
-    int col[4], cl[4], cr[4];
+    // the lane's 32 bytes of a plane's run (its row 0 = box row jb0): columns 4 cg .. 4 cg + 3 of row ci.  Groups past the cube's last
+    // column, and rows past the run, lie outside the resource: zeros
+    const unsigned offF = (unsigned)(((jb - jb0) * W + iw + 4 * cg) * 8);
+    int col[4];
     bool zero[4], first[4], last[4];
-    double fac[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int c = 4 * cg + q;
         first[q] = c == 0; last[q] = c == nxb - 1;
         zero[q] = c == 0 || c >= nxb - 1;                  // the trapezoid's end points (added in the epilogue with weight 1/2) and columns beside the box
         col[q] = min(c, nxb - 1);
-        cl[q] = max(col[q] - 1, 0); cr[q] = min(col[q] + 1, nxb - 1);      // one-sided at the row ends: the point itself stands in for the missing neighbour
-        fac[q] = (first[q] || last[q]) ? 2.0 : 1.0;
     }
+    // d/dlon of T at the lane's point q, centred; one-sided at the row ends (the point itself stands in for the missing neighbour, the
+    // difference counts twice: lec_boxtile.hip's ((last ? T : Tr) - (first ? T : Tl)) * ((first || last) ? 2 : 1)).  The neighbours'
+    // columns are formed where they are used: eight lane constants fewer in registers that the two prefetch sets need
+    auto ddlon = [&](const double* tile, int q) -> double {
+#pragma clang fp contract(off)
+        int c = col[q];
+        asm volatile("" : "+v"(c));
+        const double d = tile[rT + min(c + 1, nxb - 1)] - tile[rT + max(c - 1, 0)];
+        return (first[q] || last[q]) ? d * 2.0 : d;
+    };
     // coefficients of the lane's row (d/dlat a, b, c; 1 / dx) and of the wave's levels (one per lane: picked with v_readlane, so that
-    // no table load -- a vector load the compiler would wait for with vmcnt(0) -- sits inside the level loop)
+    // no table load -- a vector load the compiler would wait for with vmcnt(0), draining the prefetch -- sits inside the level loop)
     const double* lt = p.lattab + ((size_t)bi * p.nyb_max + jbc) * 4;
     const double ga = lt[0], gb = lt[1], gc = lt[2], idx = lt[3];
-    const double levv = p.levtab[(size_t)min(k0 + lane / 3, p.nl - 1) * 3 + lane % 3];
+    const double levv = p.levtab[(size_t)min(k0 + lane / 3, p.nl - 1) * 3 + lane % 3];                 // levels k0 .. k0 + 20 (lane 63: level 21's first)
+    const double levw = p.levtab[(size_t)min(k0 + (lane + 64) / 3, p.nl - 1) * 3 + (lane + 64) % 3];     // ... and on from there
     const double inv_xlen = p.boxtab[4 * bi + 0], h_rad = p.boxtab[4 * bi + 1], inv_hdeg = p.boxtab[4 * bi + 2];
     const double cx = (0.5 * inv_hdeg) * idx;
 
-    // ---- prologue: T(k0)'s tile (as "set k0 - 1", into the last buffer), the lane's points of T(k0 - 1), then the first kAhead sets
-    double Tm[4], Tc[4], sPc[4], ddc[4], cT;
-    issue_T(k0, lds0 + kAhead * kSet);
+    // ---- the loads of one level: the T run as three flat pieces; the lane's 32 bytes of the five other planes into one of TWO register
+    // sets, picked by the level's parity at compile time -- the planes of level k + 1 are requested BEFORE level k's are waited for, so a
+    // wave has two levels in flight while it waits (as the bare load stream of the probe has) and one while it computes
+    dbl2_t tT[kPiecesT], fU[2][2], fV[2][2], fW[2][2], fP[2][2], fD[2][2];
+    auto issue_T = [&](int kT) {
+        if (LEC_BP_ABLATE & 2) return;
+        const __amdgpu_buffer_rsrc_t rt = run_resource(gT + lev(kT), bytesT);
+#pragma unroll
+        for (int i = 0; i < kPiecesT; ++i) tT[i] = load16<false>(rt, 1024u * i + 16u * lane);      // (halo rows are the neighbouring wave's own rows: default policy)
+    };
+    auto issue_F = [&](auto set_tag, int kF) {
+        constexpr int SET = decltype(set_tag)::value;
+        if (LEC_BP_ABLATE & 2) return;
+        const size_t lk = lev(kF);
+        const __amdgpu_buffer_rsrc_t ru = run_resource(gU + lk, bytesF), rv = run_resource(gV + lk, bytesF), rw = run_resource(gW + lk, bytesF),
+                                     rp = run_resource(gP + lk, bytesF), rd = run_resource(gD + lk, bytesF);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            fU[SET][h] = load16<LEC_BP_NT != 0>(ru, offF + 16u * h);
+            fV[SET][h] = load16<LEC_BP_NT != 0>(rv, offF + 16u * h);
+            fW[SET][h] = load16<LEC_BP_NT != 0>(rw, offF + 16u * h);
+            fP[SET][h] = load16<LEC_BP_NT != 0>(rp, offF + 16u * h);
+            fD[SET][h] = load16<LEC_BP_NT != 0>(rd, offF + 16u * h);
+        }
+    };
+    auto tile_in = [&](double* tile, const dbl2_t (&xT)[kPiecesT]) {     // a T run into a tile, as it lies in memory (the tile's readers are done: one wave, LDS in order)
+        dbl2_t* dst = reinterpret_cast<dbl2_t*>(tile);
+#pragma unroll
+        for (int i = 0; i < kPiecesT; ++i) dst[64 * i + lane] = xT[i];
+    };
+    if (LEC_BP_ABLATE & 2) {
+#pragma unroll
+        for (int i = 0; i < kPiecesT; ++i) { tT[i].x = 280.0 + lane; tT[i].y = 281.0 + i; }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int z = 0; z < 2; ++z) { fU[z][h].x = lane; fU[z][h].y = h; fV[z][h] = fU[z][h]; fW[z][h].x = 0.1; fW[z][h].y = 0.2; fP[z][h] = fU[z][h]; fD[z][h] = fW[z][h]; }
+    }
+
+    // ---- prologue: T(k0)'s tile, the lane's points of T(k0 - 1); the loads of level k0 and T(k0 + 1)'s run on their way
+    double Tm[4];
     {
+        const __amdgpu_buffer_rsrc_t rt = run_resource(gT + lev(k0), bytesT);
+        dbl2_t x[kPiecesT];
+#pragma unroll
+        for (int i = 0; i < kPiecesT; ++i) x[i] = load16<false>(rt, 1024u * i + 16u * lane);
         const double* g = (const double*)p.T + (size_t)t * cube + lev(k0 - 1) + (size_t)(js + jbc) * W + iw;
 #pragma unroll
         for (int q = 0; q < 4; ++q) Tm[q] = g[col[q]];
-    }
-    issue_T(k0 + 1, lds0);
-    issue_F(k0, lds0);
-    if (kAhead > 1 && k0 + 1 < k1) {
-        issue_T(k0 + 2, lds0 + kSet);
-        issue_F(k0 + 1, lds0 + kSet);
-        wait_vm<2 * kPieces>();
-    } else {
-        wait_vm<kPieces>();
-    }
-    {
-#pragma clang fp contract(off)
-        const double* sT = reinterpret_cast<const double*>(sm_raw + kAhead * kSet);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            Tc[q] = sT[rT + col[q]];
-            ddc[q] = (sT[rT + cr[q]] - sT[rT + cl[q]]) * fac[q];
-            sPc[q] = stencil3(ga, sT[rTm + col[q]], gc, sT[rTp + col[q]], gb, Tc[q]);
-        }
-        cT = sT[rT];
+        issue_F(std::integral_constant<int, 0>{}, k0);
+        issue_T(k0 + 1);
+        tile_in(tiles, x);
     }
 
     double acc[kNA];
 #pragma unroll
     for (int s = 0; s < kNA; ++s) acc[s] = 0.0;
 
-    double keep0 = 0.0, keep1 = 0.0;      // the row totals of the level in slot 0, until its partner level is done
-    bool stored = false;                  // did the previous level's epilogue issue its record stores (at least 13, in front of the next set)?
-    int buf = 0;
-    for (int k = k0; k < k1; ++k) {
+    auto level = [&](auto set_tag, const int k) {
+        constexpr int SET = decltype(set_tag)::value;
         const int kk = k - k0, slot = kk % kLB;
-        wait_lds();                       // the reads of the buffer that is refilled now (the previous level's hand-over and epilogue, the prologue) are done
-        // set k + kAhead goes into the buffer level k - 1 has left; then wait for set k -- everything but the sets behind it (and the
-        // record stores issued between them: never fewer than 13 where an epilogue ran)
-        const int ahead = min(kAhead, k1 - 1 - k);                 // sets behind set k once this level's issue is done
-        if (k + kAhead < k1) {
-            const int bnew = buf == 0 ? kAhead : buf - 1;          // = (buf + kAhead) % kBufs
-            const unsigned set = lds0 + bnew * kSet;
-            issue_T(k + kAhead + 1, set);
-            issue_F(k + kAhead, set);
-        }
-        if (ahead == 2) { if (stored) wait_vm<2 * kPieces + 13>(); else wait_vm<2 * kPieces>(); }
-        else if (ahead == 1) { if (stored) wait_vm<kPieces + 13>(); else wait_vm<kPieces>(); }
-        else wait_vm<0>();
-        stored = false;
-        const double* sT = reinterpret_cast<const double*>(sm_raw + buf * kSet);
-        const double* sU = sT + kTileT / 8;
-        const double* sV = sU + kTileF / 8;
-        const double* sW = sV + kTileF / 8;
-        const double* sP = sW + kTileF / 8;
-        const double* sD = sP + kTileF / 8;
         double* const sd = side + (slot * kWR + ci) * kSide;
+        // the next level's five planes into the other register set, then T(k + 1)'s run into the other tile and T(k + 2)'s run requested
+        // (levels and tiles alternate together: SET is also the tile that holds T(k))
+        const double* const tileC = tiles + SET * kTileT;            // T(k): the lane's points and their four horizontal neighbours
+        double* const tileN = tiles + (SET ^ 1) * kTileT;            // T(k + 1): the lane's points
+        if (k + 1 < k1) issue_F(std::integral_constant<int, SET ^ 1>{}, k + 1);
+        tile_in(tileN, tT);
+        if (k + 1 < k1) issue_T(k + 2);
+        const double Uq[4] = {fU[SET][0].x, fU[SET][0].y, fU[SET][1].x, fU[SET][1].y}, Vq[4] = {fV[SET][0].x, fV[SET][0].y, fV[SET][1].x, fV[SET][1].y},
+                     Wq[4] = {fW[SET][0].x, fW[SET][0].y, fW[SET][1].x, fW[SET][1].y}, Pq[4] = {fP[SET][0].x, fP[SET][0].y, fP[SET][1].x, fP[SET][1].y},
+                     Dq[4] = {fD[SET][0].x, fD[SET][0].y, fD[SET][1].x, fD[SET][1].y};
+        // the shifts of the other four planes: the row's first box element, which the lane of group 0 holds -- through the side array
+        if (first[0]) { sd[0] = tileC[rT]; sd[1] = Uq[0]; sd[2] = Vq[0]; sd[3] = Wq[0]; sd[4] = Pq[0]; }
+        row_sync<64>();
         if (!(LEC_BP_ABLATE & 1)) {
 #pragma clang fp contract(off)
-            const double al = lane_value(levv, 3 * kk), be = lane_value(levv, 3 * kk + 1), gm = lane_value(levv, 3 * kk + 2);
-            const double cU = sU[rF], cV = sV[rF], cW = sW[rF], cP = sP[rF];      // shifts: the row's first box element
+            auto levc = [&](int e) -> double { return e < 64 ? lane_value(levv, e) : lane_value(levw, e - 64); };      // (wave-uniform choice)
+            const double al = levc(3 * kk), be = levc(3 * kk + 1), gm = levc(3 * kk + 2);
+            const double cT = tileC[rT], cU = sd[1], cV = sd[2], cW = sd[3], cP = sd[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const double Tn = sT[rT + col[q]];                                // T one level down: the lane's own point
-                const double U = sU[rF + col[q]], V = sV[rF + col[q]], Wv = sW[rF + col[q]], P = sP[rF + col[q]], D = sD[rF + col[q]];
-                const double T = Tc[q];
+                const double T = tileC[rT + col[q]], Tn = tileN[rT + col[q]];     // the lane's point at this level and one level down
+                const double U = Uq[q], V = Vq[q], Wv = Wq[q], P = Pq[q], D = Dq[q];
                 const double sS = stencil3(al, Tm[q], gm, Tn, be, T);
-                const double adv = (U * cx) * ddc[q];
-                const double f = fma(-Wv, sS, fma(V, sPc[q], D + adv));
+                const double adv = (U * cx) * ddlon(tileC, q);
+                const double sP_ = stencil3(ga, tileC[rTm + col[q]], gc, tileC[rTp + col[q]], gb, T);
+                const double f = fma(-Wv, sS, fma(V, sP_, D + adv));
                 const double a = T - cT, b = U - cU, c = V - cV, d = Wv - cW, ee = P - cP;
                 if (!zero[q]) accum20<true>(acc, 1.0, a, b, c, d, ee, f);
-                if (first[q]) { sd[0] = cT; sd[1] = cU; sd[2] = cV; sd[3] = cW; sd[4] = cP; sd[5] = f; }
+                if (first[q]) sd[5] = f;
                 if (last[q]) {
                     sd[6] = a; sd[7] = b; sd[8] = c; sd[9] = d; sd[10] = ee; sd[11] = f;
                     sd[12] = T; sd[13] = U; sd[14] = V;
                 }
-                // the horizontal stencils of the NEXT level, while its tile is here
-                const double ddn = (sT[rT + cr[q]] - sT[rT + cl[q]]) * fac[q];
-                const double sPn = stencil3(ga, sT[rTm + col[q]], gc, sT[rTp + col[q]], gb, Tn);
-                Tm[q] = T; Tc[q] = Tn; ddc[q] = ddn; sPc[q] = sPn;
+                Tm[q] = T;                                                        // (the level above, next time: the one value a lane carries)
+                // one point at a time: interleaved, the four points' temporaries push the kernel past its 256 registers (two prefetch sets live)
+                __builtin_amdgcn_sched_barrier(0);
             }
-            cT = sT[rT];
         }
-        double* const part = reinterpret_cast<double*>(sm_raw + buf * kSet);            // (the set is consumed)
-        double* const stash = reinterpret_cast<double*>(sm_raw + buf * kSet + kStashOff);   // [kLB levels][kWR rows][kNA]
-        const bool finish = slot == kLB - 1 || k == k1 - 1;
         {
-            // the level's rows are complete: 16 partial sums per row and statistic -> one total, through LDS: every lane stores its 20
-            // partials, then lane (row, s) adds the 16 of its row in a fixed order (lec_boxtile.hip's hand-over).  The totals of the
-            // level in slot 0 wait in two registers for their partner level: the consumed set is refilled before that one is done
+            // the level's rows are complete: 16 partial sums per row and statistic -> one total, through LDS, ten statistics at a time: every
+            // lane stores its partials, then lane (row, s) adds the 16 of its row in a fixed order (lec_boxtile.hip's hand-over and order)
 #pragma clang fp contract(off)
-            row_sync<64>();
+            double* st = stash + (slot * kWR + ci) * kNA;
 #pragma unroll
-            for (int s = 0; s < kNA; ++s) { part[s * kPS + slot16] = acc[s]; acc[s] = 0.0; }
-            row_sync<64>();
-            const double* p0 = part + cg * kPS + ci * 16;                 // statistic cg of row ci
-            const double* p1 = part + (min(cg, 3) + 16) * kPS + ci * 16;  // statistic 16 + cg (cg < 4)
-            double t0 = p0[0], t1 = p1[0];
+            for (int h = 0; h < 2; ++h) {
+                row_sync<64>();
 #pragma unroll
-            for (int g = 1; g < 16; ++g) { t0 += p0[g]; t1 += p1[g]; }
-            if (finish) {
-                if (slot > 0) {
-                    double* s0 = stash + ci * kNA;
-                    s0[cg] = keep0;
-                    if (cg < 4) s0[16 + cg] = keep1;
-                }
-                double* st = stash + (slot * kWR + ci) * kNA;
-                st[cg] = t0;
-                if (cg < 4) st[16 + cg] = t1;
-            } else {
-                keep0 = t0; keep1 = t1;
+                for (int s = 0; s < kHalf; ++s) { part[s * kPS + lane] = acc[kHalf * h + s]; acc[kHalf * h + s] = 0.0; }
+                row_sync<64>();
+                const double* p0 = part + min(cg, kHalf - 1) * kPS + 8 * ci;       // statistic 10 h + cg of row ci (cg < 10)
+                double t0 = p0[0];
+#pragma unroll
+                for (int g = 1; g < 16; ++g) t0 += p0[(g & 7) + 32 * (g >> 3)];
+                if (cg < kHalf) st[kHalf * h + cg] = t0;
             }
             row_sync<64>();
         }
-        // ---- up to kLB finished levels x 4 rows: one (level, row) per lane finishes its record (lec_boxtile.hip's epilogue)
-        if (finish) {
+        // ---- up to kLB finished levels x 4 rows: one (level, row) per lane finishes its record (lec_boxtile.hip's epilogue, expression by
+        // expression) -- into LDS (the hand-over array is free); then ALL lanes store the records, sixteen lanes per 256-byte record:
+        // four store instructions that write whole lines.  (One record per lane straight to memory is 13 store instructions of sixteen
+        // 16-byte pieces in sixteen different lines each: as many partial-line write requests as the kernel has read requests.)
+        if (slot == kLB - 1 || k == k1 - 1) {
 #pragma clang fp contract(off)
+            constexpr int kRS = LEC_NSTAT + 2;           // record stride in the buffer (doubles): 16-byte aligned, and eight lanes' 16-byte writes fall on different banks
+            static_assert(kLB * kWR * kRS <= kHalf * kPS, "the finished records must fit the hand-over array");
             int ln = lane;
             asm volatile("" : "+v"(ln));
             const int lv = ln >> 2, r = ln & 3;
-            const int jr = jb0 + r;
-            if (lv <= slot && jr < p.nyb_max) {
-                const int kout = k - slot + lv;
-                dbl2_t* __restrict__ out = reinterpret_cast<dbl2_t*>(p.rows + ((size_t)(tl * p.nl + kout) * p.nyb_max + jr) * LEC_NSTAT);
-                if (jr >= nyb) {                 // padding row of a box lower than nyb_max
+            if (lv <= slot) {
+                dbl2_t* __restrict__ out = reinterpret_cast<dbl2_t*>(part + (lv * kWR + r) * kRS);
+                if (jb0 + r >= nyb) {            // padding row of a box lower than nyb_max
 #pragma unroll
                     for (int s = 0; s < LEC_NSTAT / 2; ++s) { dbl2_t z; z.x = 0.0; z.y = 0.0; out[s] = z; }
                 } else {
@@ -377,9 +370,21 @@ __global__ void __launch_bounds__(64, 1) lec_boxplane_kernel(const RowParams p) 
                 }
             }
             row_sync<64>();
-            stored = true;               // (lane 0 finishes a record or a padding row whenever this branch runs: at least 13 store instructions)
+#pragma unroll
+            for (int i = 0; i < kLB * kWR * (LEC_NSTAT / 2) / 64; ++i) {
+                const int e = 64 * i + lane, rec = e >> 4, piece = e & 15;      // record (level slot, row) and the lane's 16 bytes of it
+                const int rl = rec >> 2, rr = rec & 3;
+                if (rl <= slot && jb0 + rr < p.nyb_max) {
+                    const dbl2_t v2 = *reinterpret_cast<const dbl2_t*>(part + rec * kRS + 2 * piece);
+                    reinterpret_cast<dbl2_t*>(p.rows + ((size_t)(tl * p.nl + (k - slot + rl)) * p.nyb_max + jb0 + rr) * LEC_NSTAT)[piece] = v2;
+                }
+            }
+            row_sync<64>();
         }
-        buf = buf == kAhead ? 0 : buf + 1;
+    };
+    for (int k = k0; k < k1; k += 2) {
+        level(std::integral_constant<int, 0>{}, k);
+        if (k + 1 < k1) level(std::integral_constant<int, 1>{}, k + 1);
     }
 }
 
@@ -398,9 +403,10 @@ int lec_launch_boxplane(lec::RowParams p, hipStream_t st) {
     p.jchunk = (int)((p.t_count + 7) / 8);                // time steps per XCD
     if (p.jgroup > kMaxLevels) return LEC_ERR_ARG;
     if (p.jgroup < 1) {
-        // levels per wave: as many as still leave kTargetWaves waves (the chip holds 1024 of these at four per CU); a chunk's first set
-        // costs a T tile and a pipeline fill of its own
-        constexpr long long kTargetWaves = 8192;
+        // levels per wave: as many as still leave kTargetWaves waves (the chip holds 2048 of these at eight per CU: sixteen rounds) -- a
+        // chunk's first level costs a T tile and a pipeline fill of its own, but short waves fill the chip's tail better (512 steps: 10
+        // levels per wave 0.743 ms, 19: 0.750, 37: 0.754; profiles/r06_notes.md)
+        constexpr long long kTargetWaves = 32768;
         const long long per_chunk = 8LL * p.jchunk * n_rb;
         const long long want = (kTargetWaves + per_chunk - 1) / per_chunk;
         const long long most = (p.nl + kMinLevels - 1) / kMinLevels, least = (p.nl + kMaxLevels - 1) / kMaxLevels;

@@ -88,8 +88,10 @@ __global__ void __launch_bounds__(256) lec_ingest_kernel(const IngestParams p) {
 
 template <typename TSRC>
 void launch(const IngestParams& p, int out_dtype, long long rows, hipStream_t st) {
-    if (out_dtype == LEC_F64) hipLaunchKernelGGL((lec_ingest_kernel<TSRC, double>), dim3((unsigned)rows), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((lec_ingest_kernel<TSRC, float>), dim3((unsigned)rows), dim3(256), 0, st, p);
+    // one workgroup per output row; its threads walk the row: short rows (a box-packed series: 61 columns) get one wave, not four
+    const dim3 block(p.nx <= 64 ? 64 : (p.nx <= 128 ? 128 : 256));
+    if (out_dtype == LEC_F64) hipLaunchKernelGGL((lec_ingest_kernel<TSRC, double>), dim3((unsigned)rows), block, 0, st, p);
+    else hipLaunchKernelGGL((lec_ingest_kernel<TSRC, float>), dim3((unsigned)rows), block, 0, st, p);
 }
 
 }  // namespace

@@ -455,7 +455,7 @@ extern "C" int lec_rowstats(const lec_rowstats_args* a) {
         }
         if (rc == LEC_OK && mode == 3) rc = lec_launch_qtime(p, st);
     }
-    if (rc == LEC_ERR_ARG) return lec_set_error(rc, "lec_rowstats: tuning.tile_j: the box-tile / box-plane kernels walk at most 21 levels per wave");
+    if (rc == LEC_ERR_ARG) return lec_set_error(rc, "lec_rowstats: tuning.tile_j: the box-tile kernel walks at most 21 levels per wave, the box-plane kernel 42");
     if (rc != LEC_OK) return lec_set_error(rc, "lec_rowstats: row too long for the compiled kernels");
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return lec_set_error(LEC_ERR_LAUNCH, hipGetErrorString(e));

@@ -139,8 +139,45 @@ class LECEngine:
     def pack_boxes(self, cube: torch.Tensor, boxes, shift: int = 0, ny: Optional[int] = None, nx: Optional[int] = None) -> torch.Tensor:
         """[nt, nl, ny_grid, nx_grid] -> the box-packed layout [len(boxes), nl, ny, nx] (default: the tallest / widest box): step t
         holds box t of ``cube[t + shift]`` (clamped to the cube: the step itself where a time neighbour does not exist) at its
-        origin, zeros outside.  One gather on the device -- for tests, ``bench.py --moving`` and host-prepared tracks; the streamed
-        moving framework writes the same layout straight from the file bytes (``ingest.lec_streamed``, ``lec_ingest``)."""
+        origin.  ONE launch of ``lec_ingest`` -- the gather the streamed moving framework packs its series with (``ingest.lec_streamed``:
+        there the source is the file's raw bytes, here a cube in HBM; ``lec_ingest_args.step_d`` = per step {source step, where the box
+        starts}) -- for tests, ``bench.py --moving`` and cubes a caller already holds.  What a slab holds beside a box lower / narrower
+        than the slab is whatever the lengthened index maps point at (the grid's last row / column): stage 1 never reads it."""
+        b = np.array([tuple(int(x) for x in q) for q in (boxes.boxes if isinstance(boxes, PreparedBoxes) else boxes)], dtype=np.int64)
+        nt, nl, ny_in, nx_in = (int(x) for x in cube.shape)
+        if len(b) != nt:
+            raise ValueError("pack_boxes: one box per time step of the cube")
+        if cube.dtype not in (torch.float64, torch.float32) or not cube.is_contiguous() or cube.device.type != "cuda":
+            raise ValueError("pack_boxes: a contiguous float64 / float32 cube on the GPU")
+        nxb, nyb = b[:, 1] - b[:, 0] + 1, b[:, 3] - b[:, 2] + 1
+        ny, nx = int(ny or nyb.max()), int(nx or nxb.max())
+        if ny < nyb.max() or nx < nxb.max() or ny > ny_in or nx > nx_in:
+            raise ValueError("pack_boxes: slabs must hold the tallest / widest box and fit the grid")
+        dev = cube.device
+        key = (nl, ny_in, nx_in, ny, nx, str(dev))
+        maps = self._pack_maps.get(key) if hasattr(self, "_pack_maps") else None
+        if maps is None:            # identity maps, lengthened by a slab (their last entry repeated): a box at the grid's edge is gathered with the slab's extents
+            up = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.int32).to(dev)
+            maps = (up(np.arange(nl)), up(np.minimum(np.arange(ny_in + ny), ny_in - 1)), up(np.minimum(np.arange(nx_in + nx), nx_in - 1)))
+            self._pack_maps = {key: maps}
+        step = torch.as_tensor(np.column_stack([np.clip(np.arange(nt) + shift, 0, nt - 1), b[:, 2], b[:, 0]]).astype(np.int32)).to(dev)
+        out = torch.empty((nt, nl, ny, nx), dtype=cube.dtype, device=dev)
+        code = _lib.LEC_F64 if cube.dtype == torch.float64 else _lib.LEC_F32
+        for a0 in range(0, nt, 8192):            # (a call addresses its output rows with a 31-bit grid index)
+            a1 = min(nt, a0 + 8192)
+            ga = _lib.IngestArgs(
+                src_d=_ptr(cube), src_dtype=code, swap_bytes=0, nt=a1 - a0, nl_in=nl, ny_in=ny_in, nx_in=nx_in, nl=nl, ny=ny, nx=nx,
+                kmap_d=_ptr(maps[0]), jmap_d=_ptr(maps[1]), imap_d=_ptr(maps[2]), has_packing=0, has_fill=0, scale_factor=1.0, add_offset=0.0,
+                fill_value=0.0, unit_scale=1.0, out_dtype=code, decode_dtype=code, out_d=_ptr(out[a0:a1]),
+                stream=C.c_void_p(torch.cuda.current_stream(dev).cuda_stream), step_d=_ptr(step[a0:a1]), step_base=0, nt_src=nt,
+                jmap_len=int(maps[1].numel()), imap_len=int(maps[2].numel()))
+            with torch.cuda.device(dev):
+                _lib.check(self.lib.lec_ingest(C.byref(ga)), "lec_ingest")
+        return out
+
+    def pack_boxes_by_indexing(self, cube: torch.Tensor, boxes, shift: int = 0, ny: Optional[int] = None, nx: Optional[int] = None) -> torch.Tensor:
+        """``pack_boxes`` as one torch advanced-indexing gather, zeros beside the boxes: the independent form the tests hold the
+        ``lec_ingest`` gather to (inside the boxes: the same values)."""
         b = np.array([tuple(int(x) for x in q) for q in (boxes.boxes if isinstance(boxes, PreparedBoxes) else boxes)], dtype=np.int64)
         nt = cube.shape[0]
         if len(b) != nt:

@@ -50,7 +50,7 @@ def test_config5_shape_bit_identical_and_against_the_oracle():
     eng, f, tc, ps, pb = _series(dom, boxes)
     ref = _rows(eng, ps, pb, "box_tile")
     assert torch.isfinite(ref).all()
-    for tj in (0, 5, 8, 13, 19, 21):
+    for tj in (0, 5, 8, 13, 19, 21, 22, 30, 37):              # (the box-plane kernel walks up to 42 levels per wave: 37 = one walk)
         got = _rows(eng, ps, pb, "box_plane", tile_j=tj)
         assert torch.equal(got, ref), f"tile_j={tj}"
     auto = eng.rowstats(ps["tair"], ps["u"], ps["v"], ps["omega"], ps["geopt"], pb, dTdt=ps["dTdt"], per_step_boxes=True)
@@ -78,8 +78,8 @@ def test_random_geometries_bit_identical():
         wmax, hmax = max(b[1] - b[0] + 1 for b in boxes), max(b[3] - b[2] + 1 for b in boxes)
         pad = case % 3
         eng, f, tc, ps, pb = _series(dom, boxes, ny=min(ny, hmax + pad), nx=min(nx, 64, wmax + pad))
-        tj = int(rng.integers(0, min(nl, 21) + 1))
-        ref, got = _rows(eng, ps, pb, "box_tile", tile_j=tj), _rows(eng, ps, pb, "box_plane", tile_j=tj)
+        tj = int(rng.integers(0, min(nl, 42) + 1))
+        ref, got = _rows(eng, ps, pb, "box_tile", tile_j=min(tj, 21)), _rows(eng, ps, pb, "box_plane", tile_j=tj)
         assert torch.equal(got, ref), f"case {case}: nt={nt} nl={nl} grid {ny}x{nx} slab {tuple(ps['tair'].shape[2:])} tile_j={tj} boxes {boxes}"
         for t, bx in enumerate(boxes):
             assert torch.all(got[t, :, bx[3] - bx[2] + 1:] == 0), (case, t)
@@ -152,10 +152,11 @@ def test_box_plane_refuses_what_it_does_not_serve():
     f4 = [_dev(a) for a in (st.tair, st.u, st.v, st.omega, st.geopt)]
     with pytest.raises(ValueError, match="BOX_PLANE"):
         eng4.rowstats(*f4, boxes, dTdt=_dev(o.moving_dTdt(st)), per_step_boxes=True, tuning={"kernel": "box_plane"})
-    with pytest.raises(ValueError, match="21 levels"):
-        big = synthetic_domain(2, 30, 12, 16, seed=2)
-        e5, f5, tc5, ps5, pb5 = _series(big, [(1, 12, 1, 9)] * 2)
-        _rows(e5, ps5, pb5, "box_plane", tile_j=22)
+    big = synthetic_domain(2, 30, 12, 16, seed=2)
+    e5, f5, tc5, ps5, pb5 = _series(big, [(1, 12, 1, 9)] * 2)
+    assert torch.equal(_rows(e5, ps5, pb5, "box_plane", tile_j=30), _rows(e5, ps5, pb5, "box_tile", tile_j=15))     # (one walk of all 30 levels)
+    with pytest.raises(ValueError, match="42"):
+        _rows(e5, ps5, pb5, "box_plane", tile_j=43)
 
 
 def test_a_long_series_takes_every_xcd_chunk_and_level_walk():

@@ -224,6 +224,8 @@ def test_ingest_auto_falls_back_to_the_host_preparation(workdir, monkeypatch):
     real_close = ingest.ds.RawDataset.close
     monkeypatch.setattr(ingest.ds.RawDataset, "close", lambda self: (closed.append(1), real_close(self))[1])
 
+    real_streamed = ingest.lec_streamed
+
     def refuse(*a, **k):
         raise ValueError("simulated refusal of the streamed path")
     monkeypatch.setattr(ingest, "lec_streamed", refuse)
@@ -235,7 +237,7 @@ def test_ingest_auto_falls_back_to_the_host_preparation(workdir, monkeypatch):
         _main([src, "-r", "-f", "--ingest", "device"])
     # ... but only a REFUSAL of the streamed path falls back: an error later in the run (here: while the tables are written, after the
     # engine has returned) is an error -- no second analysis on the host
-    monkeypatch.undo()
+    monkeypatch.setattr(ingest, "lec_streamed", real_streamed)
     import lorenzcycletoolkit as cli
     from lorenzcycletoolkit_amd import frameworks
     host_runs = []

@@ -64,6 +64,29 @@ def test_packed_series_gives_the_bits_of_the_cube(dtype, nonuni):
         compare(res.scalars_dict(), res.levels_dict(), ref_s, ref_l, 1e-9, "packed series vs oracle", time_s=dom.time_s)
 
 
+def test_pack_boxes_is_the_products_gather():
+    """LECEngine.pack_boxes runs lec_ingest with per-step origins (the gather the streamed moving framework packs its series with):
+    inside every step's box the values of the cube -- held here to an independent torch gather --, both dtypes, time-shifted too,
+    NaN and -0.0 as they are, boxes at the grid's edges gathered with a slab that reaches past the grid."""
+    dom = synthetic_domain(6, 4, 23, 31, seed=12)
+    dom.tair[2, 1, 5:9, 4:7] = np.nan
+    dom.tair[3, 0, 7, 7] = -0.0
+    boxes = [(0, 9, 0, 5), (21, 30, 17, 22), (3, 30, 0, 22), (5, 12, 4, 19), (0, 30, 0, 22), (29, 30, 21, 22)]
+    for dtype in (np.float64, np.float32):
+        eng = _engine(dom)
+        cube = _dev(dom.tair.astype(dtype))
+        for shift in (0, -1, 1):
+            for ny, nx in ((None, None), (23, 31)):
+                got, ref = eng.pack_boxes(cube, boxes, shift=shift, ny=ny, nx=nx), eng.pack_boxes_by_indexing(cube, boxes, shift=shift, ny=ny, nx=nx)
+                assert got.shape == ref.shape and got.dtype == ref.dtype
+                for t, (iw, ie, js, jn) in enumerate(boxes):
+                    a, b = got[t, :, :jn - js + 1, :ie - iw + 1], ref[t, :, :jn - js + 1, :ie - iw + 1]
+                    assert torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(torch.nan_to_num(a, nan=1.0).view(torch.int64 if dtype == np.float64 else torch.int32),
+                                                                                       torch.nan_to_num(b, nan=1.0).view(torch.int64 if dtype == np.float64 else torch.int32)), (t, shift)
+    with pytest.raises(ValueError, match="tallest"):
+        eng.pack_boxes(cube, boxes, ny=10)
+
+
 def test_packed_series_random_geometries():
     """Boxes of any size anywhere in the grid (also at its edges, also wider than one 64-column pass), slabs larger than the boxes,
     1..6 steps, fp32 / fp64, uniform or stretched longitudes: records equal bit for bit, padding rows of the lower boxes zero."""
