@@ -116,8 +116,14 @@ __device__ __forceinline__ void finish_lane(const double (&tot)[kNA], double cT,
     o[21] = tot[19] - 2 * db * tot[12] + db * db * dd - 2 * dc * tot[13] + dc * dc * dd + cW * (sUU + sVV);
 }
 
-__global__ void __launch_bounds__(64, 2) lec_boxplane_kernel(const RowParams p) {
-    __shared__ __attribute__((aligned(16))) double sm[kLdsDoubles];
+// G: waves per workgroup = neighbouring row blocks of one (time step, level chunk).  The waves share nothing and never wait for each other;
+// they run on ONE CU at about the same time, so the lines two neighbouring blocks both ask for -- a block's first and last row are its
+// neighbours' halo rows, and a run rarely ends on a line boundary -- are asked for once: the second request finds the line in that CU's L1,
+// or on its way there (the kernel is bound by the L1's outstanding misses: every merged request is a slot).
+template <int G>
+__global__ void __launch_bounds__(64 * G, 2) lec_boxplane_kernel(const RowParams p) {
+    __shared__ __attribute__((aligned(16))) double sm_all[G * kLdsDoubles];
+    double* const sm = sm_all + (G > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0) * kLdsDoubles;
     double* const tiles = sm;                              // 2 x [6 rows][W]: T of this level and of the next, each as it lies in memory
     double* const part = sm + 2 * kTileT;                  // [kHalf][kPS]: the lanes' partial sums of a level, ten statistics at a time
     double* const stash = part + kHalf * kPS;              // [kLB levels][kWR rows][kNA]: row totals waiting for their finishing lane
@@ -129,7 +135,7 @@ __global__ void __launch_bounds__(64, 2) lec_boxplane_kernel(const RowParams p) 
     const int n_rb = p.jrows, kchunk = p.jgroup, n_kc = (p.nl + kchunk - 1) / kchunk;
     const int xcd = blockIdx.x & 7;
     int q0 = blockIdx.x >> 3;
-    const int rbi = q0 % n_rb; q0 /= n_rb;
+    const int rbi = (q0 % n_rb) * G + (G > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0); q0 /= n_rb;     // (n_rb: row-block GROUPS)
     const int ti = q0 % p.tgroup; q0 /= p.tgroup;
     const int kc = q0 % n_kc;
     const int tin = (q0 / n_kc) * p.tgroup + ti;
@@ -398,18 +404,23 @@ bool lec_boxplane_serves(const lec::RowParams& p, int dtype, bool uniform, int m
 
 // p.tgroup: time steps per tile group, p.jgroup: levels per wave (< 1: chosen here; more than 21: LEC_ERR_ARG) -- as lec_launch_boxtile
 int lec_launch_boxplane(lec::RowParams p, hipStream_t st) {
-    const long long n_rb = (p.nyb_max + kWR - 1) / kWR;
+#ifndef LEC_BP_GROUP      // measured (profiles/r06_notes.md): 2 and 4 waves per workgroup 0.76-0.78 ms per 512 steps against 0.757 for 1 -- no gain
+#define LEC_BP_GROUP 1
+#endif
+    constexpr int G = LEC_BP_GROUP;                       // waves (neighbouring row blocks) per workgroup
+    const long long n_rb = ((p.nyb_max + kWR - 1) / kWR + G - 1) / G;      // row-block groups
     p.jrows = (int)n_rb;
     p.jchunk = (int)((p.t_count + 7) / 8);                // time steps per XCD
     if (p.jgroup > kMaxLevels) return LEC_ERR_ARG;
     if (p.jgroup < 1) {
         // levels per wave: as many as still leave kTargetWaves waves (the chip holds 2048 of these at eight per CU: sixteen rounds) -- a
-        // chunk's first level costs a T tile and a pipeline fill of its own, but short waves fill the chip's tail better (512 steps: 10
-        // levels per wave 0.743 ms, 19: 0.750, 37: 0.754; profiles/r06_notes.md)
-        constexpr long long kTargetWaves = 32768;
-        const long long per_chunk = 8LL * p.jchunk * n_rb;
+        // chunk's first level costs a T tile and a pipeline fill of its own, but short walks run better at every series length -- never
+        // more than kWalk levels unless asked (512 steps: 10 levels per wave 0.743 ms, 19: 0.750, 37: 0.754; 2048 steps: 2.77 / 2.78 /
+        // 2.87 ms; profiles/r06_notes.md)
+        constexpr long long kTargetWaves = 32768, kWalk = 10;
+        const long long per_chunk = 8LL * p.jchunk * n_rb * G;
         const long long want = (kTargetWaves + per_chunk - 1) / per_chunk;
-        const long long most = (p.nl + kMinLevels - 1) / kMinLevels, least = (p.nl + kMaxLevels - 1) / kMaxLevels;
+        const long long most = (p.nl + kMinLevels - 1) / kMinLevels, least = (p.nl + kWalk - 1) / kWalk;
         const long long n_kc0 = want < least ? least : (want > most ? most : want);
         p.jgroup = (int)((p.nl + n_kc0 - 1) / n_kc0);
     }
@@ -420,6 +431,6 @@ int lec_launch_boxplane(lec::RowParams p, hipStream_t st) {
     const long long tgroups = (p.jchunk + p.tgroup - 1) / p.tgroup;
     const long long nblocks = 8LL * tgroups * p.tgroup * n_rb * n_kc;
     if (nblocks > 0x7fffffffLL) return LEC_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(lec_boxplane_kernel, dim3((unsigned)nblocks), dim3(64), 0, st, p);
+    hipLaunchKernelGGL(lec_boxplane_kernel<G>, dim3((unsigned)nblocks), dim3(64 * G), 0, st, p);
     return LEC_OK;
 }

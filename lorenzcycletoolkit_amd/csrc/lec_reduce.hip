@@ -305,7 +305,10 @@ struct LaneSums {
 
 // grid (nl * t_count), block 64; requires nyb_max <= 64
 #ifndef LEC_SMALL_WAVES
-#define LEC_SMALL_WAVES 4       // 98 VGPRs (rounds 2-5: 193 -- the hand-over's fully unrolled loop had sixty LDS values in flight at once)
+// (rounds 2-5: 193 VGPRs, two waves per SIMD -- the hand-over's fully unrolled loop had sixty LDS values in flight at once.  Round 6:
+// four waves per SIMD, and the SAME 85 us per 512 x 37 levels: the kernel is not bound by its occupancy; nor by its record loads --
+// staged through LDS as coalesced 16-byte loads: 86 us.  profiles/r06_stage2_pmc.txt)
+#define LEC_SMALL_WAVES 4
 #endif
 __global__ void __launch_bounds__(64, LEC_SMALL_WAVES) lec_level_small_kernel(const RedParams p) {
     __shared__ double part[kSmallRound * kPartStride];
@@ -320,11 +323,9 @@ __global__ void __launch_bounds__(64, LEC_SMALL_WAVES) lec_level_small_kernel(co
     const int jb = lane, jbc = min(jb, nyb_max - 1);
     const dbl2_t* rr = reinterpret_cast<const dbl2_t*>(p.rows + (size_t)(tl * nl + k) * lstride + (size_t)jbc * LEC_NSTAT);
     constexpr int kUsed = LEC_S_SPARE / 2;                  // the four spare slots of a record are not read
-    constexpr int kFirst = LEC_S_VTT / 2;                   // means and covariances (slots 0..15): the common part and part A
-    static_assert(LEC_S_VTT == 16 && LEC_S_VTT % 2 == 0, "the record's third moments and edge values (part B only) start at slot 16");
     dbl2_t R[kUsed];
 #pragma unroll
-    for (int i = 0; i < kFirst; ++i) R[i] = rr[i];
+    for (int i = 0; i < kUsed; ++i) R[i] = rr[i];
     static_assert(LEC_S_MT == 0 && LEC_S_MU == 1 && LEC_S_MV == 2, "the neighbour rows' [T] [u] [v] are read as r[0..2]");
     const dbl2_t km2 = *reinterpret_cast<const dbl2_t*>(p.rows + (size_t)(tl * nl + km) * lstride + (size_t)jbc * LEC_NSTAT);
     const dbl2_t kp2 = *reinterpret_cast<const dbl2_t*>(p.rows + (size_t)(tl * nl + kp) * lstride + (size_t)jbc * LEC_NSTAT);
@@ -337,7 +338,7 @@ __global__ void __launch_bounds__(64, LEC_SMALL_WAVES) lec_level_small_kernel(co
 
     double r[LEC_S_SPARE];
 #pragma unroll
-    for (int i = 0; i < kFirst; ++i) { r[2 * i] = R[i].x; r[2 * i + 1] = R[i].y; }
+    for (int i = 0; i < kUsed; ++i) { r[2 * i] = R[i].x; r[2 * i + 1] = R[i].y; }
     const double cw = L0.x, wphi = L0.y, c = L1.x, tn = L1.y, gra = L2.x, grb = L2.y, grc = L3.x;
 
     // area means: lec_area_means_kernel's products and butterfly ({[u]} and {[v]} are not used by any term)
@@ -396,13 +397,7 @@ __global__ void __launch_bounds__(64, LEC_SMALL_WAVES) lec_level_small_kernel(co
 #include "lec_level_row.inc"
 #undef LEC_ROW_PART_A
     }
-    // the rest of the record (third moments, the box columns' values: part B alone reads them) is fetched only now -- the loads fly while
-    // part A's sums are handed over; held from the start they cost 24 registers through part A and the kernel a wave per SIMD
-#pragma unroll
-    for (int i = kFirst; i < kUsed; ++i) R[i] = rr[i];
     reduce_round(0, V_B1);
-#pragma unroll
-    for (int i = kFirst; i < kUsed; ++i) { r[2 * i] = R[i].x; r[2 * i + 1] = R[i].y; }
     {
 #pragma unroll
         for (int i = 0; i < V_SIG - V_B1; ++i) part[i * kPartStride + lane] = 0.0;      // the north-south sums take a row at either end only

@@ -26,7 +26,7 @@ noq_run = "--no-q" in open(os.path.join(src, "bench_stats.json")).read() or "T,u
 def stage1(n):
     """Kernels of one lec_rowstats call of the benched configuration.  The default bench line also times the conversion-terms
     configuration (roofline.conversion_terms): those launches are lec_rowsweep_kernel<..., MODE 0, ...> and are not part of it."""
-    if not any(s in n for s in ("lec_rowsweep", "lec_rowblock", "lec_rowstats", "lec_boxtile", "lec_qtime")):
+    if not any(s in n for s in ("lec_rowsweep", "lec_rowblock", "lec_rowstats", "lec_boxtile", "lec_boxplane", "lec_qtime")):
         return False
     m = re.search(r"lec_rowsweep_kernel<\w+, \d+, \w+, (\d+),", n)
     return not (m and m.group(1) == "0" and not noq_run)
