@@ -467,6 +467,9 @@ def measure(args, ctx, cpu_kind="none"):
         all_boxes = eng.prepare_boxes(all_boxes, nyb_min=nyb_max, packed=packed)
     tc_all = eng.time_coefs_device(time_s) if with_q else None      # d/dt coefficients of the whole axis on the device: no upload per call
     crop = {}                      # a packed series: the crop it was produced from (resident runs keep it: the producer is timed on it)
+    crop_head = {}                 # ... its first steps, always kept by rank 0: the kernel cross-check and the CPU leg read them
+    # (ranks that SHARE a GPU -- the gloo rehearsals of the N > 1 path on a one-GPU box -- do not hold a crop each beside their series)
+    keep_whole_crop = not use_dist or world == 1 or bool(who["devices_distinct"])
     producer_ms = {"pack": [], "dtdt": []}
 
     def pack(f, h0, h1, timing=None):
@@ -492,8 +495,17 @@ def measure(args, ctx, cpu_kind="none"):
         tm = {}
         ps = pack(f, h0, h1, timing=tm)
         note_producer(tm)
+        if keep_crop and not keep_whole_crop:      # the crop will not be there to time the producer on afterwards: a second, warmed-up production now
+            del ps
+            tm = {}
+            ps = pack(f, h0, h1, timing=tm)
+            note_producer(tm)
         if keep_crop:
-            crop.update(h0=h0, h1=h1, f=f)
+            if rank == 0:
+                n = min(b - a, 32) + 2
+                crop_head.update(h0=h0, f={k: v[:n].clone() for k, v in f.items()})
+            if keep_whole_crop:
+                crop.update(h0=h0, h1=h1, f=f)
         del f
         cut = lambda x: None if x is None else x[a - h0: b - h0].contiguous()
         kw = {k: cut(ps[k]) for k in ("dTdt", "tm", "tp") if k in ps}
@@ -502,7 +514,8 @@ def measure(args, ctx, cpu_kind="none"):
         return a, b, {k: cut(ps[k]) for k in ("tair", "u", "v", "omega", "geopt")}, kw
 
     held = generate(*chunks[0], keep_crop=True) if resident else None
-    producer_ms["pack"].clear(); producer_ms["dtdt"].clear()          # (the first call pays torch's one-time costs: not a measurement)
+    produced_once = {k: list(v) for k, v in producer_ms.items()}      # (a first call: it may pay one-time costs -- used only where the crop is not kept)
+    producer_ms["pack"].clear(); producer_ms["dtdt"].clear()
     # Everything a pass writes is allocated ONCE, here: the row records, the NaN counters, and (SeriesGatherer) the send / receive
     # buffers of the gather in two pipeline slots.  lec_reduce writes its packed [T_local, 16 + 21 nl] records straight into the
     # slot's send buffer; the gather of pass i is waited for when its slot comes round again, so it overlaps the kernels of pass i + 1.
@@ -638,7 +651,9 @@ def measure(args, ctx, cpu_kind="none"):
     producer = None
     if packed:
         repack_same = None
-        if resident:
+        if resident and not crop:          # the crop was not kept (ranks share a GPU): what producing the series took, once, before the timed passes
+            per_pass = [float(produced_once["pack"][-1]), float(produced_once["dtdt"][-1])]
+        elif resident:
             for i in range(3):
                 tm = {}
                 ps = pack(crop["f"], crop["h0"], crop["h1"], timing=tm)
@@ -657,7 +672,8 @@ def measure(args, ctx, cpu_kind="none"):
                     "pack_is": "the per-step gathers out of the crop (5 fields + T of the two time neighbours; torch advanced indexing here, lec_ingest's "
                                "gather in the product's streamed path)",
                     "dtdt_is": ("lec_dtdt: dT/dt of the packed series as an fp64 cube" if args.storage == "f64" else "none: fp32 storage hands T of the two neighbours over"),
-                    "how": ("re-produced 3 times from the resident crop after the timed passes (median)" if resident else
+                    "how": ("the second of two productions before the timed passes (ranks share a GPU: the crop is not kept beside the series; the other ranks' work runs on the same GPU meanwhile)"
+                            if (resident and not crop) else "re-produced 3 times from the resident crop after the timed passes (median)" if resident else
                             "taken inside every timed pass's generation of every chunk (sum over a pass's chunks, mean over passes)")}
         if repack_same is not None:
             producer["reproduced_series_is_the_timed_one"] = repack_same
@@ -716,7 +732,7 @@ def measure(args, ctx, cpu_kind="none"):
     if rank == 0 and resident and args.moving:
         # (a box-packed series: the check runs on the CROP the series was produced from, so it also says that packing changed no
         # value: the timed pass read the packed series, `a` reads the crop)
-        h0, f = (crop["h0"], crop["f"]) if packed else held[:3:2]
+        h0, f = (crop_head["h0"], crop_head["f"]) if packed else held[:3:2]
         n = min(T_local, 8)
         bx = [all_boxes.boxes[i] for i in range(n)]
         nheld = f["tair"].shape[0]
@@ -931,7 +947,7 @@ def measure(args, ctx, cpu_kind="none"):
                 n = cpu_leg_steps_moving(leg, T_local)
                 hold = min(n + 1, T_global)
                 if packed and resident:
-                    keep = {k: v[:hold].clone() for k, v in crop["f"].items()}
+                    keep = {k: v[:hold] for k, v in crop_head["f"].items()}
                 elif resident:
                     keep = {k: v[:hold].clone() for k, v in held[2].items()}
                 else:

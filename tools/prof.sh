@@ -8,6 +8,9 @@ OUT=$REPO/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $REPO/bench.py --cpu-baseline none "$@" > $OUT/bench_stats.json 2> $OUT/stats.err || { echo "stats pass failed"; tail -5 $OUT/stats.err; exit 1; }
+# (gpurun copies at most 64 MiB back: of the kernel trace only the header and the lec_ launches are kept -- a moving run's trace holds
+# tens of thousands of torch launches of the synthetic generator)
+for f in $OUT/stats/*/*_kernel_trace.csv; do head -1 "$f" > "$f.tmp"; grep lec_ "$f" >> "$f.tmp"; mv "$f.tmp" "$f"; done
 i=0
 IFS=';' read -ra ARR <<< "$SETS"
 for SET in "${ARR[@]}"; do
