@@ -779,8 +779,8 @@ def measure(args, ctx, cpu_kind="none"):
             except Exception:
                 traffic = None
         if args.moving:
-            kname = (("lec_boxplane_kernel (a box-packed fp64 series: one wave per four box rows x a chunk of levels, the planes' rows straight into the "
-                      "layout the sums are taken in)" if (args.storage == "f64" and not args.nonuniform_lon and "box_tile" not in args.tuning)
+            kname = (("lec_boxplane_kernel (a box-packed series: one wave per four box rows x a chunk of levels, the planes' rows straight into the "
+                      "layout the sums are taken in)" if (not args.nonuniform_lon and "box_tile" not in args.tuning)
                       else "lec_boxtile_kernel on a box-packed series") if packed else
                      "lec_boxtile_kernel (one wave per four box rows x a chunk of levels of a time step; six values per point transposed through LDS)")
         elif args.no_q or args.storage == "f32":

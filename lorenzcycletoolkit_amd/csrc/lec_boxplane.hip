@@ -32,8 +32,11 @@
 // order: groups of four columns, sixteen groups in order, end points in the epilogue), so the records are BIT-IDENTICAL to that
 // kernel's and results still do not depend on how a series is sharded, chunked or which of the two kernels ran (tested).
 //
-// Serves: fp64 storage, even longitudes, dT/dt as a cube, Phi present, cubes at most 64 columns wide.  Everything else of a
-// per-step-box call runs on lec_boxtile.hip.
+// Serves per-step boxes on even longitudes with Phi present, cubes at most 64 columns wide: fp64 storage with dT/dt as a cube (what
+// pack_series / the streamed -t path hand over for fp64 data), fp32 storage with dT/dt as a cube or with T of the two time neighbours
+// as cubes of their own (tm_d / tp_d: a box-packed fp32 series -- the reference's float32 samples, ERA5's int16 + fill value).  An fp32
+// lane's four points of a plane are 16 bytes: ONE load per plane.  Everything else of a per-step-box call (crops wider than 64
+// columns, table longitudes, fp64 time neighbours: six 32-byte operands per prefetch set do not fit the registers) runs on lec_boxtile.hip.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -62,11 +65,9 @@ constexpr int kLB = 4;                    // levels whose rows are finished toge
 constexpr int kPS = 65;                   // stride between the statistics of the partial-sum array
 constexpr int kMaxLevels = 42;            // a wave keeps its chunk's static-stability coefficients one per lane (3 per level) in two registers
 constexpr int kMinLevels = 5;
-constexpr int kTileT = (kWR + 2) * kMaxW;         // doubles: T with its two halo rows, row pitch = the cube's nx
-constexpr int kPiecesT = kTileT * 8 / 1024;       // flat 1-KiB pieces of the T run: 3
+constexpr int kTileT = (kWR + 2) * kMaxW;         // elements: T with its two halo rows, row pitch = the cube's nx (LDS is laid out for fp64 tiles)
 constexpr int kHalf = kNA / 2;                    // the sums are handed over ten statistics at a time
 constexpr int kLdsDoubles = 2 * kTileT + kHalf * kPS + kLB * kWR * (kNA + kSide);       // 15,952 B
-static_assert(kTileT * 8 % 1024 == 0, "the T tile is whole 1-KiB pieces");
 static_assert(3 * kMaxLevels <= 128, "the level coefficients of a wave's chunk must fit one value per lane of two registers");
 
 __device__ __forceinline__ double lane_value(double v, int src) {
@@ -77,18 +78,36 @@ __device__ __forceinline__ double lane_value(double v, int src) {
 // its length) and the range check is per dword: what lies past the run reads as zero and is never touched.
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 template <bool NT>
-__device__ __forceinline__ dbl2_t load16(__amdgpu_buffer_rsrc_t run, unsigned byte_off) {
-    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(run, (int)byte_off, 0, NT ? 2 : 0);
-    dbl2_t r;
-    r.x = __hiloint2double((int)v.y, (int)v.x);
-    r.y = __hiloint2double((int)v.w, (int)v.z);
-    return r;
+__device__ __forceinline__ u32x4_t load16(__amdgpu_buffer_rsrc_t run, unsigned byte_off) {
+    return __builtin_amdgcn_raw_buffer_load_b128(run, (int)byte_off, 0, NT ? 2 : 0);
 }
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t run_resource(const double* first, unsigned bytes) {
+// the lane's four consecutive elements of a plane: 32 bytes (two loads) in fp64 storage, 16 bytes (one load) in fp32
+template <typename TIN> struct Quad;
+template <> struct Quad<double> {
+    u32x4_t h[2];
+    template <bool NT> __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t run, unsigned byte_off) { h[0] = load16<NT>(run, byte_off); h[1] = load16<NT>(run, byte_off + 16u); }
+    __device__ __forceinline__ void get(double (&o)[4]) const {
+        o[0] = __hiloint2double((int)h[0].y, (int)h[0].x); o[1] = __hiloint2double((int)h[0].w, (int)h[0].z);
+        o[2] = __hiloint2double((int)h[1].y, (int)h[1].x); o[3] = __hiloint2double((int)h[1].w, (int)h[1].z);
+    }
+    __device__ __forceinline__ void fill(double a, double b) {
+        h[0].x = h[1].x = (unsigned)__double2loint(a); h[0].y = h[1].y = (unsigned)__double2hiint(a);
+        h[0].z = h[1].z = (unsigned)__double2loint(b); h[0].w = h[1].w = (unsigned)__double2hiint(b);
+    }
+};
+template <> struct Quad<float> {
+    u32x4_t h;
+    template <bool NT> __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t run, unsigned byte_off) { h = load16<NT>(run, byte_off); }
+    __device__ __forceinline__ void get(double (&o)[4]) const {
+        o[0] = (double)__uint_as_float(h.x); o[1] = (double)__uint_as_float(h.y); o[2] = (double)__uint_as_float(h.z); o[3] = (double)__uint_as_float(h.w);
+    }
+    __device__ __forceinline__ void fill(double a, double b) { h.x = h.z = __float_as_uint((float)a); h.y = h.w = __float_as_uint((float)b); }
+};
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t run_resource(const void* first, unsigned bytes) {
     // (wave-uniform, and said so: a resource the compiler cannot prove uniform costs a waterfall loop around every load)
     const unsigned long long b = (unsigned long long)first;
     const unsigned long long u = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)b);
-    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<double*>(u), (short)0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(u), (short)0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
 }
 
 // centred row statistics from the 20 shifted sums: lec_boxtile.hip's finish_lane (the formulas of finish_row, lec_sweep.h)
@@ -120,11 +139,19 @@ __device__ __forceinline__ void finish_lane(const double (&tot)[kNA], double cT,
 // they run on ONE CU at about the same time, so the lines two neighbouring blocks both ask for -- a block's first and last row are its
 // neighbours' halo rows, and a run rarely ends on a line boundary -- are asked for once: the second request finds the line in that CU's L1,
 // or on its way there (the kernel is bound by the L1's outstanding misses: every merged request is a slot).
-template <int G>
+// TIN: storage type.  MODE 2: dT/dt is a cube (p.DT);  MODE 1: dT/dt = ta T(t-1) + tb T(t) + tc T(t+1) per point, T of the two time
+// neighbours on this step's box in cubes of their own (p.TM, p.TP: a box-packed series).
+template <typename TIN, int MODE, int G>
 __global__ void __launch_bounds__(64 * G, 2) lec_boxplane_kernel(const RowParams p) {
+    static_assert(MODE == 2 || (MODE == 1 && sizeof(TIN) == 4), "time neighbours as operands: fp32 storage (six 32-byte operands per set do not fit)");
+    constexpr int kPiecesT = (kTileT * (int)sizeof(TIN) + 1023) / 1024;      // flat 1-KiB pieces of the T run: 3 (fp64) / 2 (fp32)
+    constexpr int kTileStride = kPiecesT * 1024 / (int)sizeof(TIN);          // elements between the two tiles: whole pieces (a piece's lanes past the run write zeros)
+    static_assert(2 * kTileStride * sizeof(TIN) <= 2 * kTileT * sizeof(double), "the two tiles must fit their LDS");
+    constexpr int NX = MODE == 2 ? 1 : 2;                  // dT/dt operands per point
+    constexpr unsigned ESZ = (unsigned)sizeof(TIN);
     __shared__ __attribute__((aligned(16))) double sm_all[G * kLdsDoubles];
     double* const sm = sm_all + (G > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0) * kLdsDoubles;
-    double* const tiles = sm;                              // 2 x [6 rows][W]: T of this level and of the next, each as it lies in memory
+    TIN* const tiles = reinterpret_cast<TIN*>(sm);         // 2 x [6 rows][W]: T of this level and of the next, each as it lies in memory
     double* const part = sm + 2 * kTileT;                  // [kHalf][kPS]: the lanes' partial sums of a level, ten statistics at a time
     double* const stash = part + kHalf * kPS;              // [kLB levels][kWR rows][kNA]: row totals waiting for their finishing lane
     double* const side = stash + kLB * kWR * kNA;          // [kLB levels][kWR rows][kSide]
@@ -165,14 +192,17 @@ __global__ void __launch_bounds__(64 * G, 2) lec_boxplane_kernel(const RowParams
     auto lev = [&](int k) -> size_t { return (size_t)min(max(k, 0), p.nl - 1) * plane; };
     // the wave's rows: box rows jb0 .. jb0 + 3 (cut at the box's last row); T also one row either side where the box has one
     const int h0 = max(jb0 - 1, 0), h1 = min(jb0 + kWR + 1, nyb), r1 = min(jb0 + kWR, nyb);
-    const unsigned bytesT = (unsigned)((h1 - h0) * W * 8), bytesF = (unsigned)((r1 - jb0) * W * 8);
-    const double* const gT = (const double*)p.T + (size_t)t * cube + (size_t)(js + h0) * W;
+    const unsigned bytesT = (unsigned)((h1 - h0) * W) * ESZ, bytesF = (unsigned)((r1 - jb0) * W) * ESZ;
+    const TIN* const gT = (const TIN*)p.T + (size_t)t * cube + (size_t)(js + h0) * W;
     const size_t fbase = (size_t)t * cube + (size_t)(js + jb0) * W;
-    const double* const gU = (const double*)p.U + fbase;
-    const double* const gV = (const double*)p.V + fbase;
-    const double* const gW = (const double*)p.W + fbase;
-    const double* const gP = (const double*)p.P + fbase;
-    const double* const gD = (const double*)p.DT + fbase;
+    const TIN* const gU = (const TIN*)p.U + fbase;
+    const TIN* const gV = (const TIN*)p.V + fbase;
+    const TIN* const gW = (const TIN*)p.W + fbase;
+    const TIN* const gP = (const TIN*)p.P + fbase;
+    const TIN* const gX0 = (const TIN*)(MODE == 2 ? p.DT : p.TM) + fbase;     // dT/dt itself, or T(t - 1) ...
+    const TIN* const gX1 = (const TIN*)(MODE == 2 ? p.DT : p.TP) + fbase;     // ... and T(t + 1) on this step's box
+    double ta = 0.0, tb = 0.0, tc = 0.0;
+    if (MODE == 1) { const double* tcf = p.tcoef + (size_t)t * 3; ta = tcf[0]; tb = tcf[1]; tc = tcf[2]; }
 
     // ---- lane roles: (row ci of the wave's four, column group cg of sixteen), columns 4 cg + q.  Lanes 0..31 hold groups 0..7 of all
     // four rows, lanes 32..63 groups 8..15: the 32 lanes that an LDS read serves together then touch 32 different 8-byte banks
@@ -185,7 +215,7 @@ __global__ void __launch_bounds__(64 * G, 2) lec_boxplane_kernel(const RowParams
     const int rT = (jbc - h0) * W + iw, rTm = (max(jbc - 1, 0) - h0) * W + iw, rTp = (min(jbc + 1, nyb - 1) - h0) * W + iw;
     // the lane's 32 bytes of a plane's run (its row 0 = box row jb0): columns 4 cg .. 4 cg + 3 of row ci.  Groups past the cube's last
     // column, and rows past the run, lie outside the resource: zeros
-    const unsigned offF = (unsigned)(((jb - jb0) * W + iw + 4 * cg) * 8);
+    const unsigned offF = (unsigned)((jb - jb0) * W + iw + 4 * cg) * ESZ;
     int col[4];
     bool zero[4], first[4], last[4];
 #pragma unroll
@@ -198,11 +228,11 @@ __global__ void __launch_bounds__(64 * G, 2) lec_boxplane_kernel(const RowParams
     // d/dlon of T at the lane's point q, centred; one-sided at the row ends (the point itself stands in for the missing neighbour, the
     // difference counts twice: lec_boxtile.hip's ((last ? T : Tr) - (first ? T : Tl)) * ((first || last) ? 2 : 1)).  The neighbours'
     // columns are formed where they are used: eight lane constants fewer in registers that the two prefetch sets need
-    auto ddlon = [&](const double* tile, int q) -> double {
+    auto ddlon = [&](const TIN* tile, int q) -> double {
 #pragma clang fp contract(off)
         int c = col[q];
         asm volatile("" : "+v"(c));
-        const double d = tile[rT + min(c + 1, nxb - 1)] - tile[rT + max(c - 1, 0)];
+        const double d = (double)tile[rT + min(c + 1, nxb - 1)] - (double)tile[rT + max(c - 1, 0)];
         return (first[q] || last[q]) ? d * 2.0 : d;
     };
     // coefficients of the lane's row (d/dlat a, b, c; 1 / dx) and of the wave's levels (one per lane: picked with v_readlane, so that
@@ -217,7 +247,8 @@ __global__ void __launch_bounds__(64 * G, 2) lec_boxplane_kernel(const RowParams
     // ---- the loads of one level: the T run as three flat pieces; the lane's 32 bytes of the five other planes into one of TWO register
     // sets, picked by the level's parity at compile time -- the planes of level k + 1 are requested BEFORE level k's are waited for, so a
     // wave has two levels in flight while it waits (as the bare load stream of the probe has) and one while it computes
-    dbl2_t tT[kPiecesT], fU[2][2], fV[2][2], fW[2][2], fP[2][2], fD[2][2];
+    u32x4_t tT[kPiecesT];
+    Quad<TIN> fU[2], fV[2], fW[2], fP[2], fX[2][NX];
     auto issue_T = [&](int kT) {
         if (LEC_BP_ABLATE & 2) return;
         const __amdgpu_buffer_rsrc_t rt = run_resource(gT + lev(kT), bytesT);
@@ -228,41 +259,36 @@ __global__ void __launch_bounds__(64 * G, 2) lec_boxplane_kernel(const RowParams
         constexpr int SET = decltype(set_tag)::value;
         if (LEC_BP_ABLATE & 2) return;
         const size_t lk = lev(kF);
-        const __amdgpu_buffer_rsrc_t ru = run_resource(gU + lk, bytesF), rv = run_resource(gV + lk, bytesF), rw = run_resource(gW + lk, bytesF),
-                                     rp = run_resource(gP + lk, bytesF), rd = run_resource(gD + lk, bytesF);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            fU[SET][h] = load16<LEC_BP_NT != 0>(ru, offF + 16u * h);
-            fV[SET][h] = load16<LEC_BP_NT != 0>(rv, offF + 16u * h);
-            fW[SET][h] = load16<LEC_BP_NT != 0>(rw, offF + 16u * h);
-            fP[SET][h] = load16<LEC_BP_NT != 0>(rp, offF + 16u * h);
-            fD[SET][h] = load16<LEC_BP_NT != 0>(rd, offF + 16u * h);
-        }
+        fU[SET].template load<LEC_BP_NT != 0>(run_resource(gU + lk, bytesF), offF);
+        fV[SET].template load<LEC_BP_NT != 0>(run_resource(gV + lk, bytesF), offF);
+        fW[SET].template load<LEC_BP_NT != 0>(run_resource(gW + lk, bytesF), offF);
+        fP[SET].template load<LEC_BP_NT != 0>(run_resource(gP + lk, bytesF), offF);
+        fX[SET][0].template load<LEC_BP_NT != 0>(run_resource(gX0 + lk, bytesF), offF);
+        if (NX > 1) fX[SET][NX - 1].template load<LEC_BP_NT != 0>(run_resource(gX1 + lk, bytesF), offF);
     };
-    auto tile_in = [&](double* tile, const dbl2_t (&xT)[kPiecesT]) {     // a T run into a tile, as it lies in memory (the tile's readers are done: one wave, LDS in order)
-        dbl2_t* dst = reinterpret_cast<dbl2_t*>(tile);
+    auto tile_in = [&](TIN* tile, const u32x4_t (&xT)[kPiecesT]) {     // a T run into a tile, as it lies in memory (the tile's readers are done: one wave, LDS in order)
+        u32x4_t* dst = reinterpret_cast<u32x4_t*>(tile);
 #pragma unroll
         for (int i = 0; i < kPiecesT; ++i) dst[64 * i + lane] = xT[i];
     };
     if (LEC_BP_ABLATE & 2) {
+        Quad<TIN> z; z.fill(280.0 + lane, 281.0);
 #pragma unroll
-        for (int i = 0; i < kPiecesT; ++i) { tT[i].x = 280.0 + lane; tT[i].y = 281.0 + i; }
+        for (int i = 0; i < kPiecesT; ++i) tT[i] = sizeof(TIN) == 8 ? reinterpret_cast<const Quad<double>&>(z).h[0] : reinterpret_cast<const Quad<float>&>(z).h;
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int z = 0; z < 2; ++z) { fU[z][h].x = lane; fU[z][h].y = h; fV[z][h] = fU[z][h]; fW[z][h].x = 0.1; fW[z][h].y = 0.2; fP[z][h] = fU[z][h]; fD[z][h] = fW[z][h]; }
+        for (int w = 0; w < 2; ++w) { fU[w].fill(lane, 1.0); fV[w].fill(lane, 2.0); fW[w].fill(0.1, 0.2); fP[w].fill(lane, 3.0); fX[w][0].fill(0.1, 0.2); fX[w][NX - 1].fill(0.1, 0.2); }
     }
 
     // ---- prologue: T(k0)'s tile, the lane's points of T(k0 - 1); the loads of level k0 and T(k0 + 1)'s run on their way
     double Tm[4];
     {
         const __amdgpu_buffer_rsrc_t rt = run_resource(gT + lev(k0), bytesT);
-        dbl2_t x[kPiecesT];
+        u32x4_t x[kPiecesT];
 #pragma unroll
         for (int i = 0; i < kPiecesT; ++i) x[i] = load16<false>(rt, 1024u * i + 16u * lane);
-        const double* g = (const double*)p.T + (size_t)t * cube + lev(k0 - 1) + (size_t)(js + jbc) * W + iw;
+        const TIN* g = (const TIN*)p.T + (size_t)t * cube + lev(k0 - 1) + (size_t)(js + jbc) * W + iw;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) Tm[q] = g[col[q]];
+        for (int q = 0; q < 4; ++q) Tm[q] = (double)g[col[q]];
         issue_F(std::integral_constant<int, 0>{}, k0);
         issue_T(k0 + 1);
         tile_in(tiles, x);
@@ -278,29 +304,29 @@ __global__ void __launch_bounds__(64 * G, 2) lec_boxplane_kernel(const RowParams
         double* const sd = side + (slot * kWR + ci) * kSide;
         // the next level's five planes into the other register set, then T(k + 1)'s run into the other tile and T(k + 2)'s run requested
         // (levels and tiles alternate together: SET is also the tile that holds T(k))
-        const double* const tileC = tiles + SET * kTileT;            // T(k): the lane's points and their four horizontal neighbours
-        double* const tileN = tiles + (SET ^ 1) * kTileT;            // T(k + 1): the lane's points
+        const TIN* const tileC = tiles + SET * kTileStride;          // T(k): the lane's points and their four horizontal neighbours
+        TIN* const tileN = tiles + (SET ^ 1) * kTileStride;          // T(k + 1): the lane's points
         if (k + 1 < k1) issue_F(std::integral_constant<int, SET ^ 1>{}, k + 1);
         tile_in(tileN, tT);
         if (k + 1 < k1) issue_T(k + 2);
-        const double Uq[4] = {fU[SET][0].x, fU[SET][0].y, fU[SET][1].x, fU[SET][1].y}, Vq[4] = {fV[SET][0].x, fV[SET][0].y, fV[SET][1].x, fV[SET][1].y},
-                     Wq[4] = {fW[SET][0].x, fW[SET][0].y, fW[SET][1].x, fW[SET][1].y}, Pq[4] = {fP[SET][0].x, fP[SET][0].y, fP[SET][1].x, fP[SET][1].y},
-                     Dq[4] = {fD[SET][0].x, fD[SET][0].y, fD[SET][1].x, fD[SET][1].y};
+        double Uq[4], Vq[4], Wq[4], Pq[4], X0q[4], X1q[4];
+        fU[SET].get(Uq); fV[SET].get(Vq); fW[SET].get(Wq); fP[SET].get(Pq); fX[SET][0].get(X0q); fX[SET][NX - 1].get(X1q);
         // the shifts of the other four planes: the row's first box element, which the lane of group 0 holds -- through the side array
-        if (first[0]) { sd[0] = tileC[rT]; sd[1] = Uq[0]; sd[2] = Vq[0]; sd[3] = Wq[0]; sd[4] = Pq[0]; }
+        if (first[0]) { sd[0] = (double)tileC[rT]; sd[1] = Uq[0]; sd[2] = Vq[0]; sd[3] = Wq[0]; sd[4] = Pq[0]; }
         row_sync<64>();
         if (!(LEC_BP_ABLATE & 1)) {
 #pragma clang fp contract(off)
             auto levc = [&](int e) -> double { return e < 64 ? lane_value(levv, e) : lane_value(levw, e - 64); };      // (wave-uniform choice)
             const double al = levc(3 * kk), be = levc(3 * kk + 1), gm = levc(3 * kk + 2);
-            const double cT = tileC[rT], cU = sd[1], cV = sd[2], cW = sd[3], cP = sd[4];
+            const double cT = (double)tileC[rT], cU = sd[1], cV = sd[2], cW = sd[3], cP = sd[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const double T = tileC[rT + col[q]], Tn = tileN[rT + col[q]];     // the lane's point at this level and one level down
-                const double U = Uq[q], V = Vq[q], Wv = Wq[q], P = Pq[q], D = Dq[q];
+                const double T = (double)tileC[rT + col[q]], Tn = (double)tileN[rT + col[q]];     // the lane's point at this level and one level down
+                const double U = Uq[q], V = Vq[q], Wv = Wq[q], P = Pq[q];
+                const double D = (MODE == 1) ? stencil3(ta, X0q[q], tc, X1q[q], tb, T) : X0q[q];     // dT/dt: lec_boxtile.hip's expression
                 const double sS = stencil3(al, Tm[q], gm, Tn, be, T);
                 const double adv = (U * cx) * ddlon(tileC, q);
-                const double sP_ = stencil3(ga, tileC[rTm + col[q]], gc, tileC[rTp + col[q]], gb, T);
+                const double sP_ = stencil3(ga, (double)tileC[rTm + col[q]], gc, (double)tileC[rTp + col[q]], gb, T);
                 const double f = fma(-Wv, sS, fma(V, sP_, D + adv));
                 const double a = T - cT, b = U - cU, c = V - cV, d = Wv - cW, ee = P - cP;
                 if (!zero[q]) accum20<true>(acc, 1.0, a, b, c, d, ee, f);
@@ -399,11 +425,13 @@ __global__ void __launch_bounds__(64 * G, 2) lec_boxplane_kernel(const RowParams
 // true where lec_boxplane_kernel serves the call (the KIND of call and the slabs' shape -- the same for every shard and chunk of a
 // series; never the boxes' extents or the step count)
 bool lec_boxplane_serves(const lec::RowParams& p, int dtype, bool uniform, int mode) {
-    return dtype == LEC_F64 && uniform && mode == 2 && p.DT && p.P && !p.TM && !p.TP && p.n_box != 1 && p.nx <= kMaxW && p.nxb_max <= kMaxW;
+    if (!uniform || !p.P || p.n_box == 1 || p.nx > kMaxW || p.nxb_max > kMaxW) return false;
+    if (mode == 2) return p.DT && !p.TM && !p.TP;                          // dT/dt as a cube: either storage type
+    return mode == 1 && dtype == LEC_F32 && p.TM && p.TP;                  // time neighbours as cubes of their own: a box-packed fp32 series
 }
 
 // p.tgroup: time steps per tile group, p.jgroup: levels per wave (< 1: chosen here; more than 21: LEC_ERR_ARG) -- as lec_launch_boxtile
-int lec_launch_boxplane(lec::RowParams p, hipStream_t st) {
+int lec_launch_boxplane(lec::RowParams p, int dtype, int mode, hipStream_t st) {
 #ifndef LEC_BP_GROUP      // measured (profiles/r06_notes.md): 2 and 4 waves per workgroup 0.76-0.78 ms per 512 steps against 0.757 for 1 -- no gain
 #define LEC_BP_GROUP 1
 #endif
@@ -431,6 +459,9 @@ int lec_launch_boxplane(lec::RowParams p, hipStream_t st) {
     const long long tgroups = (p.jchunk + p.tgroup - 1) / p.tgroup;
     const long long nblocks = 8LL * tgroups * p.tgroup * n_rb * n_kc;
     if (nblocks > 0x7fffffffLL) return LEC_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(lec_boxplane_kernel<G>, dim3((unsigned)nblocks), dim3(64 * G), 0, st, p);
+    const dim3 grid((unsigned)nblocks), block(64 * G);
+    if (dtype == LEC_F64) hipLaunchKernelGGL((lec_boxplane_kernel<double, 2, G>), grid, block, 0, st, p);
+    else if (mode == 2) hipLaunchKernelGGL((lec_boxplane_kernel<float, 2, G>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((lec_boxplane_kernel<float, 1, G>), grid, block, 0, st, p);
     return LEC_OK;
 }

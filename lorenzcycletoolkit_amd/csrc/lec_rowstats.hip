@@ -306,7 +306,7 @@ int lec_launch_rowblock(lec::RowParams p, int dtype, bool aligned, bool aligned8
 int lec_launch_boxtile(const lec::RowParams& p, int dtype, bool uniform, int mode, int tg, hipStream_t st);
 int lec_launch_qtime(const lec::RowParams& p, hipStream_t st);
 bool lec_boxplane_serves(const lec::RowParams& p, int dtype, bool uniform, int mode);
-int lec_launch_boxplane(lec::RowParams p, hipStream_t st);
+int lec_launch_boxplane(lec::RowParams p, int dtype, int mode, hipStream_t st);
 
 extern "C" int lec_max_row(int dtype, int aligned, int kernel) {
     (void)dtype;
@@ -359,7 +359,7 @@ extern "C" int lec_rowstats(const lec_rowstats_args* a) {
     const size_t esz = a->dtype == LEC_F32 ? 4 : 8;
     const int vecw = (int)(16 / esz);
     if (packed && (!tile_call || tu.block_shape > 1))
-        return lec_set_error(LEC_ERR_ARG, "lec_rowstats: a box-packed series runs on the box-tile kernel, one time step per workgroup");
+        return lec_set_error(LEC_ERR_ARG, "lec_rowstats: a box-packed series runs on the box-tile / box-plane kernels, one time step per workgroup");
     const void* cubes[8] = {a->tair_d, a->u_d, a->v_d, a->omega_d, a->geopt_d, a->dTdt_d, a->tm_d, a->tp_d};
     bool aligned = (a->nx % vecw) == 0, aligned8 = (a->nx % 2) == 0;
     for (const void* c : cubes) {
@@ -437,9 +437,9 @@ extern "C" int lec_rowstats(const lec_rowstats_args* a) {
         // the records are bit-identical to the box-tile kernel's anyway (tested)
         const bool plane_ok = a->box_per_step && tu.block_shape <= 1 && lec_boxplane_serves(pt, a->dtype, uni, wq);
         if (kernel == LEC_KERNEL_BOX_PLANE && !plane_ok)
-            return lec_set_error(LEC_ERR_ARG, "lec_rowstats: LEC_KERNEL_BOX_PLANE serves per-step boxes in fp64 storage with a dT/dt cube and geopotential on even "
-                                              "longitudes, cubes at most 64 columns wide");
-        if (plane_ok && (kernel == LEC_KERNEL_BOX_PLANE || tu.kernel == LEC_KERNEL_AUTO)) rc = lec_launch_boxplane(pt, st);
+            return lec_set_error(LEC_ERR_ARG, "lec_rowstats: LEC_KERNEL_BOX_PLANE serves per-step boxes with geopotential on even longitudes, cubes at most 64 columns wide, "
+                                              "dT/dt as a cube or (fp32 storage, box-packed) T of the two time neighbours as tm_d / tp_d");
+        if (plane_ok && (kernel == LEC_KERNEL_BOX_PLANE || tu.kernel == LEC_KERNEL_AUTO)) rc = lec_launch_boxplane(pt, a->dtype, wq, st);
         else rc = lec_launch_boxtile(pt, a->dtype, uni, wq, tu.block_shape, st);
     } else {
         // Single-sweep row kernels.  All terms with dT/dt from the cube on one fixed box (the headline configuration, mode 3): a

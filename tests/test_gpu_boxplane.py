@@ -34,12 +34,40 @@ def _series(dom, boxes, ny=None, nx=None):
     return eng, f, tc, ps, eng.prepare_boxes(boxes, packed=True)
 
 
-def _rows(eng, ps, pb, kernel, t0=0, t1=None, **tuning):
+def _dkw(ps, tc):
+    """dT/dt as the packed series carries it: a cube (fp64 storage), or T of the two time neighbours + the time coefficients (fp32)."""
+    return {"dTdt": ps["dTdt"]} if "dTdt" in ps else {"tm": ps["tm"], "tp": ps["tp"], "tcoef": tc}
+
+
+def _rows(eng, ps, pb, kernel, t0=0, t1=None, tc=None, **tuning):
     t1 = len(pb) if t1 is None else t1
-    r = eng.rowstats(ps["tair"], ps["u"], ps["v"], ps["omega"], ps["geopt"], pb.part(t0, t1), dTdt=ps["dTdt"], t_begin=t0, t_count=t1 - t0,
-                     per_step_boxes=True, tuning=dict(kernel=kernel, **tuning))
+    r = eng.rowstats(ps["tair"], ps["u"], ps["v"], ps["omega"], ps["geopt"], pb.part(t0, t1), t_begin=t0, t_count=t1 - t0,
+                     per_step_boxes=True, tuning=dict(kernel=kernel, **tuning), **_dkw(ps, tc))
     torch.cuda.synchronize()
     return r
+
+
+def test_fp32_series_with_time_neighbours_and_with_a_dtdt_cube():
+    """fp32 storage: the packed series of the moving framework carries T of the two time neighbours (no dT/dt cube: a float32 one would
+    not be the engine's fp64 dT/dt) -- every record of lec_boxtile's, shards too; and a caller's own float32 dT/dt cube is served as well."""
+    dom = synthetic_domain(9, 17, 70, 90, seed=32, dtype=np.float32)
+    boxes = [(10 + t, 70 + t, 5 + (t // 2), 60 + (t // 3)) for t in range(9)]
+    eng, f, tc, ps, pb = _series(dom, boxes)
+    assert "tm" in ps and ps["tair"].dtype == torch.float32
+    ref = _rows(eng, ps, pb, "box_tile", tc=tc)
+    for tj in (0, 5, 9, 17):
+        assert torch.equal(_rows(eng, ps, pb, "box_plane", tc=tc, tile_j=tj), ref), tj
+    auto = eng.rowstats(ps["tair"], ps["u"], ps["v"], ps["omega"], ps["geopt"], pb, per_step_boxes=True, **_dkw(ps, tc))
+    assert torch.equal(auto, ref) and torch.isfinite(ref).all()
+    assert torch.equal(_rows(eng, ps, pb, "box_plane", 2, 7, tc=tc), ref[2:7])
+    d32 = _dev(o.moving_dTdt(dom).astype(np.float32))
+    pk = {k: eng.pack_boxes(c, boxes) for k, c in zip(("tair", "u", "v", "omega", "geopt"), f)}
+    dp = eng.pack_boxes(d32, boxes)
+    kw = dict(dTdt=dp, per_step_boxes=True)
+    a = eng.rowstats(pk["tair"], pk["u"], pk["v"], pk["omega"], pk["geopt"], pb, tuning={"kernel": "box_tile"}, **kw)
+    b = eng.rowstats(pk["tair"], pk["u"], pk["v"], pk["omega"], pk["geopt"], pb, tuning={"kernel": "box_plane"}, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
 
 
 def test_config5_shape_bit_identical_and_against_the_oracle():
@@ -62,14 +90,17 @@ def test_config5_shape_bit_identical_and_against_the_oracle():
     compare(res.scalars_dict(), res.levels_dict(), ref_s, ref_l, 1e-9, "box-plane kernel vs oracle", time_s=dom.time_s)
 
 
-def test_random_geometries_bit_identical():
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_random_geometries_bit_identical(dtype):
     """Boxes from 2 x 2 to 64 x 90 points anywhere in the grid, 2 .. 45 levels, 2 .. 19 steps with another box each, slabs with and
-    without room to spare (odd and even pitches: the DMA pieces then start on 8- and on 16-byte boundaries), random level chunks."""
+    without room to spare (odd and even pitches: the runs then start on 4-, 8- and 16-byte boundaries), random level chunks.  fp64
+    storage: dT/dt as a cube; fp32 storage: T of the two time neighbours as cubes of their own -- the box-packed series the product's
+    -t paths hand over for either kind of data."""
     rng = np.random.default_rng(606)
     for case in range(40):
         nt, nl = int(rng.integers(2, 20)), int(rng.integers(2, 46))
         ny, nx = int(rng.integers(8, 110)), int(rng.integers(8, 90))
-        dom = synthetic_domain(nt, nl, ny, nx, seed=6000 + case)
+        dom = synthetic_domain(nt, nl, ny, nx, seed=6000 + case, dtype=dtype)
         boxes = []
         for _ in range(nt):
             wx, wy = int(rng.integers(2, min(nx, 64) + 1)), int(rng.integers(2, min(ny, 90) + 1))
@@ -79,7 +110,7 @@ def test_random_geometries_bit_identical():
         pad = case % 3
         eng, f, tc, ps, pb = _series(dom, boxes, ny=min(ny, hmax + pad), nx=min(nx, 64, wmax + pad))
         tj = int(rng.integers(0, min(nl, 42) + 1))
-        ref, got = _rows(eng, ps, pb, "box_tile", tile_j=min(tj, 21)), _rows(eng, ps, pb, "box_plane", tile_j=tj)
+        ref, got = _rows(eng, ps, pb, "box_tile", tc=tc, tile_j=min(tj, 21)), _rows(eng, ps, pb, "box_plane", tc=tc, tile_j=tj)
         assert torch.equal(got, ref), f"case {case}: nt={nt} nl={nl} grid {ny}x{nx} slab {tuple(ps['tair'].shape[2:])} tile_j={tj} boxes {boxes}"
         for t, bx in enumerate(boxes):
             assert torch.all(got[t, :, bx[3] - bx[2] + 1:] == 0), (case, t)
@@ -128,8 +159,8 @@ def test_nans_travel_as_in_the_box_tile_kernel():
 
 
 def test_box_plane_refuses_what_it_does_not_serve():
-    """Asked for by name the kernel must run or say no -- never another kernel silently: fp32 storage, stretched longitudes, cubes wider
-    than 64 columns, dT/dt from the time neighbours, a fixed box."""
+    """Asked for by name the kernel must run or say no -- never another kernel silently: stretched longitudes, cubes wider than 64
+    columns, dT/dt from the cube's own time axis, fp64 time neighbours, a fixed box."""
     dom = synthetic_domain(3, 4, 20, 30, seed=1)
     boxes = [(2, 20, 3, 15)] * 3
     eng, f, tc, ps, pb = _series(dom, boxes)
@@ -142,11 +173,10 @@ def test_box_plane_refuses_what_it_does_not_serve():
     f2 = [_dev(a) for a in (wide.tair, wide.u, wide.v, wide.omega, wide.geopt)]
     with pytest.raises(ValueError, match="BOX_PLANE"):
         eng2.rowstats(*f2, boxes, dTdt=_dev(o.moving_dTdt(wide)), per_step_boxes=True, tuning={"kernel": "box_plane"})
-    d32 = synthetic_domain(3, 4, 20, 30, seed=1, dtype=np.float32)
-    eng3 = _engine(d32)
-    f3 = [_dev(a) for a in (d32.tair, d32.u, d32.v, d32.omega, d32.geopt)]
+    # fp64 storage with the time neighbours as operands (six 32-byte operands per prefetch set): lec_boxtile's
+    tm, tp = eng.pack_boxes(f[0], boxes, shift=-1), eng.pack_boxes(f[0], boxes, shift=1)
     with pytest.raises(ValueError, match="BOX_PLANE"):
-        eng3.rowstats(*f3, boxes, dTdt=_dev(o.moving_dTdt(d32).astype(np.float32)), per_step_boxes=True, tuning={"kernel": "box_plane"})
+        eng.rowstats(ps["tair"], ps["u"], ps["v"], ps["omega"], ps["geopt"], pb, tm=tm, tp=tp, tcoef=tc, per_step_boxes=True, tuning={"kernel": "box_plane"})
     st = synthetic_domain(3, 4, 20, 30, seed=1, nonuniform_lon=True)
     eng4 = _engine(st)
     f4 = [_dev(a) for a in (st.tair, st.u, st.v, st.omega, st.geopt)]

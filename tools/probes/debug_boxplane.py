@@ -6,14 +6,15 @@ from tests.helpers import synthetic_domain
 from lorenzcycletoolkit_amd.engine import LECEngine
 
 nt, nl = int(sys.argv[1]) if len(sys.argv) > 1 else 3, int(sys.argv[2]) if len(sys.argv) > 2 else 7
-dom = synthetic_domain(nt, nl, 100, 140, seed=61)
+dtype = np.float32 if (len(sys.argv) > 3 and sys.argv[3] == "f32") else np.float64
+dom = synthetic_domain(nt, nl, 100, 140, seed=61, dtype=dtype)
 boxes = [(20 + t, 80 + t, 15 + (t // 2), 75 + (t // 2)) for t in range(nt)]
 eng = LECEngine(dom.lat, dom.lon, dom.level, device="cuda:0")
 f = [torch.as_tensor(np.ascontiguousarray(a)).to("cuda:0") for a in (dom.tair, dom.u, dom.v, dom.omega, dom.geopt)]
 tc = eng.time_coefs_device(dom.time_s)
 ps = eng.pack_series(*f, boxes, tc)
 pb = eng.prepare_boxes(boxes, packed=True)
-kw = dict(dTdt=ps["dTdt"], per_step_boxes=True)
+kw = dict(per_step_boxes=True, **({"dTdt": ps["dTdt"]} if "dTdt" in ps else {"tm": ps["tm"], "tp": ps["tp"], "tcoef": tc}))
 a = eng.rowstats(ps["tair"], ps["u"], ps["v"], ps["omega"], ps["geopt"], pb, tuning={"kernel": "box_tile"}, **kw)
 b = eng.rowstats(ps["tair"], ps["u"], ps["v"], ps["omega"], ps["geopt"], pb, tuning={"kernel": "box_plane"}, **kw)
 torch.cuda.synchronize()
