@@ -555,13 +555,17 @@ __global__ void __launch_bounds__(64 * TG, (TG == 4 && !UNIFORM) ? 1 : 2) lec_bo
             // (the epilogue's lane arithmetic and its scale factors are made opaque here: hoisted out of the pass loop as loop invariants
             // they cost the shipped instantiation three spilled registers, reloaded from scratch in every pass -- this branch runs once
             // per four levels)
+            // Round 6: the records go to LDS first (the hand-over array is free) and ALL lanes store them, sixteen lanes per 256-byte
+            // record -- whole lines; one record per lane straight to memory is 13 store instructions of sixteen 16-byte pieces in sixteen
+            // different lines each (lec_boxplane.hip: 0.767 -> 0.753 ms per 512 steps).
+            constexpr int kRS = LEC_NSTAT + 2;           // record stride in the buffer (doubles): 16-byte aligned, eight lanes' 16-byte writes on different banks
+            static_assert(kLB * kWR * kRS <= kNA * kPS, "the finished records must fit the hand-over array");
             int ln = lane;
             asm volatile("" : "+v"(ln));
             const int lv = ln >> 2, r = ln & 3;
             const int jb = jb0 + r;
             if (lv <= slot && jb >= 0 && jb < p.nyb_max && live) {
-                const int kout = k - slot + lv;
-                dbl2_t* __restrict__ out = reinterpret_cast<dbl2_t*>(p.rows + ((size_t)(tl * p.nl + kout) * p.nyb_max + jb) * LEC_NSTAT);
+                dbl2_t* __restrict__ out = reinterpret_cast<dbl2_t*>(part + (lv * kWR + r) * kRS);
                 // (few values live at a time: the epilogue runs while two passes' loads are in flight in registers)
                 if (jb >= nyb) {                 // padding row of a box lower than nyb_max
 #pragma unroll
@@ -592,6 +596,16 @@ __global__ void __launch_bounds__(64 * TG, (TG == 4 && !UNIFORM) ? 1 : 2) lec_bo
                     e2.x = sr[1]; e2.y = sr[13]; out[LEC_S_UW / 2] = e2;
                     e2.x = sr[2]; e2.y = sr[14]; out[LEC_S_VW / 2] = e2;
                     e2.x = 0.0; e2.y = 0.0; out[LEC_S_SPARE / 2] = e2; out[LEC_S_SPARE / 2 + 1] = e2;
+                }
+            }
+            row_sync<64>();
+#pragma unroll
+            for (int i = 0; i < kLB * kWR * (LEC_NSTAT / 2) / 64; ++i) {
+                const int e = 64 * i + lane, rec = e >> 4, piece = e & 15;      // record (level slot, row) and the lane's 16 bytes of it
+                const int rl = rec >> 2, jr = jb0 + (rec & 3);
+                if (rl <= slot && jr >= 0 && jr < p.nyb_max && live) {
+                    const dbl2_t v2 = *reinterpret_cast<const dbl2_t*>(part + rec * kRS + 2 * piece);
+                    reinterpret_cast<dbl2_t*>(p.rows + ((size_t)(tl * p.nl + (k - slot + rl)) * p.nyb_max + jr) * LEC_NSTAT)[piece] = v2;
                 }
             }
             row_sync<64>();
