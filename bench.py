@@ -669,8 +669,8 @@ def measure(args, ctx, cpu_kind="none"):
         per_pass = ctx.reduce_max(per_pass)
         producer = {"pack": per_pass[0], "dtdt": per_pass[1], "total": per_pass[0] + per_pass[1],
                     "unit": "ms per pass over a rank's shard, HIP events, max over ranks",
-                    "pack_is": "the per-step gathers out of the crop (5 fields + T of the two time neighbours; torch advanced indexing here, lec_ingest's "
-                               "gather in the product's streamed path)",
+                    "pack_is": "the per-step gathers out of the crop (5 fields + T of the two time neighbours): LECEngine.pack_boxes = lec_ingest with "
+                               "per-step origins, the gather the product's streamed path runs",
                     "dtdt_is": ("lec_dtdt: dT/dt of the packed series as an fp64 cube" if args.storage == "f64" else "none: fp32 storage hands T of the two neighbours over"),
                     "how": ("the second of two productions before the timed passes (ranks share a GPU: the crop is not kept beside the series; the other ranks' work runs on the same GPU meanwhile)"
                             if (resident and not crop) else "re-produced 3 times from the resident crop after the timed passes (median)" if resident else
