@@ -76,6 +76,36 @@ def test_bench_starts_its_own_ranks_and_counts_them():
         assert k in sg, k
 
 
+def test_bench_under_the_drivers_launch_line(tmp_path):
+    """The driver's own N > 1 launch: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N --steps K --warmup W` -- the launcher's environment names the ranks, bench.py starts nobody, rank 0
+    prints the one line with both strong-scaling legs in it (gloo here: both ranks share this box's one GPU)."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    n1 = str(tmp_path / "n1.json")
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e["LEC_DIST_BACKEND"] = "gloo"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--timesteps", "3", "--ny", "61", "--nx", "128",
+           "--cpu-baseline", "quick", "--leg-timesteps", "12,16", "--n1-file", n1]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=e)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    c = d["config"]
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and c["timesteps_global"] == 6
+    assert c["backend"] == "gloo" and c["rccl_ranks_seen"] == 2 and c["peer_blocks_ok"] is True and c["gathered_series_ok"] is True
+    assert d["cpu_baseline"]["value"] > 0 and d["parity"]["ok"] is True
+    legs = c["strong_scaling"]
+    assert set(legs) == {"config4", "config5"} and all(legs[k]["results_finite"] and legs[k]["peer_blocks_ok"] for k in legs)
+    assert legs["config4"]["timesteps_global"] == 12 and legs["config5"]["timesteps_global"] == 16 and "producer_ms" in legs["config5"]
+
+
 def test_a_two_rank_line_carries_the_cpu_leg_and_the_parity_of_rank_0():
     """north_star: the N-GPU throughput "next to the reference CPU path timed on the node's own host cores in the same run".  Rank 0 runs
     the oracle after the timed region while rank 1 waits in the closing barrier; `parity` is rank 0's shard against the oracle."""
